@@ -1,0 +1,210 @@
+"""Seeded synthetic artefacts in the reference's on-disk formats.
+
+The reference ships no weights, lexicon or test data ("zero
+data/weights"), and its corpus tooling needs the licensed BCCWJ corpus, so the
+build generates stand-ins with the same file formats:
+
+* ``data/lexicon.pkl``      list of ``(word, freq)`` sorted by (-freq, word)
+                            (reference data.py:33,44); ``word`` is
+                            ``display/reading/POS`` or ``<eos>``.
+* ``data/reading_dict.pkl`` dict reading -> list of lexicon indices
+                            (reference data.py:57-76,86).
+* ``data/test.txt``         one sentence per line, tokens separated by a blank
+                            (read by reference decoder/eval.py:141-166).
+* ``train/experiments/<id>/config.json``   keys used at inference
+                            (reference decoder/model.py:39-71).
+* ``train/experiments/<id>/weights/lstm_weights.pkl`` dict of float32 arrays
+                            (reference train/weights.py:30-74).
+
+Everything is drawn from ``numpy.random.RandomState(seed)`` whose stream is
+stable across numpy versions, so the same seeds regenerate the same artefacts
+in this container and on the GPU box; only *outputs* are committed as golden
+vectors.  Parameters follow SURVEY.md section 8(d).
+"""
+import json
+import os
+import pickle
+
+import numpy as np
+
+KANA = [chr(0x30A1 + i) for i in range(80)]
+READING_LEN_P = (0.05, 0.30, 0.40, 0.25)
+README_SEGS = [(200, 0, 12000), (100, 12000, 30000), (50, 30000, None)]
+
+
+def make_lexicon(vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
+    """-> (lexicon, reading_dict).  ``<eos>`` is the most frequent entry; the
+    first ``vocab_size-1`` entries are in-vocabulary, the ``oov_frac`` tail is
+    not (exercises the skip at reference decoder/decoder.py:99-103)."""
+    rng = np.random.RandomState(seed)
+    n_words = int(round(vocab_size * (1.0 + oov_frac)))
+    lens = rng.choice([1, 2, 3, 4], size=n_words, p=READING_LEN_P)
+    chars = rng.randint(0, alphabet, size=(n_words, 4))
+    top = n_words + 10
+    lexicon = [("<eos>", top + 1)]
+    for i in range(n_words):
+        reading = "".join(KANA[c] for c in chars[i, : lens[i]])
+        lexicon.append(("w%d/%s/N" % (i, reading), top - i))
+    reading_dict = {}
+    for i, (word, _) in enumerate(lexicon):
+        tokens = word.split("/")
+        if len(tokens) < 3:
+            continue
+        reading = tokens[1] if tokens[1] != "" else tokens[0]
+        reading_dict.setdefault(reading, []).append(i)
+    return lexicon, reading_dict
+
+
+def write_lexicon(root, vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
+    lexicon, reading_dict = make_lexicon(vocab_size, seed, oov_frac, alphabet)
+    d = os.path.join(root, "data")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "lexicon.pkl"), "wb") as f:
+        pickle.dump(lexicon, f)
+    with open(os.path.join(d, "reading_dict.pkl"), "wb") as f:
+        pickle.dump(reading_dict, f)
+    return lexicon, reading_dict
+
+
+def make_config(vocab_size, hidden, embed, mode="tied", segs=None, self_norm=False):
+    """config.json content.  ``mode``: tied | untied | dsoftmax | vtable."""
+    assert mode in ("tied", "untied", "dsoftmax", "vtable")
+    cfg = {
+        "vocab_size": int(vocab_size),
+        "hidden_size": int(hidden),
+        "embed_size": int(embed),
+        "share_embedding": mode != "untied",
+        "D_softmax": mode == "dsoftmax",
+        "V_table": mode == "vtable",
+        "embedding_seg": [list(s) for s in (segs if segs is not None else README_SEGS)],
+        "self_norm": bool(self_norm),
+        "char_rnn": False,
+    }
+    return cfg
+
+
+def make_weights(cfg, seed=7, scale=0.05):
+    """Weight dict with the key names / shapes of reference train/weights.py:30-55
+    (shapes from reference train/model.py:137-150,188-193,57-60)."""
+    rng = np.random.RandomState(seed)
+
+    def w(*shape):
+        return rng.normal(0.0, scale, size=shape).astype(np.float32)
+
+    V, H = cfg["vocab_size"], cfg["hidden_size"]
+    segs = cfg["embedding_seg"]
+    if cfg["V_table"]:
+        E = segs[0][0]                       # reference train/model.py:53
+    elif cfg["D_softmax"]:
+        E = sum(s[0] for s in segs)          # reference train/model.py:77
+    else:
+        E = cfg["embed_size"]
+    weights = {}
+    for g in "ifog":
+        weights["HM" + g] = w(H, H)
+    for g in "ifog":
+        weights["IM" + g] = w(E, H)
+    for g in "ifog":
+        weights["b" + g] = w(H)
+    weights["b2"] = w(V)
+    if cfg["share_embedding"]:
+        weights["PM"] = w(H, E)
+    else:
+        weights["UM"] = w(H, V)
+    if cfg["V_table"]:
+        for i, (size, s, e) in enumerate(segs):
+            e = V if e is None else e
+            weights["LM%d" % i] = w(e - s, size)
+            if i != 0:
+                weights["VT%d" % i] = w(size, E)
+    elif cfg["D_softmax"]:
+        blocks = []
+        for size, s, e in segs:
+            e = V if e is None else e
+            blocks.append(w(e - s, size))
+        weights["LM"] = blocks
+    else:
+        weights["LM"] = w(V, E)
+    return weights
+
+
+def write_experiment(root, exp_id, cfg, seed=7, scale=0.05):
+    d = os.path.join(root, "train", "experiments", str(exp_id))
+    os.makedirs(os.path.join(d, "weights"), exist_ok=True)
+    with open(os.path.join(d, "config.json"), "wt") as f:
+        f.write(json.dumps(cfg))
+    weights = make_weights(cfg, seed, scale)
+    with open(os.path.join(d, "weights", "lstm_weights.pkl"), "wb") as f:
+        pickle.dump(weights, f)
+    return weights
+
+
+def make_sentences(n, length, seed=99, alphabet=80):
+    """Uniform random kana strings of the stated length."""
+    rng = np.random.RandomState(seed)
+    idx = rng.randint(0, alphabet, size=(n, length))
+    return ["".join(KANA[c] for c in row) for row in idx]
+
+
+def make_ragged_sentences(n, min_len, max_len, seed=99, alphabet=80):
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(min_len, max_len + 1, size=n)
+    return ["".join(KANA[c] for c in rng.randint(0, alphabet, size=l)) for l in lens]
+
+
+def make_test_corpus(lexicon, vocab_size, n, words_per_sentence=6, seed=5, oov_every=0):
+    """Lines for data/test.txt: concatenations of random in-vocabulary words so
+    that an eval target exists.  ``oov_every``>0 inserts an
+    out-of-vocabulary word into every such line (those lines are skipped by
+    the harness, reference decoder/eval.py:131-143)."""
+    rng = np.random.RandomState(seed)
+    lines = []
+    for j in range(n):
+        ids = rng.randint(1, vocab_size - 1, size=words_per_sentence)
+        toks = [lexicon[i][0] for i in ids]
+        if oov_every and j % oov_every == oov_every - 1:
+            toks[len(toks) // 2] = lexicon[len(lexicon) - 1 - (j % 7)][0]
+        lines.append(" ".join(toks))
+    return lines
+
+
+def write_test_corpus(root, lexicon, vocab_size, n, words_per_sentence=6, seed=5, oov_every=0):
+    lines = make_test_corpus(lexicon, vocab_size, n, words_per_sentence, seed, oov_every)
+    d = os.path.join(root, "data")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "test.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+    return lines
+
+
+# Named fixture recipes shared by tests, golden-vector generation and bench.
+def small_segs(V):
+    return [(32, 0, V // 4), (16, V // 4, (3 * V) // 5), (8, (3 * V) // 5, None)]
+
+
+def build_fixture(root, name, exp_id=1):
+    """Materialise one named fixture under ``root``; returns (cfg, lexicon,
+    reading_dict, alphabet).  The small fixtures use a 12-kana alphabet so
+    that their 2 200-word lexicon still gives a dense lattice.  Names:
+
+      small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
+      mid-tied / mid-vtable                       V=50000 H=512 (configs 1 / 2)
+      big-tied                                    V=100000 H=512 E=256 (config 3)
+    """
+    parts = name.split("-")
+    size, mode = parts[0], parts[1]
+    self_norm = len(parts) > 2 and parts[2] == "sn"
+    alphabet, scale = 80, 0.05
+    if size == "small":
+        scale = 0.25                      # keeps the tiny model's logits O(1)
+        V, H, E, segs, alphabet = 2000, 64, 32, small_segs(2000), 12
+    elif size == "mid":
+        V, H, E, segs = 50000, 512, 256, README_SEGS
+    elif size == "big":
+        V, H, E, segs = 100000, 512, 256, README_SEGS
+    else:
+        raise ValueError(name)
+    cfg = make_config(V, H, E, mode, segs, self_norm)
+    lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet)
+    write_experiment(root, exp_id, cfg, scale=scale)
+    return cfg, lexicon, reading_dict, alphabet

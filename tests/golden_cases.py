@@ -1,0 +1,74 @@
+"""Case list shared by tools/make_golden.py (which runs the REFERENCE in the
+build container) and the tests (which replay the same seeded inputs through
+the oracle / the HIP path).  Only outputs are committed under tests/golden/."""
+import numpy as np
+
+from jlm_amd import synth
+
+LM_FIXTURES = ["small-tied", "small-untied", "small-dsoftmax", "small-vtable", "small-tied-sn",
+               "mid-tied", "mid-vtable"]
+LM_ROWS = [1, 10]
+LM_STEPS = 3
+LM_NCOLS = 256
+LM_SUBSET = 300
+
+
+def lm_inputs(cfg, rows, seed=11):
+    """index lists for LM_STEPS consecutive steps, the sorted vocab subset and
+    the sampled logit columns."""
+    rng = np.random.RandomState(seed + rows)
+    V = cfg["vocab_size"]
+    idx = [[int(x) for x in rng.randint(0, V, size=rows)] for _ in range(LM_STEPS)]
+    subset = sorted(int(x) for x in rng.choice(V, size=LM_SUBSET, replace=False))
+    cols = np.sort(rng.choice(V, size=LM_NCOLS, replace=False))
+    h0 = rng.normal(0, 0.3, size=(rows, cfg["hidden_size"]))
+    c0 = rng.normal(0, 0.3, size=(rows, cfg["hidden_size"]))
+    return idx, subset, cols, h0, c0
+
+
+# (case name, fixture, decoder kind, decode kwargs, sentence spec)
+# sentence spec: ("ragged", n, min_len, max_len, seed) | ("fixed", n, length, seed)
+DECODE_CASES = [
+    ("small-tied/static", "small-tied", "static", dict(beam_width=10), ("ragged", 12, 1, 20, 3)),
+    ("small-tied/static-b3", "small-tied", "static", dict(beam_width=3, topN=5), ("ragged", 8, 1, 16, 4)),
+    ("small-tied/static-vs", "small-tied", "static", dict(beam_width=10, vocab_select=True), ("ragged", 12, 1, 20, 3)),
+    ("small-tied/static-vs-top", "small-tied", "static",
+     dict(beam_width=10, vocab_select=True, samples=50, top_sampling=True), ("ragged", 6, 2, 14, 5)),
+    ("small-tied/static-vs-rand", "small-tied", "static",
+     dict(beam_width=10, vocab_select=True, samples=30, random_sampling=True), ("ragged", 6, 2, 14, 6)),
+    ("small-tied-sn/static", "small-tied-sn", "static", dict(beam_width=10), ("ragged", 8, 1, 16, 7)),
+    ("small-untied/static", "small-untied", "static", dict(beam_width=10), ("ragged", 8, 1, 16, 8)),
+    ("small-dsoftmax/static", "small-dsoftmax", "static", dict(beam_width=10), ("ragged", 8, 1, 16, 9)),
+    ("small-dsoftmax/static-vs", "small-dsoftmax", "static", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 9)),
+    ("small-vtable/static", "small-vtable", "static", dict(beam_width=10), ("ragged", 8, 1, 16, 10)),
+    ("small-vtable/static-vs", "small-vtable", "static", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 10)),
+    ("small-tied/dynamic", "small-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 12, 1, 20, 3)),
+    ("small-tied/dynamic-b4", "small-tied", "dynamic", dict(beam_width=4, vocab_select=True), ("ragged", 8, 1, 16, 4)),
+    ("small-tied/dynamic-top", "small-tied", "dynamic",
+     dict(beam_width=10, vocab_select=True, samples=20, top_sampling=True), ("ragged", 6, 2, 14, 5)),
+    ("small-tied-sn/dynamic", "small-tied-sn", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 7)),
+    # BASELINE.json configs[0]: 100 sentences, beam 10, V=50k, tied softmax
+    ("mid-tied/static", "mid-tied", "static", dict(beam_width=10), ("fixed", 100, 20, 99)),
+    ("mid-tied/static-vs", "mid-tied", "static", dict(beam_width=10, vocab_select=True), ("fixed", 24, 20, 98)),
+    ("mid-tied/dynamic", "mid-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 24, 20, 98)),
+    ("mid-vtable/static", "mid-vtable", "static", dict(beam_width=10), ("fixed", 24, 20, 97)),
+    ("big-tied/static-b20", "big-tied", "static", dict(beam_width=20), ("fixed", 4, 20, 96)),
+]
+
+RANDOM_SAMPLING_SEED = 123
+TRACE_SENTENCES = 4          # per case: frame-by-frame beams kept for the first few sentences
+
+
+def case_sentences(spec, alphabet):
+    if spec[0] == "ragged":
+        _, n, lo, hi, seed = spec
+        return synth.make_ragged_sentences(n, lo, hi, seed=seed, alphabet=alphabet)
+    _, n, length, seed = spec
+    return synth.make_sentences(n, length, seed=seed, alphabet=alphabet)
+
+
+EVAL_CASES = [
+    ("small-tied/eval-static", "small-tied", ["-e", "1", "-es", "20", "-b", "10"]),
+    ("small-tied/eval-dynamic", "small-tied", ["-e", "1", "-es", "12", "-b", "10", "-vs", "True", "-dd", "True"]),
+]
+EVAL_CORPUS = dict(n=30, words_per_sentence=5, seed=5, oov_every=6)
