@@ -1,0 +1,190 @@
+/*
+ * jlm_hip.h -- C ABI of libjlm_hip.so, the MI355X (gfx950) implementation of
+ * JLM's LSTM inference + lattice beam-search hot path.
+ *
+ * The reference has no FFI of its own: the path is pure Python over numpy
+ * (decoder/model.py, decoder/decoder.py, decoder/decoder_dynamic.py).  Each
+ * entry point below therefore replaces a group of numpy / Python statements of
+ * the reference, cited as file:line.  The Python classes in jlm_amd/ keep the
+ * reference's signatures and call these through ctypes (INTEGRATION.md shows
+ * the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed call
+ *     (or -1 for an argument the kernels cannot handle, e.g. K % 4 != 0);
+ *   - matrices are float32, row-major, leading dimension in floats, a multiple
+ *     of 4, base pointers 16-byte aligned; scores are float64;
+ *   - "rows" are beam hypotheses.  A hypothesis lives in global row
+ *         g = frame * rmax + sentence * beam + slot,  rmax = nsent * beam,
+ *     and all per-hypothesis arrays (score, lse, bp, node, word, h, c, T) are
+ *     indexed by g.  `live` lists (compact r -> g) name the rows a frame steps.
+ *   - counts that exist only on the device (number of live rows of a frame)
+ *     are passed as `const int *n_dev`; kernels launched for the static upper
+ *     bound exit early past *n_dev.
+ */
+#ifndef JLM_HIP_H
+#define JLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
+#define JLM_ABI_VERSION 1
+int jlm_abi_version(void);
+/* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
+int jlm_device_arch(int dev, char *buf, int buflen);
+
+/* ------------------------------------------------------------------------
+ * K1+K2+K3+K9: embedding gather, fused gate GEMM, sigmoid/tanh, state update.
+ * Replaces LSTM_Model._lstm_cell (decoder/model.py:125-139) and the state
+ * gather/scatter of Decoder._batch_predict (decoder/decoder.py:206-218).
+ *
+ * For compact row r < min(n_rows_max, *n_dev):   g = rows ? rows[r] : r
+ *   p = prev[g] (row whose state is consumed; <0 means zero state)
+ *   x = [ h[p, 0:H] | emb[word[g], 0:E] ]
+ *   z = x . Wt^T + bias     Wt is the packed [4H, kpad] gate matrix
+ *   c[g] = c[p]*sig(z_f) + tanh(z_g)*sig(z_i) ;  h[g] = tanh(c[g])*sig(z_o)
+ * Packed gate layout (jlm_amd/model.py packs it): row n of Wt / bias is
+ *   n = (u / 32) * 128 + gate * 32 + (u % 32), gate order i,f,o,g
+ * with Wt[n, 0:H] = HM_gate[:, u], Wt[n, H:H+E] = IM_gate[:, u], zero padded to
+ * kpad (multiple of 32).  Requires H % 32 == 0, E % 4 == 0.
+ */
+int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state,
+                  float *h_out, float *c_out,
+                  const int *rows, const int *prev, const int *word,
+                  const float *emb, int ld_emb,
+                  const float *wt, const float *bias, int kpad,
+                  int H, int E, int n_rows_max, const int *n_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K4 / generic NT GEMM with optional row gathers and column bias:
+ *   C[c_rows[m], n] = sum_k A[a_rows[m], k] * B[b_rows[n], k] + bias[n]
+ * Replaces np.dot(hidden, PM) (model.py:145,162,184,186), the V_table
+ * projections np.dot(temp, VT.T) (model.py:175,177) and, with b_rows = vocab,
+ * the materialised logits of LSTM_Model.project (model.py:141-193).
+ * NULL row maps mean identity; bias may be NULL.  K % 4 == 0.
+ */
+int jlm_gemm_nt(const float *A, int lda, const int *a_rows,
+                const float *B, int ldb, const int *b_rows,
+                float *C, int ldc, const int *c_rows, const float *bias,
+                int M, int N, int K, const int *m_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * K5+K6 fused: one vocabulary segment's logits are produced tile by tile on
+ * the MFMA pipe and reduced on the fly to per-row (max, sum exp) partials; the
+ * [rows, V] logits never reach HBM.  Replaces the full-vocabulary branch of
+ * LSTM_Model.project + softmax (model.py:141-193,15-20).
+ *   logit[v, r] = sum_k Bseg[v, k] * T[rows[r], k] + bias[v]   v < n_vocab
+ *   part[(tile0 + v/128) * ld_part + r] = (max_v, sum_v exp(logit - max)) over the tile
+ * Returns the number of vocab tiles used (>=0) or a negative error.
+ */
+int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, int K,
+                           const float *T, int ldt, const int *rows,
+                           const float *bias, float *part, int ld_part, int tile0,
+                           int n_rows_max, const int *n_dev, void *stream);
+/* lse[g] = log sum exp over n_tiles partials, float64;  g = rows[r]. */
+int jlm_lse_combine(const float *part, int ld_part, int n_tiles,
+                    const int *rows, double *lse,
+                    int n_rows_max, const int *n_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Vocabulary segments for word-addressed logits (tied softmax: one segment;
+ * D-softmax / D-softmax*: model.py:144-181).  Host struct, copied per call.
+ */
+typedef struct {
+    int v_start, v_end;      /* word ids [v_start, v_end) */
+    int k;                   /* contraction length (multiple of 4 after padding) */
+    int t_off;               /* column offset of this segment's input inside T */
+    const float *B;          /* [v_end - v_start, ldb] block, device */
+    int ldb;
+} jlm_segment;
+#define JLM_MAX_SEGMENTS 8
+
+/* Word-list groups: one per (sentence, frame).  Group j covers hypothesis rows
+ * g0[j] .. g0[j]+cnt[cnt_idx[j]]-1 and the word list number l = wl_base +
+ * wl_idx[j], i.e. words wl[wl_off[l] .. wl_off[l+1]). */
+
+/* K7 operand: logits of the lattice edges leaving a frame.  For every group j,
+ * word position i in its list and beam slot k:
+ *   edge[wl_out[i] * beam + k] = T[g0+k] . B[w_i] + b2[w_i]
+ * (wl_out = lattice node id of the edge).  Replaces the indexing
+ * pred[node.word_idx] of Path.append_node (decoder.py:43-49,172-182) -- only
+ * the logits the lattice can consume are ever formed. */
+int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const float *b2,
+                    const float *T, int ldt,
+                    const int *g0, const int *cnt, const int *cnt_idx,
+                    const int *wl, const int *wl_off, const int *wl_idx, int wl_base,
+                    const int *wl_out, float *edge, int beam, int n_groups, void *stream);
+
+/* K5b/K6/K11: log-sum-exp over a selected vocabulary (vocab_select), or its
+ * online extension by newly needed words (incremental vocabulary selection).
+ * Replaces project(hidden, vocab)+softmax (model.py:184,15-20; decoder.py:202-218)
+ * and the back-fill + re-softmax of DynamicDecoder._incremental_decode
+ * (decoder_dynamic.py:133-148).  merge=0: (m,s) := over the list; merge=1:
+ * (m,s) := (m,s) (+) list.  lse[g] = m + log(s) is refreshed either way.
+ * Duplicate words in a list count twice, as in the reference. */
+int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const float *b2,
+                     const float *T, int ldt,
+                     const int *g0, const int *cnt, const int *cnt_idx,
+                     const int *wl, const int *wl_off, const int *wl_idx, int wl_base,
+                     float *run_max, double *run_sum, double *lse,
+                     int merge, int beam, int n_groups, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Lattice of a batch (CSR, built on the host by jlm_amd/lattice.py following
+ * Decoder._build_lattice, decoder.py:79-135), resident in HBM for the decode.
+ */
+typedef struct {
+    int n_sent, beam, n_frames;   /* n_frames = max sentence length + 1 */
+    const int *sent_len;          /* [n_sent] kana length */
+    const int *end_off;           /* [n_frames*n_sent + 1] nodes ending at (frame, sentence) */
+    const int *node_start;        /* [n_nodes] start frame (-1 for <eos>) */
+    const int *node_word;         /* [n_nodes] softmax row of the word */
+} jlm_lattice;
+
+typedef struct {
+    double *score;                /* [G] accumulated -log p (decoder.py:36,49) */
+    double *lse;                  /* [G] log-normaliser of the row's next-word distribution */
+    double *ysum;                 /* [G] dynamic decoder: sum of edge logits along the path */
+    int *bp;                      /* [G] previous hypothesis row (-1 at the root) */
+    int *node;                    /* [G] lattice node consumed last */
+    int *word;                    /* [G] its softmax row (LSTM input) */
+    int *cnt;                     /* [n_frames*n_sent] hypotheses alive per (frame, sentence) */
+    int *live;                    /* [n_frames*rmax] compact list of rows to step per frame */
+    int *n_live;                  /* [n_frames] */
+    const float *edge;            /* [n_nodes*beam] edge logits */
+} jlm_beam_state;
+
+/* K7+K8: candidate scoring and stable per-sentence top-k for frame `frame`.
+ * Replaces Decoder._build_current_frame + sort/truncate (decoder.py:164-182,
+ * 227-229).  mode 0: static decoder, score = score[p] + lse[p] - edge;
+ * mode 1: self-normalised model, score = score[p] - edge (model.py:117-118);
+ * mode 2: DynamicDecoder (decoder_dynamic.py:53-91,150-175): every path is
+ * re-scored from the head with the current normalisers.
+ * Ties keep candidate generation order (node order, then beam slot).  Rows of
+ * a sentence's last frame are not listed in `live`: the reference steps them
+ * too but never reads the result (decoder.py:233-237).
+ * max_cands >= beam * (largest number of nodes ending at one (frame, sentence)). */
+int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
+                  int frame, int mode, int max_cands, void *stream);
+
+/* K10: n-best read-out.  For sentence s and rank r < cnt at its last frame:
+ * out_nodes[(s*beam+r)*stride + d] = node ids from the LAST word back to the
+ * root, out_len = number of nodes, out_score = path score (decoder.py:237). */
+int jlm_backtrace(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
+                  int *out_nodes, int *out_len, double *out_score, int stride, void *stream);
+
+/* K6: row softmax / exp for the LSTM_Model.predict API (model.py:15-20,117-120).
+ * pred[r, :] = self_norm ? exp(y[r, :]) : softmax(y[r, :]). */
+int jlm_softmax_rows(const float *y, float *pred, int ld, int n_rows, int n_cols,
+                     int self_norm, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JLM_HIP_H */

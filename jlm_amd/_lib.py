@@ -1,0 +1,88 @@
+"""ctypes binding of libjlm_hip.so (C ABI declared in include/jlm_hip.h).
+
+The product path has no CPU fallback: :func:`lib` raises if the shared library
+has not been built (``python -c 'import __graft_entry__ as g; g.build()'``) and
+:func:`require_gpu` raises if no MI355X is visible.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjlm_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "csrc", "libjlm_host.so")
+
+JLM_MAX_SEGMENTS = 8
+
+
+class Segment(Structure):
+    _fields_ = [("v_start", c_int), ("v_end", c_int), ("k", c_int), ("t_off", c_int),
+                ("B", c_void_p), ("ldb", c_int)]
+
+
+class Lattice(Structure):
+    _fields_ = [("n_sent", c_int), ("beam", c_int), ("n_frames", c_int),
+                ("sent_len", c_void_p), ("end_off", c_void_p),
+                ("node_start", c_void_p), ("node_word", c_void_p)]
+
+
+class BeamState(Structure):
+    _fields_ = [("score", c_void_p), ("lse", c_void_p), ("ysum", c_void_p),
+                ("bp", c_void_p), ("node", c_void_p), ("word", c_void_p),
+                ("cnt", c_void_p), ("live", c_void_p), ("n_live", c_void_p),
+                ("edge", c_void_p)]
+
+
+P = c_void_p
+_SIGS = {
+    "jlm_abi_version": ([], c_int),
+    "jlm_device_arch": ([c_int, c_char_p, c_int], c_int),
+    "jlm_lstm_step": ([P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P, P], c_int),
+    "jlm_gemm_nt": ([P, c_int, P, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
+    "jlm_vocab_lse_partials": ([P, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, c_int, P, P], c_int),
+    "jlm_lse_combine": ([P, c_int, c_int, P, P, c_int, P, P], c_int),
+    "jlm_edge_logits": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
+    "jlm_wordlist_lse": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
+                         c_int),
+    "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
+    "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
+    "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
+}
+EXPORTS = sorted(_SIGS)
+
+_lib = None
+
+
+class JlmHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (argtypes set).  Raises when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JlmHipError(
+                "libjlm_hip.so is not built (%s).  Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
+        if l.jlm_abi_version() != 1:
+            raise JlmHipError("libjlm_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise JlmHipError("no GPU visible: jlm_amd runs only on MI355X (gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(rc, what):
+    if rc != 0:
+        raise JlmHipError("%s failed with code %d" % (what, rc))

@@ -1,0 +1,400 @@
+// Lattice beam-search kernels for gfx950: word-addressed logits (edge logits,
+// selected-vocabulary log-sum-exp), candidate scoring + stable top-k, n-best
+// back-pointer trace, row softmax.  All of it is small, irregular, HBM/latency
+// bound integer + scalar work: one 64-lane wave (or one workgroup) per sentence,
+// wavefront shuffles for the reductions, no MFMA.
+#include "jlm_common.h"
+
+// ------------------------------------------------------------ word-list logits
+// One workgroup per (sentence, frame) group.  The group's <= beam hypothesis
+// rows of T are staged in LDS once; 8 lanes share one word (each reads 16-B
+// chunks k = sub, sub+8, ... of the word's weight row: 128 B contiguous per
+// word per pass -> coalesced), 32 words per pass; rows are processed 8 at a time
+// out of registers; partial dots are reduced over the 8 lanes with 3 xor-shuffles.
+#define WL_THREADS 256
+#define WL_ROWS 8
+
+template <int MODE>   // 0: edge logits, 1: log-sum-exp over the list
+__global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
+    SegTable segs, const float *__restrict__ b2, const float *__restrict__ T, int ldt,
+    const int *__restrict__ g0v, const int *__restrict__ cnt, const int *__restrict__ cnt_idx,
+    const int *__restrict__ wl, const int *__restrict__ wl_off, const int *__restrict__ wl_idx, int wl_base,
+    const int *__restrict__ wl_out, float *__restrict__ edge, float *__restrict__ run_max, double *__restrict__ run_sum,
+    double *__restrict__ lse, int merge, int beam) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int j = blockIdx.x;
+    const int nrows = min(cnt[cnt_idx[j]], beam);
+    if (nrows <= 0) return;
+    const int gbase = g0v[j];
+    const int lid = wl_base + wl_idx[j];
+    const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
+    if (MODE == 0 && nw == 0) return;
+    const int tid = threadIdx.x;
+    {   // stage T[gbase .. gbase+nrows) (rows are consecutive in g)
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(T + (size_t)gbase * ldt);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(sm);
+        for (int i = tid; i < nrows * (ldt / 4); i += WL_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    float *red = sm + (size_t)beam * ldt;            // [4 waves][WL_ROWS][2] reduction scratch
+    const int sub = tid & 7, slot = tid >> 3;
+    for (int rc = 0; rc < nrows; rc += WL_ROWS) {
+        float rm[WL_ROWS], rs[WL_ROWS];
+#pragma unroll
+        for (int r = 0; r < WL_ROWS; ++r) { rm[r] = JLM_NEG_BIG; rs[r] = 0.0f; }
+        for (int wb = 0; wb < nw; wb += WL_THREADS / 8) {
+            const int wi = wb + slot;
+            const bool valid = wi < nw;
+            const int w = valid ? wl[w0 + wi] : -1;
+            int K4 = 0, toff = 0;
+            const f32x4 *brow = nullptr;
+            if (valid) {
+                for (int si = 0; si < segs.n; ++si)
+                    if (w >= segs.s[si].v_start && w < segs.s[si].v_end) {
+                        K4 = segs.s[si].k >> 2;
+                        toff = segs.s[si].t_off;
+                        brow = reinterpret_cast<const f32x4 *>(segs.s[si].B + (size_t)(w - segs.s[si].v_start) * segs.s[si].ldb);
+                    }
+            }
+            float acc[WL_ROWS];
+#pragma unroll
+            for (int r = 0; r < WL_ROWS; ++r) acc[r] = 0.0f;
+            for (int kc = sub; kc < K4; kc += 8) {
+                const f32x4 bv = brow[kc];
+#pragma unroll
+                for (int r = 0; r < WL_ROWS; ++r) {
+                    if (rc + r < nrows) {
+                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)(rc + r) * ldt + toff + kc * 4);
+                        acc[r] = fmaf(bv[0], tv[0], acc[r]);
+                        acc[r] = fmaf(bv[1], tv[1], acc[r]);
+                        acc[r] = fmaf(bv[2], tv[2], acc[r]);
+                        acc[r] = fmaf(bv[3], tv[3], acc[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < WL_ROWS; ++r) {
+                acc[r] += __shfl_xor(acc[r], 1);
+                acc[r] += __shfl_xor(acc[r], 2);
+                acc[r] += __shfl_xor(acc[r], 4);
+            }
+            if (valid && sub == 0) {
+                const float bw = b2[w];
+#pragma unroll
+                for (int r = 0; r < WL_ROWS; ++r) {
+                    if (rc + r < nrows) {
+                        const float y = acc[r] + bw;
+                        if (MODE == 0) {
+                            edge[(size_t)wl_out[w0 + wi] * beam + rc + r] = y;
+                        } else {
+                            const float mm = fmaxf(rm[r], y);
+                            rs[r] = rs[r] * expf(rm[r] - mm) + expf(y - mm);
+                            rm[r] = mm;
+                        }
+                    }
+                }
+            }
+        }
+        if (MODE == 1) {
+            // workgroup reduction of (max, sum) per row: wave shuffles, then 4 waves through LDS
+#pragma unroll
+            for (int r = 0; r < WL_ROWS; ++r) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    float m2 = __shfl_xor(rm[r], off), s2 = __shfl_xor(rs[r], off);
+                    lse_merge(rm[r], rs[r], m2, s2);
+                }
+            }
+            const int wave = tid >> 6, lane = tid & 63;
+            __syncthreads();
+            if (lane == 0)
+                for (int r = 0; r < WL_ROWS; ++r) {
+                    red[(wave * WL_ROWS + r) * 2] = rm[r];
+                    red[(wave * WL_ROWS + r) * 2 + 1] = rs[r];
+                }
+            __syncthreads();
+            if (tid < WL_ROWS && rc + tid < nrows) {
+                float m = red[tid * 2], s = red[tid * 2 + 1];
+                for (int w2 = 1; w2 < WL_THREADS / 64; ++w2)
+                    lse_merge(m, s, red[(w2 * WL_ROWS + tid) * 2], red[(w2 * WL_ROWS + tid) * 2 + 1]);
+                const int g = gbase + rc + tid;
+                double S = (double)s;
+                float M = m;
+                if (merge) {
+                    const float pm = run_max[g];
+                    const double ps = run_sum[g];
+                    M = fmaxf(pm, m);
+                    S = ps * exp((double)pm - (double)M) + (double)s * exp((double)m - (double)M);
+                }
+                run_max[g] = M;
+                run_sum[g] = S;
+                lse[g] = (double)M + log(S);
+            }
+        }
+    }
+}
+
+static int seg_table(const jlm_segment *segs_host, int n_segs, SegTable &t) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS) return -1;
+    t.n = n_segs;
+    for (int i = 0; i < n_segs; ++i) {
+        t.s[i] = segs_host[i];
+        if (t.s[i].k % 4 || t.s[i].ldb % 4 || t.s[i].t_off % 4) return -1;
+    }
+    return 0;
+}
+
+static size_t wl_lds_bytes(int beam, int ldt) { return ((size_t)beam * ldt + 4 * WL_ROWS * 2) * sizeof(float); }
+
+extern "C" int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
+                               const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
+                               const int *wl_idx, int wl_base, const int *wl_out, float *edge, int beam, int n_groups,
+                               void *stream) {
+    SegTable t;
+    if (seg_table(segs_host, n_segs, t) || ldt % 4) return -1;
+    if (n_groups <= 0) return 0;
+    size_t lds = wl_lds_bytes(beam, ldt);
+    if (lds > 160 * 1024) return -1;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_kernel<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(wordlist_kernel<0>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
+                       g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, wl_out, edge, nullptr, nullptr, nullptr, 0, beam);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
+                                const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
+                                const int *wl_idx, int wl_base, float *run_max, double *run_sum, double *lse, int merge,
+                                int beam, int n_groups, void *stream) {
+    SegTable t;
+    if (seg_table(segs_host, n_segs, t) || ldt % 4) return -1;
+    if (n_groups <= 0) return 0;
+    size_t lds = wl_lds_bytes(beam, ldt);
+    if (lds > 160 * 1024) return -1;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(wordlist_kernel<1>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
+                       g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, nullptr, nullptr, run_max, run_sum, lse, merge, beam);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ beam step
+// One wave per sentence.  Candidate c = (node - first node of the frame) * beam
+// + slot enumerates (node, previous hypothesis) pairs in the reference's
+// generation order (outer loop nodes, inner loop previous paths:
+// decoder/decoder.py:172-182), so a lexicographic (score, c) minimum reproduces
+// Python's stable sort.  Selection: `beam` rounds of a wave-wide arg-min over
+// keys kept in LDS; the winner is struck out by writing +inf.
+__device__ __forceinline__ void wave_argmin(double &v, int &i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double v2 = __shfl_xor(v, off);
+        int i2 = __shfl_xor(i, off);
+        if (v2 < v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam_state st, int frame) {
+    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] (+ [n_frames*beam] for MODE 2)
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
+    const int len = lat.sent_len[s];
+    const int fs = frame * B + s;
+    if (frame > len) { if (lane == 0) st.cnt[fs] = 0; return; }
+    const int nb = lat.end_off[fs], ne = lat.end_off[fs + 1];
+    const int gout = frame * rmax + s * beam;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    int K;
+    if (frame == 0) {
+        K = 1;
+        if (lane == 0) {
+            st.score[gout] = 0.0;
+            if (st.ysum) st.ysum[gout] = 0.0;
+            st.bp[gout] = -1;
+            st.node[gout] = nb;
+            st.word[gout] = lat.node_word[nb];
+        }
+    } else {
+        const int C = (ne - nb) * beam;
+        double *Sarr = keys + C;                       // MODE 2 only
+        if (MODE == 2) {
+            // S(g) = sum of the CURRENT log-normalisers of g's ancestors: every path is
+            // re-scored from the head (decoder_dynamic.py:150-175), frame by frame.
+            for (int f = 0; f < frame; ++f) {
+                const int c = st.cnt[f * B + s];
+                if (lane < c) {
+                    const int g = f * rmax + s * beam + lane;
+                    const int p = st.bp[g];
+                    double S = 0.0;
+                    if (p >= 0) {
+                        const int pf = p / rmax, pk = p - pf * rmax - s * beam;
+                        S = Sarr[pf * beam + pk] + st.lse[p];
+                    }
+                    Sarr[f * beam + lane] = S;
+                }
+                __syncthreads();
+            }
+        }
+        int nvalid = 0;
+        for (int c = lane; c < C; c += 64) {
+            const int n = nb + c / beam, k = c % beam;
+            const int sf = lat.node_start[n];
+            double sc = INF;
+            if (k < st.cnt[sf * B + s]) {
+                const int gp = sf * rmax + s * beam + k;
+                const double e = (double)st.edge[(size_t)n * beam + k];
+                if (MODE == 0) sc = st.score[gp] + (st.lse[gp] - e);
+                else if (MODE == 1) sc = st.score[gp] - e;
+                else sc = (Sarr[sf * beam + k] + st.lse[gp]) - (st.ysum[gp] + e);
+                ++nvalid;
+            }
+            keys[c] = sc;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nvalid += __shfl_xor(nvalid, off);
+        __syncthreads();
+        K = min(beam, nvalid);
+        for (int r = 0; r < K; ++r) {
+            double bv = INF;
+            int bi = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) {
+                const double v = keys[c];
+                if (v < bv || (v == bv && c < bi)) { bv = v; bi = c; }
+            }
+            wave_argmin(bv, bi);
+            if (lane == 0) {
+                const int n = nb + bi / beam, k = bi % beam;
+                const int gp = lat.node_start[n] * rmax + s * beam + k;
+                st.score[gout + r] = bv;
+                if (MODE == 2) st.ysum[gout + r] = st.ysum[gp] + (double)st.edge[(size_t)n * beam + k];
+                st.bp[gout + r] = gp;
+                st.node[gout + r] = n;
+                st.word[gout + r] = lat.node_word[n];
+                keys[bi] = INF;
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        st.cnt[fs] = K;
+        if (frame < len) {      // the last frame's LSTM step is never consumed (decoder.py:233-237)
+            const int base = atomicAdd(&st.n_live[frame], K);
+            for (int r = 0; r < K; ++r) st.live[(size_t)frame * rmax + base + r] = gout + r;
+        }
+    }
+}
+
+extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int frame, int mode,
+                             int max_cands, void *stream) {
+    const jlm_lattice lat = *lat_host;
+    const jlm_beam_state st = *st_host;
+    if (lat.n_sent <= 0) return 0;
+    if (mode == 2 && !st.ysum) return -1;
+    size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0);
+    if (lds > 160 * 1024) return -1;
+    if (mode < 0 || mode > 2) return -1;
+    const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
+                   : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;
+    static size_t attr[3] = {0, 0, 0};
+    if (lds > 64 * 1024 && lds > attr[mode]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr[mode] = lds;
+    }
+    if (mode == 0) hipLaunchKernelGGL(beam_step_kernel<0>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
+    else if (mode == 1) hipLaunchKernelGGL(beam_step_kernel<1>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
+    else hipLaunchKernelGGL(beam_step_kernel<2>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ backtrace
+__global__ void backtrace_kernel(jlm_lattice lat, jlm_beam_state st, int *out_nodes, int *out_len, double *out_score,
+                                 int stride) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
+    if (idx >= rmax) return;
+    const int s = idx / beam, r = idx % beam;
+    const int len = lat.sent_len[s];
+    const int c = st.cnt[len * B + s];
+    if (r >= c) { out_len[idx] = 0; out_score[idx] = 0.0; return; }
+    int g = len * rmax + s * beam + r;
+    out_score[idx] = st.score[g];
+    int d = 0;
+    while (g >= 0 && d < stride) {
+        out_nodes[(size_t)idx * stride + d] = st.node[g];
+        ++d;
+        g = st.bp[g];
+    }
+    out_len[idx] = d;
+}
+
+extern "C" int jlm_backtrace(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int *out_nodes, int *out_len,
+                             double *out_score, int stride, void *stream) {
+    const jlm_lattice lat = *lat_host;
+    const jlm_beam_state st = *st_host;
+    const int total = lat.n_sent * lat.beam;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(backtrace_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, lat, st,
+                       out_nodes, out_len, out_score, stride);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// --------------------------------------------------------------- row softmax
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *y, float *pred, int ld, int n_cols, int self_norm) {
+    __shared__ float redm[4], reds[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float *yr = y + (size_t)r * ld;
+    float *pr = pred + (size_t)r * ld;
+    if (self_norm) {
+        for (int c = tid; c < n_cols; c += 256) pr[c] = expf(yr[c]);
+        return;
+    }
+    float m = JLM_NEG_BIG;
+    for (int c = tid; c < n_cols; c += 256) m = fmaxf(m, yr[c]);
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) redm[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float s = 0.0f;
+    for (int c = tid; c < n_cols; c += 256) s += expf(yr[c] - m);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((tid & 63) == 0) reds[tid >> 6] = s;
+    __syncthreads();
+    s = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+    const float inv = 1.0f / s;
+    for (int c = tid; c < n_cols; c += 256) pr[c] = expf(yr[c] - m) * inv;
+}
+
+extern "C" int jlm_softmax_rows(const float *y, float *pred, int ld, int n_rows, int n_cols, int self_norm, void *stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, y, pred, ld, n_cols, self_norm);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jlm_abi_version(void) { return JLM_ABI_VERSION; }
+
+extern "C" int jlm_device_arch(int dev, char *buf, int buflen) {
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    int i = 0;
+    for (; i < buflen - 1 && p.gcnArchName[i]; ++i) buf[i] = p.gcnArchName[i];
+    buf[i] = 0;
+    return 0;
+}

@@ -1,0 +1,400 @@
+// f32 MFMA "NT" GEMM family for gfx950 (MI355X).
+//
+//   C[m][n] = sum_k Arow(m)[k] * Brow(n)[k]        both operands K-contiguous
+//
+// One mainloop, three epilogues:
+//   EpiStore  plain store + column bias            (K4, V_table projections, debug logits)
+//   EpiGate   LSTM gate nonlinearity + state update (K2+K3; operand A is the
+//             gathered [h_prev | embedding] row, K1+K9 fused into the tile load)
+//   EpiLse    per-tile online log-sum-exp          (K5+K6; logits never stored)
+//
+// Precision: the reference computes in float64 over float32 weights and the
+// parity bar is <=1e-4 relative on logits, so the contraction runs on the
+// exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s dense peak), not
+// on single-pass bf16/fp16 MFMA (which misses the bar at K~768).
+//
+// Tiling: block = WAVES_M x WAVES_N waves, wave tile = (MT*32) x (NT*32),
+// BK = 32 floats per k-step.  LDS rows are padded to 36 floats: the wave's
+// ds_read_b128 fragment reads (row = lane&31, 16-B slot = 9*row + const) hit 16
+// distinct slots per 16-lane service group, i.e. conflict free, and the
+// 128-B-per-row ds_write_b128 staging writes are conflict free as well.
+// Global -> LDS staging goes through registers (8 lanes read one 128-B row
+// segment: fully coalesced) and is issued one k-step ahead of the MFMAs; two
+// LDS buffers, one barrier per k-step.  f32 MFMA retires 4096 FLOP per 64
+// cycles per SIMD, so a 64x64 wave tile spends 4096 cycles per k-step against
+// 16 ds_read_b128 + 8 global loads: the kernel is MFMA-issue bound by design.
+//
+// MFMA operand mapping (32x32x2): lane l supplies A[i = l&31][kk = l>>5] and
+// B[kk = l>>5][j = l&31].  Within a k-step lane-half h owns k = 16h .. 16h+15
+// (one ds_read_b128 per 4 k), so MFMA (q, e) contracts k = 4q+e and 16+4q+e;
+// A and B use the same assignment, hence the sum over k is complete.
+// Accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "jlm_common.h"
+
+#define BK 32
+#define LDS_LD 36
+
+template <int WM_, int WN_, int MT_, int NT_>
+struct TileCfg {
+    static constexpr int WAVES_M = WM_, WAVES_N = WN_, MT = MT_, NT = NT_;
+    static constexpr int BM = WM_ * MT_ * 32;
+    static constexpr int BN = WN_ * NT_ * 32;
+    static constexpr int NTHREADS = WM_ * WN_ * 64;
+    static constexpr int A_CHUNKS = BM * 8 / NTHREADS;
+    static constexpr int B_CHUNKS = BN * 8 / NTHREADS;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
+    static_assert(BM * 8 % NTHREADS == 0 && BN * 8 % NTHREADS == 0, "tile/threads mismatch");
+};
+
+// ---------------------------------------------------------------- row sources
+struct PlainRows {
+    const float *base;
+    const int *map;      // row -> storage row (NULL = identity, <0 = zero row)
+    int ld;
+    int nrows;           // static upper bound
+    const int *ndev;     // optional device-side count
+    struct St { const float *p; };
+    __device__ int count() const { return ndev ? min(*ndev, nrows) : nrows; }
+    __device__ St init(int row, int n) const {
+        St s; s.p = nullptr;
+        if (row < n) {
+            int r = map ? map[row] : row;
+            if (r >= 0) s.p = base + (size_t)r * ld;
+        }
+        return s;
+    }
+    __device__ const float *ptr(const St &s, int) const { return s.p; }
+};
+
+// A operand of the gate GEMM: row r -> g = rows[r]; [ h[prev[g]] (k < H) | emb[word[g]] (k >= H) ]
+struct GateRows {
+    const float *h; int ldh;
+    const int *rows; const int *prev; const int *word;
+    const float *emb; int lde;
+    int H;
+    int nrows; const int *ndev;
+    struct St { const float *ph; const float *pe; };
+    __device__ int count() const { return ndev ? min(*ndev, nrows) : nrows; }
+    __device__ St init(int row, int n) const {
+        St s; s.ph = nullptr; s.pe = nullptr;
+        if (row < n) {
+            int g = rows ? rows[row] : row;
+            int p = prev[g];
+            if (p >= 0) s.ph = h + (size_t)p * ldh;
+            s.pe = emb + (size_t)word[g] * lde - H;    // so that pe + k addresses emb[k - H]
+        }
+        return s;
+    }
+    __device__ const float *ptr(const St &s, int k0) const { return k0 < H ? s.ph : s.pe; }
+};
+
+// ------------------------------------------------------------------ tile map
+// XCD-aware mode: block b runs on XCD b%8 (observed placement, speed only).  All
+// N tiles of one M tile are walked consecutively by ONE XCD, so the M-side panel
+// (the vocabulary block, the big operand) is fetched from HBM once and re-read
+// from that XCD's L2; the N-side operand is small and lives in every L2.
+struct TileMap {
+    int tiles_m, tiles_n, xcd;
+    __device__ bool get(int b, int &tm, int &tn) const {
+        if (!xcd) { tm = b / tiles_n; tn = b % tiles_n; return tm < tiles_m; }
+        int x = b & 7, j = b >> 3;
+        tm = (j / tiles_n) * 8 + x; tn = j % tiles_n;
+        return tm < tiles_m;
+    }
+    int grid() const { return xcd ? ((tiles_m + 7) / 8) * 8 * tiles_n : tiles_m * tiles_n; }
+};
+
+// ------------------------------------------------------------------ epilogues
+struct EpiStore {
+    float *C; const int *c_map; int ldc; const float *bias;
+    template <class Cfg>
+    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
+                        int M, int N, float *) const {
+#pragma unroll
+        for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                int r = c_map ? c_map[row] : row;
+                float *crow = C + (size_t)r * ldc;
+#pragma unroll
+                for (int nt = 0; nt < Cfg::NT; ++nt) {
+                    int col = n0 + (wn * Cfg::NT + nt) * 32 + (lane & 31);
+                    if (col < N) crow[col] = acc[mt][nt][reg] + (bias ? bias[col] : 0.0f);
+                }
+            }
+    }
+};
+
+// Gate epilogue.  Needs NT == 4 and WAVES_N == 1: the four 32-column MFMA tiles
+// of a wave are the i, f, o, g pre-activations of the same 32 hidden units
+// (packed weight layout, include/jlm_hip.h), so the LSTM cell update is done in
+// registers by the lane that owns (row, unit).
+struct EpiGate {
+    const float *c_in; float *h_out; float *c_out; int ld;
+    const int *rows; const int *prev; const float *bias;
+    template <class Cfg>
+    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int, int lane,
+                        int M, int, float *) const {
+        static_assert(Cfg::NT == 4 && Cfg::WAVES_N == 1, "gate epilogue wants 4 gate tiles per wave");
+        const int u = (n0 >> 2) + (lane & 31);          // hidden unit
+        const float bi = bias[n0 + (lane & 31)], bf = bias[n0 + 32 + (lane & 31)];
+        const float bo = bias[n0 + 64 + (lane & 31)], bg = bias[n0 + 96 + (lane & 31)];
+#pragma unroll
+        for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                int g = rows ? rows[row] : row;
+                int p = prev[g];
+                float cp = p >= 0 ? c_in[(size_t)p * ld + u] : 0.0f;
+                float gi = jlm_sigmoid(acc[mt][0][reg] + bi);
+                float gf = jlm_sigmoid(acc[mt][1][reg] + bf);
+                float go = jlm_sigmoid(acc[mt][2][reg] + bo);
+                float gg = tanhf(acc[mt][3][reg] + bg);
+                float cn = cp * gf + gg * gi;
+                c_out[(size_t)g * ld + u] = cn;
+                h_out[(size_t)g * ld + u] = tanhf(cn) * go;
+            }
+    }
+};
+
+// LSE epilogue.  GEMM M = vocabulary rows, N = hypothesis rows ("swapped"
+// orientation): a lane then holds 16*MT vocabulary logits of ONE hypothesis in
+// registers, so max / sum-exp are in-lane chains plus one cross-half exchange
+// and one 2-wave combine through LDS.
+struct EpiLse {
+    const float *bias;     // per vocabulary row of this segment
+    float *part;           // float2 [tiles][ld_part]
+    int ld_part, tile0;
+    template <class Cfg>
+    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
+                        int M, int N, float *smem) const {
+        float2 *red = reinterpret_cast<float2 *>(smem);      // [WAVES_M][BN]
+#pragma unroll
+        for (int nt = 0; nt < Cfg::NT; ++nt) {
+            float m = JLM_NEG_BIG;
+            float v[Cfg::MT][16];
+#pragma unroll
+            for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    bool ok = row < M;
+                    float x = ok ? acc[mt][nt][reg] + bias[row] : JLM_NEG_BIG;
+                    v[mt][reg] = x;
+                    m = fmaxf(m, x);
+                }
+            float s = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    s += (v[mt][reg] > JLM_NEG_BIG) ? expf(v[mt][reg] - m) : 0.0f;
+            float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+            lse_merge(m, s, m2, s2);
+            if (lane < 32) red[wm * Cfg::BN + (wn * Cfg::NT + nt) * 32 + lane] = make_float2(m, s);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Cfg::BN; c += Cfg::NTHREADS) {
+            float2 a = red[c];
+#pragma unroll
+            for (int w = 1; w < Cfg::WAVES_M; ++w) {
+                float2 b = red[w * Cfg::BN + c];
+                lse_merge(a.x, a.y, b.x, b.y);
+            }
+            int col = n0 + c;
+            if (col < N) reinterpret_cast<float2 *>(part)[(size_t)(tile0 + m0 / Cfg::BM) * ld_part + col] = a;
+        }
+    }
+};
+
+// ------------------------------------------------------------------- mainloop
+template <class Cfg, class ARows, class BRows, class Epi>
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(ARows A, BRows B, int K, Epi epi, TileMap tmap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MT = Cfg::MT, NT = Cfg::NT;
+    int tile_m, tile_n;
+    if (!tmap.get(blockIdx.x, tile_m, tile_n)) return;
+    const int M = A.count(), N = B.count();
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= M || n0 >= N) return;
+
+    float *As = smem;                         // [2][BM][LDS_LD]
+    float *Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int kc = tid & 7;                   // 16-B chunk inside the 128-B row segment
+
+    typename ARows::St sa[Cfg::A_CHUNKS];
+    typename BRows::St sb[Cfg::B_CHUNKS];
+#pragma unroll
+    for (int j = 0; j < Cfg::A_CHUNKS; ++j) sa[j] = A.init(m0 + (tid >> 3) + j * (Cfg::NTHREADS / 8), M);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_CHUNKS; ++j) sb[j] = B.init(n0 + (tid >> 3) + j * (Cfg::NTHREADS / 8), N);
+
+    f32x4 ra[Cfg::A_CHUNKS], rb[Cfg::B_CHUNKS];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kc * 4;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_CHUNKS; ++j) {
+            const float *p = A.ptr(sa[j], k0);
+            ra[j] = (p && k < K) ? *reinterpret_cast<const f32x4 *>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_CHUNKS; ++j) {
+            const float *p = B.ptr(sb[j], k0);
+            rb[j] = (p && k < K) ? *reinterpret_cast<const f32x4 *>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *as = As + buf * BM * LDS_LD, *bs = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_CHUNKS; ++j)
+            *reinterpret_cast<f32x4 *>(as + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < Cfg::B_CHUNKS; ++j)
+            *reinterpret_cast<f32x4 *>(bs + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) = rb[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const float *as = As + cur * BM * LDS_LD + (wm * MT * 32) * LDS_LD + frag_off;
+        const float *bs = Bs + cur * BN * LDS_LD + (wn * NT * 32) * LDS_LD + frag_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD + q * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+}
+
+// ------------------------------------------------------------------ launchers
+template <class Cfg, class ARows, class BRows, class Epi>
+static int launch_gemm(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_nt_kernel<Cfg, ARows, BRows, Epi>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    TileMap tm;
+    tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
+    tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
+    tm.xcd = xcd;
+    if (tm.tiles_m == 0 || tm.tiles_n == 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), Cfg::LDS_BYTES, st, A, B, K, epi, tm);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+typedef TileCfg<2, 2, 2, 2> Cfg128;     // 128 x 128, wave 64 x 64
+typedef TileCfg<2, 2, 1, 1> Cfg64;      //  64 x  64, wave 32 x 32
+typedef TileCfg<4, 1, 1, 4> CfgGate;    // 128 x 128, wave 32 x 128 (4 gate tiles)
+typedef TileCfg<2, 1, 1, 4> CfgGate64;  //  64 x 128
+
+extern "C" int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state, float *h_out, float *c_out,
+                             const int *rows, const int *prev, const int *word, const float *emb, int ld_emb,
+                             const float *wt, const float *bias, int kpad, int H, int E, int n_rows_max,
+                             const int *n_dev, void *stream) {
+    if (H % 32 != 0 || E % 4 != 0 || kpad % BK != 0 || kpad < H + E || ld_state % 4 || ld_emb % 4) return -1;
+    GateRows A;
+    A.h = h_in; A.ldh = ld_state; A.rows = rows; A.prev = prev; A.word = word;
+    A.emb = emb; A.lde = ld_emb; A.H = H; A.nrows = n_rows_max; A.ndev = n_dev;
+    PlainRows B;
+    B.base = wt; B.map = nullptr; B.ld = kpad; B.nrows = 4 * H; B.ndev = nullptr;
+    EpiGate epi;
+    epi.c_in = c_in; epi.h_out = h_out; epi.c_out = c_out; epi.ld = ld_state;
+    epi.rows = rows; epi.prev = prev; epi.bias = bias;
+    // K = H + E: chunks past it are zero filled, the packed weights are zero padded
+    if (n_rows_max <= 64) return launch_gemm<CfgGate64>(A, B, H + E, epi, 0, (hipStream_t)stream);
+    return launch_gemm<CfgGate>(A, B, H + E, epi, 0, (hipStream_t)stream);
+}
+
+extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const float *Bp, int ldb, const int *b_rows,
+                           float *C, int ldc, const int *c_rows, const float *bias, int M, int N, int K,
+                           const int *m_dev, void *stream) {
+    if (K % 4 != 0 || lda % 4 != 0 || ldb % 4 != 0) return -1;
+    PlainRows A, B;
+    A.base = Ap; A.map = a_rows; A.ld = lda; A.nrows = M; A.ndev = m_dev;
+    B.base = Bp; B.map = b_rows; B.ld = ldb; B.nrows = N; B.ndev = nullptr;
+    EpiStore epi;
+    epi.C = C; epi.c_map = c_rows; epi.ldc = ldc; epi.bias = bias;
+    // small problems: 64 x 64 tiles give 4x the workgroups (K4: [R,512]x[512,256] is only 40 tiles of 128^2)
+    long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 < 512) return launch_gemm<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
+    return launch_gemm<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
+}
+
+extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, int K, const float *T, int ldt,
+                                      const int *rows, const float *bias, float *part, int ld_part, int tile0,
+                                      int n_rows_max, const int *n_dev, void *stream) {
+    if (K % 4 != 0 || ldb % 4 != 0 || ldt % 4 != 0) return -1;
+    PlainRows A, B;
+    A.base = Bseg; A.map = nullptr; A.ld = ldb; A.nrows = n_vocab; A.ndev = nullptr;
+    B.base = T; B.map = rows; B.ld = ldt; B.nrows = n_rows_max; B.ndev = n_dev;
+    EpiLse epi;
+    epi.bias = bias; epi.part = part; epi.ld_part = ld_part; epi.tile0 = tile0;
+    int r = launch_gemm<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
+    if (r != 0) return r > 0 ? -r : r;
+    return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
+}
+
+// lse[g] = log sum exp over the tile partials of one row (float64 accumulation)
+__global__ void lse_combine_kernel(const float2 *part, int ld_part, int n_tiles, const int *rows, double *lse,
+                                   int n_rows_max, const int *n_dev) {
+    int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float m = JLM_NEG_BIG;
+    for (int t = 0; t < n_tiles; ++t) m = fmaxf(m, part[(size_t)t * ld_part + r].x);
+    double s = 0.0;
+    for (int t = 0; t < n_tiles; ++t) {
+        float2 p = part[(size_t)t * ld_part + r];
+        s += (double)p.y * exp((double)p.x - (double)m);
+    }
+    int g = rows ? rows[r] : r;
+    lse[g] = (double)m + log(s);
+}
+
+extern "C" int jlm_lse_combine(const float *part, int ld_part, int n_tiles, const int *rows, double *lse,
+                               int n_rows_max, const int *n_dev, void *stream) {
+    if (n_rows_max <= 0) return 0;
+    int bs = 256, grid = (n_rows_max + bs - 1) / bs;
+    hipLaunchKernelGGL(lse_combine_kernel, dim3(grid), dim3(bs), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2 *>(part), ld_part, n_tiles, rows, lse, n_rows_max, n_dev);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,126 @@
+"""Lattice Viterbi beam-search decoder on MI355X, reference-compatible API.
+
+Counterpart of ``Decoder`` in the reference (decoder/decoder.py:54-241):
+
+    Decoder(experiment_id=0, comp=0)
+    .decode(input, topN=10, beam_width=10, vocab_select=False, samples=0,
+            top_sampling=False, random_sampling=False) -> [(neg_log_prob, [word, ...])]
+    ._check_oov(word)
+    attrs .perf_sen .perf_log_lstm .perf_log_softmax .lattice_vocab
+          .backward_lookup .model .w2i .i2w .config
+
+plus ``decode_batch(list_of_inputs, ...)`` (the reference decodes one sentence
+at a time; batching sentences is what fills the GPU).  ``decode`` is
+``decode_batch`` of one sentence.
+
+Deliberate differences (DESIGN.md "Reference quirks"):
+  * ``beam_width=None`` (no pruning, exponential) is rejected;
+  * a stale ``lattice_vocab`` from an earlier ``vocab_select=True`` call is not
+    reused by a later full-vocabulary call (decoder.py:62,176 would);
+  * the LSTM step of the last frame is skipped (its result is never read,
+    decoder.py:233-237).
+"""
+import os
+import pickle
+
+from . import config as _config
+from .data import Vocab
+from .engine import DecodeEngine
+from .lattice import BatchLattice, LatticeBuilder
+from .model import LSTM_Model
+
+
+class Node():
+    """Lattice node view, field names of the reference (decoder.py:17-27)."""
+
+    def __init__(self, s, l, idx, word, oov_prob=0.0):
+        self.start_idx = s
+        self.reading_length = l
+        self.word_idx = idx
+        self.word = word
+        self.oov_prob = oov_prob
+        self.char_rnn_step = 0
+
+    def __repr__(self):
+        return str((self.start_idx, self.word))
+
+
+class Decoder():
+    dynamic = False
+
+    def __init__(self, experiment_id=0, comp=0, device=None):
+        self.config = _config.load_config_dict(experiment_id)
+        if self.config.get('char_rnn'):
+            raise NotImplementedError("char-RNN decoding is outside the scope of this build (SURVEY.md 8f)")
+        self._load_vocab()
+        with open(os.path.join(_config.root_path, 'data', 'lexicon.pkl'), 'rb') as f:
+            self.full_lexicon = pickle.load(f)
+        with open(os.path.join(_config.root_path, 'data', 'reading_dict.pkl'), 'rb') as f:
+            self.full_reading_dict = pickle.load(f)
+        self.model = LSTM_Model(experiment_id, comp, device=device)
+        self._builder = LatticeBuilder(self.full_lexicon, self.full_reading_dict, self.w2i)
+        self._engine = DecodeEngine(self.model.dev)
+        self.lattice_vocab = None
+        self.backward_lookup = None
+        self.perf_sen = 0
+        self.perf_log_lstm = []
+        self.perf_log_softmax = []
+        self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
+        self.last_lattice = None
+
+    def _load_vocab(self):
+        self.vocab = Vocab(self.config['vocab_size'])
+        self.i2w = self.vocab.i2w
+        self.w2i = self.vocab.w2i
+
+    def _check_oov(self, word):
+        return word not in self.w2i
+
+    def _build_lattice(self, input, vocab_select=False, samples=0, top_sampling=False, random_sampling=False):
+        """Single-sentence lattice in the reference's shape: dict frame -> [Node]
+        (decoder.py:79-135)."""
+        lat = BatchLattice(self._builder, [input], 1)
+        bl = {}
+        for f, nodes in enumerate(lat.backward_lookup(0)):
+            bl[f] = [Node(s, l, w, word) for (s, l, w, word) in nodes]
+        return bl
+
+    def _log_perf(self):
+        if self.perf_timing and self._engine.last_timing:
+            for t_lstm, t_soft in self._engine.last_timing:
+                self.perf_log_lstm.append(t_lstm)
+                self.perf_log_softmax.append(t_soft)
+
+    def decode_batch(self, inputs, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
+                     random_sampling=False):
+        if beam_width is None:
+            raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+        inputs = list(inputs)
+        if any(len(x) == 0 for x in inputs):
+            raise ValueError("empty input string")
+        lat = BatchLattice(self._builder, inputs, beam_width)
+        self.last_lattice = lat
+        vocab = None
+        if vocab_select:
+            words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+            vocab = (words, off)
+            self.lattice_vocab = lists[-1]
+        out = self._engine.decode(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
+        self._log_perf()
+        self.perf_sen += len(inputs)
+        return out
+
+    def decode(self, input, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
+               random_sampling=False):
+        out = self.decode_batch([input], topN, beam_width, vocab_select, samples, top_sampling, random_sampling)[0]
+        self.backward_lookup = self.last_lattice.backward_lookup(0)
+        self.perf_sen += 0
+        return out
+
+
+class CharRNNDecoder(Decoder):
+    """Placeholder so that ``from decoder import Decoder, CharRNNDecoder``
+    (reference decoder/eval.py:7) resolves; out of scope."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("CharRNNDecoder is outside the scope of this build (SURVEY.md 8f)")

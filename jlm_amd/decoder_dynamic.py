@@ -1,0 +1,50 @@
+"""Incremental-vocabulary-selection decoder on MI355X.
+
+Counterpart of ``DynamicDecoder`` (reference decoder/decoder_dynamic.py:18-194):
+same constructor and ``decode`` signature, plus ``decode_batch``.  The
+per-frame growing vocabulary becomes an online log-sum-exp extension on the
+device (jlm_wordlist_lse with merge=1) and the "re-score every path from the
+head" fix-up (decoder_dynamic.py:150-175) becomes a per-sentence scan over the
+back-pointer chain inside jlm_beam_step (mode 2).
+
+As in the reference, ``vocab_select=True`` is required (without it the
+reference raises TypeError at decoder_dynamic.py:114).  With D-softmax /
+D-softmax* models the reference mis-assigns softmax columns in this decoder
+(SURVEY.md 8 a16); this implementation computes the self-consistent result
+instead and parity is pinned on tied-softmax models.
+"""
+from .decoder import Decoder
+from .lattice import BatchLattice
+
+
+class DynamicDecoder(Decoder):
+    dynamic = True
+
+    def __init__(self, experiment_id=0, comp=0, device=None):
+        super(DynamicDecoder, self).__init__(experiment_id=experiment_id, comp=comp, device=device)
+        print('Dynamic RNN decoder loaded')
+        self.perf_log_fix_vocab = []
+        self.perf_log_fix_lattice_path_prob = []
+
+    def decode_batch(self, inputs, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
+                     random_sampling=False):
+        if beam_width is None:
+            raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+        if not vocab_select:
+            raise TypeError("'NoneType' object is not subscriptable")      # decoder_dynamic.py:114
+        inputs = list(inputs)
+        if any(len(x) == 0 for x in inputs):
+            raise ValueError("empty input string")
+        lat = BatchLattice(self._builder, inputs, beam_width)
+        self.last_lattice = lat
+        iw, io, dw, do, lv_final = lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+        self.lattice_vocab = lv_final[-1]
+        out = self._engine.decode(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN, timing=self.perf_timing)
+        self._log_perf()
+        # the vocabulary fix-up and the path re-scoring are fused into the frame's
+        # kernels; their cost is inside perf_log_softmax.  eval.py takes np.mean of these.
+        n = len(self._engine.last_timing or [])
+        self.perf_log_fix_vocab.extend([0.0] * max(n, 1))
+        self.perf_log_fix_lattice_path_prob.extend([0.0] * max(n, 1))
+        self.perf_sen += len(inputs)
+        return out

@@ -1,0 +1,401 @@
+"""LSTM language model on MI355X: same API as the reference's numpy model.
+
+Counterpart of ``LSTM_Model`` (reference decoder/model.py:36-198):
+
+    LSTM_Model(experiment_id=0, comp=0)
+    .predict(index, vocab=None, reset=False) -> (pred, y, t_lstm, t_softmax)
+    .project(hidden, vocab=None)             -> y
+    .predict_with_context(index, hidden, cell, vocab=None)
+                                             -> ((pred, y, t1, t2), hidden, cell)
+    attrs .hidden .cell .hidden_size .embed_size .config .weights
+
+Arrays at this boundary are numpy (float64, like the reference's); on the
+device everything is float32 and runs through the HIP kernels of
+libjlm_hip.so (exact-f32 MFMA).  :class:`DeviceModel` holds the packed weight
+panels in HBM and is shared with the batched decoders, which never come back
+to numpy between frames.
+"""
+import json
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+from . import _lib
+from . import config as _config
+
+GATES = "ifog"
+
+
+def _pad(x, m):
+    return (x + m - 1) // m * m
+
+
+def load_weights(experiment_id=0, comp=0):
+    """reference model.py:73-104 (the hard-wired-off hash-code branch is not
+    reproduced).  ``comp`` > 0 picks the k-means file, same layout."""
+    name = "lstm_weights_comp_{}.pkl".format(comp) if comp else "lstm_weights.pkl"
+    with open(os.path.join(_config.experiment_path, str(experiment_id), "weights", name), "rb") as f:
+        return pickle.load(f)
+
+
+def prepare_weights(config, weights):
+    """Host-side weight preparation of LSTM_Model.__init__ (model.py:47-71).
+    -> (weights with the rebuilt 'LM', embed_size, blocks, v_tables)"""
+    w = dict(weights)
+    embed_size = config["embed_size"]
+    blocks = v_tables = None
+    segs = [tuple(s) for s in config["embedding_seg"]]
+    if config["D_softmax"]:
+        blocks = w["LM"]
+        embed_size = sum(s[0] for s in segs)
+        full = np.zeros((w["b2"].shape[0], embed_size))        # float64, as in the reference
+        c0 = 0
+        for i, (size, s, e) in enumerate(segs):
+            full[s:e, c0:c0 + size] = blocks[i]
+            c0 += size
+        w["LM"] = full
+    if config["V_table"]:
+        blocks, v_tables, emb = [], [], []
+        for i in range(len(segs)):
+            blk = w["LM{}".format(i)]
+            blocks.append(blk)
+            if i != 0:
+                vt = w["VT{}".format(i)]
+                v_tables.append(vt)
+                emb.append(np.dot(blk, vt))
+            else:
+                v_tables.append(None)
+                emb.append(blk)
+        w["LM"] = np.concatenate(emb, axis=0)
+    return w, embed_size, blocks, v_tables
+
+
+class _Stamp:
+    """HIP event on the current stream (wall clock when the tensors are not on a GPU,
+    which only happens under the CPU test double)."""
+
+    def __init__(self, torch, device):
+        self.torch = torch
+        self.ev = torch.cuda.Event(enable_timing=True) if device.type == "cuda" else None
+        self.t = 0.0
+
+    def record(self):
+        if self.ev is not None:
+            self.ev.record()
+        else:
+            self.t = time.time()
+
+    def seconds_to(self, other):
+        if self.ev is not None:
+            return self.ev.elapsed_time(other.ev) * 1e-3
+        return other.t - self.t
+
+
+def _sync(torch, device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+class DeviceModel:
+    """Weight panels in HBM, packed for the kernels (layouts: include/jlm_hip.h).
+
+    T layout: every hypothesis row owns ``ldt`` floats.  Tied softmax: T = h.PM
+    (E columns).  D-softmax: the same product, each segment's columns at a
+    4-aligned offset.  D-softmax* (V_table): [h.PM | (h.PM).VT1^T | ...].
+    Untied: T is the hidden state itself.  Pad columns are produced as exact
+    zeros (zero rows in the packed matrices)."""
+
+    def __init__(self, config, weights, blocks, v_tables, device):
+        import torch
+        self.torch = torch
+        self.device = device
+        self.config = config
+        H = config["hidden_size"]
+        if H % 32 != 0:
+            raise ValueError("hidden_size must be a multiple of 32 for the gate tile layout (got %d)" % H)
+        self.H = H
+        self.V = int(weights["b2"].shape[0])
+        self.self_norm = bool(config["self_norm"])
+        self.share_embedding = bool(config["share_embedding"])
+        self.mode = ("dsoftmax" if config["D_softmax"] else "vtable" if config["V_table"]
+                     else "tied" if self.share_embedding else "untied")
+        f32 = np.float32
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=f32)).to(device)
+
+        # --- input embedding + packed gate matrix (model.py:125-131)
+        LM = np.asarray(weights["LM"])
+        E_in = LM.shape[1]
+        self.E_in = E_in
+        self.Epad = _pad(E_in, 4)
+        emb = np.zeros((LM.shape[0], self.Epad), dtype=f32)
+        emb[:, :E_in] = LM
+        self.emb = dev(emb)
+        self.kpad = _pad(H + self.Epad, 32)
+        wt = np.zeros((4 * H, self.kpad), dtype=f32)
+        bias = np.zeros(4 * H, dtype=f32)
+        u = np.arange(H)
+        for gi, g in enumerate(GATES):
+            n = (u // 32) * 128 + gi * 32 + (u % 32)
+            wt[n, :H] = np.asarray(weights["HM" + g], dtype=f32).T
+            wt[n, H:H + E_in] = np.asarray(weights["IM" + g], dtype=f32).T
+            bias[n] = np.asarray(weights["b" + g], dtype=f32)
+        self.wt, self.gate_bias = dev(wt), dev(bias)
+        self.b2 = dev(weights["b2"])
+
+        # --- output side: segments over T
+        segs_cfg = [tuple(s) for s in config["embedding_seg"]]
+        self.seg_B = []          # device blocks [V_i, pad4(k_i)]
+        self.segments = []       # dicts: v_start v_end k t_off ldb
+        self.vt_packed = []      # V_table: (t_off, n_pad, tensor [n_pad, Epad0]) for segments > 0
+        self.pmt = None
+        if self.mode == "untied":
+            self.ldt = H
+            um_t = np.ascontiguousarray(np.asarray(weights["UM"], dtype=f32).T)      # [V, H]
+            self.seg_B.append(dev(um_t))
+            self.segments.append(dict(v_start=0, v_end=self.V, k=H, t_off=0, ldb=H))
+        else:
+            PM = np.asarray(weights["PM"], dtype=f32)                                 # [H, Ecols]
+            if self.mode == "tied":
+                k = PM.shape[1]
+                kp = _pad(k, 4)
+                self.ldt = kp
+                pmt = np.zeros((kp, H), dtype=f32)
+                pmt[:k] = PM.T
+                blk = np.zeros((self.V, kp), dtype=f32)
+                blk[:, :k] = np.asarray(weights["LM"], dtype=f32)
+                self.seg_B.append(dev(blk))
+                self.segments.append(dict(v_start=0, v_end=self.V, k=kp, t_off=0, ldb=kp))
+            elif self.mode == "dsoftmax":
+                offs, off = [], 0
+                for size, s, e in segs_cfg:
+                    offs.append(off)
+                    off += _pad(size, 4)
+                self.ldt = off
+                pmt = np.zeros((self.ldt, H), dtype=f32)
+                c0 = 0
+                for i, (size, s, e) in enumerate(segs_cfg):
+                    e = self.V if e is None else e
+                    pmt[offs[i]:offs[i] + size] = PM[:, c0:c0 + size].T
+                    c0 += size
+                    kp = _pad(size, 4)
+                    blk = np.zeros((e - s, kp), dtype=f32)
+                    blk[:, :size] = np.asarray(blocks[i], dtype=f32)
+                    self.seg_B.append(dev(blk))
+                    self.segments.append(dict(v_start=s, v_end=e, k=kp, t_off=offs[i], ldb=kp))
+            else:  # vtable
+                E0 = PM.shape[1]
+                E0p = _pad(E0, 4)
+                off = 0
+                for i, (size, s, e) in enumerate(segs_cfg):
+                    e = self.V if e is None else e
+                    kp = _pad(size, 4)
+                    blk = np.zeros((e - s, kp), dtype=f32)
+                    blk[:, :size] = np.asarray(blocks[i], dtype=f32)
+                    self.seg_B.append(dev(blk))
+                    self.segments.append(dict(v_start=s, v_end=e, k=kp, t_off=off, ldb=kp))
+                    if i != 0:
+                        vt = np.zeros((kp, E0p), dtype=f32)
+                        vt[:size, :E0] = np.asarray(v_tables[i], dtype=f32)
+                        self.vt_packed.append((off, kp, dev(vt)))
+                    off += kp if i != 0 else E0p
+                self.ldt = off
+                self.E0p = E0p
+                pmt = np.zeros((E0p, H), dtype=f32)
+                pmt[:E0] = PM.T
+            self.pmt = dev(pmt)
+        self.n_vocab_tiles = sum((sg["v_end"] - sg["v_start"] + 127) // 128 for sg in self.segments)
+        arr = (_lib.Segment * len(self.segments))()
+        for i, sg in enumerate(self.segments):
+            arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], sg["k"], sg["t_off"], self.seg_B[i].data_ptr(), sg["ldb"])
+        self.seg_array = arr
+        self.n_segs = len(self.segments)
+
+    # -- enqueue helpers (all on torch's current HIP stream) ------------------
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream):
+        L = _lib.lib()
+        _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
+                                   self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),
+                                   self.kpad, self.H, self.Epad, n_rows_max, n_dev, stream), "jlm_lstm_step")
+
+    def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream):
+        """T[g] = h[g].PM (+ the V_table projections).  No-op for untied models
+        (T aliases h there)."""
+        if self.mode == "untied":
+            return
+        L = _lib.lib()
+        n_t = self.pmt.shape[0]
+        _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
+                                 n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
+        for (t_off, n_pad, vt) in self.vt_packed:
+            _lib.check(L.jlm_gemm_nt(T, self.ldt, rows, vt.data_ptr(), self.E0p, None, T + 4 * t_off, self.ldt, rows,
+                                     None, n_rows_max, n_pad, self.E0p, n_dev, stream), "jlm_gemm_nt(VT)")
+
+    def full_vocab_lse(self, T, rows, part, ld_part, lse, n_rows_max, n_dev, stream):
+        L = _lib.lib()
+        tile0 = 0
+        for i, sg in enumerate(self.segments):
+            nv = sg["v_end"] - sg["v_start"]
+            r = L.jlm_vocab_lse_partials(self.seg_B[i].data_ptr(), sg["ldb"], nv, sg["k"], T + 4 * sg["t_off"], self.ldt,
+                                         rows, self.b2.data_ptr() + 4 * sg["v_start"], part, ld_part, tile0,
+                                         n_rows_max, n_dev, stream)
+            if r < 0:
+                raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
+            tile0 += r
+        _lib.check(L.jlm_lse_combine(part, ld_part, tile0, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
+
+
+class LSTM_Model():
+    """MI355X implementation behind the reference's LSTM_Model interface."""
+
+    def __init__(self, experiment_id=0, comp=0, device=None):
+        print('LSTM model: exp {} comp {}'.format(experiment_id, comp))
+        self.config = _config.load_config_dict(experiment_id)
+        raw = load_weights(experiment_id, comp)
+        self.weights, self.embed_size, self.blocks, self.v_tables = prepare_weights(self.config, raw)
+        if not (self.config['D_softmax'] or self.config['V_table']):
+            self.embed_size = self.config['embed_size']
+        self.hidden_size = self.config['hidden_size']
+        self.share_embedding = self.config['share_embedding']
+        self.hidden = np.zeros((1, self.hidden_size))
+        self.cell = np.zeros((1, self.hidden_size))
+        self.device = device if device is not None else _lib.require_gpu()
+        _lib.lib()
+        self.dev = DeviceModel(self.config, self.weights, self.blocks, self.v_tables, self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def _to_dev(self, a, dtype=None):
+        torch = self.dev.torch
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        return t.to(self.device, dtype=dtype if dtype is not None else torch.float32)
+
+    def _segment_columns(self, vocab):
+        """Column plan of project(): list of (segment index, word ids) in the
+        reference's output order (segment-major, then order of appearance in
+        ``vocab``: model.py:152-153,168) and the positional bias ids."""
+        d = self.dev
+        if not vocab:
+            return [(i, None) for i in range(d.n_segs)], None
+        plan = []
+        if d.mode in ("dsoftmax", "vtable"):
+            for i, sg in enumerate(d.segments):
+                plan.append((i, [v for v in vocab if v >= sg["v_start"] and v < sg["v_end"]]))
+        else:
+            plan.append((0, list(vocab)))
+        return plan, list(vocab)
+
+    def _logits_from_T(self, T, ldt, n_rows, vocab):
+        """Materialised logits [n_rows, n_cols] float32 on the device (K5a-K5e)."""
+        torch = self.dev.torch
+        d = self.dev
+        L = _lib.lib()
+        st = d.stream()
+        plan, bias_ids = self._segment_columns(vocab)
+        if d.mode == "untied" and vocab:
+            # model.py:189: UM[vocab] indexes ROWS of UM[H, V]; kept as the reference's behaviour
+            raise IndexError("untied projection with a vocab subset indexes rows of UM[H, V] in the reference")
+        n_cols = sum((d.segments[i]["v_end"] - d.segments[i]["v_start"]) if ids is None else len(ids) for i, ids in plan)
+        y = torch.empty((n_rows, _pad(max(n_cols, 1), 4)), device=self.device, dtype=torch.float32)
+        if bias_ids is not None:
+            bias_all = d.b2[torch.as_tensor(bias_ids, device=self.device, dtype=torch.long)].contiguous()
+        else:
+            bias_all = d.b2
+        c0 = 0
+        keep = []
+        for i, ids in plan:
+            sg = d.segments[i]
+            if ids is None:
+                n, bmap = sg["v_end"] - sg["v_start"], None
+            else:
+                n = len(ids)
+                bm = torch.as_tensor([v - sg["v_start"] for v in ids], device=self.device, dtype=torch.int32)
+                keep.append(bm)
+                bmap = bm.data_ptr()
+            if n:
+                _lib.check(L.jlm_gemm_nt(T.data_ptr() + 4 * sg["t_off"], ldt, None, d.seg_B[i].data_ptr(), sg["ldb"], bmap,
+                                         y.data_ptr() + 4 * c0, y.shape[1], None, bias_all.data_ptr() + 4 * c0,
+                                         n_rows, n, sg["k"], None, st), "jlm_gemm_nt(logits)")
+            c0 += n
+        return y, n_cols, keep
+
+    def _project_dev(self, hdev, n_rows, vocab):
+        torch = self.dev.torch
+        d = self.dev
+        if d.mode == "untied":
+            T, ldt = hdev, d.H
+        else:
+            T = torch.empty((n_rows, d.ldt), device=self.device, dtype=torch.float32)
+            d.project_T(hdev.data_ptr(), d.H, T.data_ptr(), None, n_rows, None, d.stream())
+            ldt = d.ldt
+        return self._logits_from_T(T, ldt, n_rows, vocab)
+
+    # ---------------------------------------------------------------- interface
+    def predict(self, index, vocab=None, reset=False):
+        if reset:  # reference model.py:107-109 (keeps the previous row count)
+            self.hidden = np.zeros(shape=self.hidden.shape)
+            self.cell = np.zeros(shape=self.cell.shape)
+        torch = self.dev.torch
+        d = self.dev
+        L = _lib.lib()
+        index = [int(i) for i in index]
+        R = len(index)
+        hid = np.asarray(self.hidden, dtype=np.float64)
+        cel = np.asarray(self.cell, dtype=np.float64)
+        if hid.shape[0] != R:
+            if hid.shape[0] == 1:        # numpy broadcasting of a [1,H] state against R embeddings
+                hid = np.repeat(hid, R, axis=0)
+                cel = np.repeat(cel, R, axis=0)
+            else:
+                raise ValueError("operands could not be broadcast together with shapes {} ({},)".format(hid.shape, R))
+        ev0, ev1, ev2 = (_Stamp(torch, self.device) for _ in range(3))
+        h_in, c_in = self._to_dev(hid), self._to_dev(cel)
+        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        ident = torch.arange(R, device=self.device, dtype=torch.int32)
+        word = torch.as_tensor(index, device=self.device, dtype=torch.int32)
+        st = d.stream()
+        ev0.record()
+        d.lstm_step(h_in.data_ptr(), c_in.data_ptr(), d.H, h_out.data_ptr(), c_out.data_ptr(), None, ident.data_ptr(),
+                    word.data_ptr(), R, None, st)
+        ev1.record()
+        y, n_cols, _keep = self._project_dev(h_out, R, vocab)
+        pred = torch.empty_like(y)
+        _lib.check(L.jlm_softmax_rows(y.data_ptr(), pred.data_ptr(), y.shape[1], R, n_cols,
+                                      1 if self.config['self_norm'] else 0, st), "jlm_softmax_rows")
+        ev2.record()
+        _sync(torch, self.device)
+        self.hidden = h_out.double().cpu().numpy()
+        self.cell = c_out.double().cpu().numpy()
+        y_np = y[:, :n_cols].double().cpu().numpy()
+        pred_np = pred[:, :n_cols].double().cpu().numpy()
+        return pred_np, y_np, ev0.seconds_to(ev1), ev1.seconds_to(ev2)
+
+    def project(self, hidden, vocab=None):
+        hid = np.asarray(hidden, dtype=np.float64)
+        if hid.ndim == 1:
+            hid = hid[None, :]
+        y, n_cols, _keep = self._project_dev(self._to_dev(hid), hid.shape[0], vocab)
+        _sync(self.dev.torch, self.device)
+        return y[:, :n_cols].double().cpu().numpy()
+
+    def predict_with_context(self, index, hidden, cell, vocab=None):
+        self.hidden = hidden
+        self.cell = cell
+        return self.predict(index, vocab), self.hidden, self.cell
+
+    def evaluate(self, start, inputs):
+        """Per-word -log p of a sequence.  The reference's version
+        (model.py:200-206) indexes the predict() tuple and raises TypeError;
+        this is the evidently intended computation."""
+        probs = []
+        pred = self.predict([start], vocab=None, reset=True)[0]
+        for inp in inputs:
+            probs.append(pred[0, inp])
+            pred = self.predict([inp])[0]
+        return [-np.log(p) for p in probs]

@@ -1,0 +1,313 @@
+"""A numpy test double of libjlm_hip.so's C ABI (include/jlm_hip.h).
+
+TEST INFRASTRUCTURE ONLY.  It lets the CPU-only suite drive the real host code
+(weight packing, lattice CSR, engine launch sequence, read-out) end to end by
+standing in for the device kernels, reading and writing the same buffers through
+the same raw pointers.  It is never importable from the product package and the
+product never falls back to it; the GPU tests run the real library.
+
+Each function restates the CONTRACT written in the header, not the HIP code.
+"""
+import ctypes
+
+import numpy as np
+
+NEG = -3.0e38
+_CT = {np.float32: ctypes.c_float, np.float64: ctypes.c_double, np.int32: ctypes.c_int32}
+
+
+def _p(x):
+    if x is None:
+        return 0
+    if isinstance(x, ctypes.c_void_p):
+        return x.value or 0
+    return int(x)
+
+
+def view(ptr, count, dtype):
+    ptr = _p(ptr)
+    assert ptr != 0
+    buf = (_CT[dtype] * int(count)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+def _n(n_max, n_dev):
+    if _p(n_dev):
+        return min(int(view(n_dev, 1, np.int32)[0]), n_max)
+    return n_max
+
+
+def _rows(rows, n):
+    return view(rows, n, np.int32).astype(np.int64) if _p(rows) else np.arange(n, dtype=np.int64)
+
+
+class FakeLib:
+    def jlm_abi_version(self):
+        return 1
+
+    # ------------------------------------------------------------------ K1-K3
+    def jlm_lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,
+                      n_rows_max, n_dev, stream):
+        n = _n(n_rows_max, n_dev)
+        if n == 0:
+            return 0
+        g = _rows(rows, n)
+        gmax = int(g.max()) + 1
+        p = view(prev, gmax, np.int32)[g].astype(np.int64)
+        w = view(word, gmax, np.int32)[g].astype(np.int64)
+        hmax = max(gmax, int(p.max()) + 1)
+        hin = view(h_in, hmax * ld, np.float32).reshape(hmax, ld)
+        cin = view(c_in, hmax * ld, np.float32).reshape(hmax, ld)
+        embv = view(emb, (int(w.max()) + 1) * ld_emb, np.float32).reshape(-1, ld_emb)
+        x = np.zeros((n, kpad), dtype=np.float32)
+        ok = p >= 0
+        x[ok, :H] = hin[p[ok], :H]
+        x[:, H:H + E] = embv[w, :E]
+        cp = np.zeros((n, H), dtype=np.float32)
+        cp[ok] = cin[p[ok], :H]
+        W = view(wt, 4 * H * kpad, np.float32).reshape(4 * H, kpad)
+        b = view(bias, 4 * H, np.float32)
+        z = (x.astype(np.float64) @ W.T.astype(np.float64)).astype(np.float32) + b
+        u = np.arange(H)
+        zi, zf, zo, zg = (z[:, (u // 32) * 128 + k * 32 + (u % 32)] for k in range(4))
+        sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
+        cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
+        hn = np.tanh(cn) * sig(zo)
+        hout = view(h_out, gmax * ld, np.float32).reshape(gmax, ld)
+        cout = view(c_out, gmax * ld, np.float32).reshape(gmax, ld)
+        hout[g, :H] = hn
+        cout[g, :H] = cn
+        return 0
+
+    # --------------------------------------------------------------------- K4
+    def jlm_gemm_nt(self, A, lda, a_rows, B, ldb, b_rows, C, ldc, c_rows, bias, M, N, K, m_dev, stream):
+        m = _n(M, m_dev)
+        if m == 0 or N == 0:
+            return 0
+        ar, br, cr = _rows(a_rows, m), _rows(b_rows, N), _rows(c_rows, m)
+        Av = view(A, (int(ar.max()) + 1) * lda, np.float32).reshape(-1, lda)[ar, :K]
+        Bv = view(B, (int(br.max()) + 1) * ldb, np.float32).reshape(-1, ldb)[br, :K]
+        out = (Av.astype(np.float64) @ Bv.T.astype(np.float64)).astype(np.float32)
+        if _p(bias):
+            out = out + view(bias, N, np.float32)
+        # C may be a column-offset view: address rows individually
+        base = _p(C)
+        for i, r in enumerate(cr):
+            view(base + 4 * int(r) * ldc, N, np.float32)[:] = out[i]
+        return 0
+
+    # ------------------------------------------------------------------ K5+K6
+    def jlm_vocab_lse_partials(self, Bseg, ldb, n_vocab, K, T, ldt, rows, bias, part, ld_part, tile0, n_rows_max,
+                               n_dev, stream):
+        ntiles = (n_vocab + 127) // 128
+        n = _n(n_rows_max, n_dev)
+        if n == 0:
+            return ntiles
+        g = _rows(rows, n)
+        base = _p(T)
+        Tv = np.stack([view(base + 4 * int(r) * ldt, K, np.float32) for r in g])
+        Bv = view(Bseg, n_vocab * ldb, np.float32).reshape(n_vocab, ldb)[:, :K]
+        y = (Tv.astype(np.float64) @ Bv.T.astype(np.float64)).astype(np.float32) + view(bias, n_vocab, np.float32)
+        pv = view(part, (tile0 + ntiles) * ld_part * 2, np.float32).reshape(-1, ld_part, 2)
+        for t in range(ntiles):
+            yt = y[:, t * 128:(t + 1) * 128]
+            mx = yt.max(axis=1)
+            pv[tile0 + t, :n, 0] = mx
+            pv[tile0 + t, :n, 1] = np.exp(yt - mx[:, None]).sum(axis=1)
+        return ntiles
+
+    def jlm_lse_combine(self, part, ld_part, n_tiles, rows, lse, n_rows_max, n_dev, stream):
+        n = _n(n_rows_max, n_dev)
+        if n == 0:
+            return 0
+        g = _rows(rows, n)
+        pv = view(part, n_tiles * ld_part * 2, np.float32).reshape(n_tiles, ld_part, 2)[:, :n].astype(np.float64)
+        mx = pv[:, :, 0].max(axis=0)
+        s = (pv[:, :, 1] * np.exp(pv[:, :, 0] - mx[None, :])).sum(axis=0)
+        view(lse, int(g.max()) + 1, np.float64)[g] = mx + np.log(s)
+        return 0
+
+    # ------------------------------------------------------------- word lists
+    def _segs(self, segs, n_segs):
+        return [segs[i] for i in range(n_segs)]
+
+    def _word_logits(self, segs, b2, T, ldt, g0, nrows, words):
+        """[len(words), nrows] float32 logits of hypothesis rows g0.. for the words."""
+        out = np.zeros((len(words), nrows), dtype=np.float32)
+        for i, w in enumerate(words):
+            w = int(w)
+            for sg in segs:
+                if sg.v_start <= w < sg.v_end:
+                    brow = view(sg.B + 4 * (w - sg.v_start) * sg.ldb, sg.k, np.float32).astype(np.float64)
+                    for k in range(nrows):
+                        t = view(_p(T) + 4 * ((g0 + k) * ldt + sg.t_off), sg.k, np.float32).astype(np.float64)
+                        out[i, k] = np.float32(np.dot(brow, t))
+                    break
+            out[i] += view(_p(b2) + 4 * int(w), 1, np.float32)[0]
+        return out
+
+    def _groups(self, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
+        g0v = view(g0, n_groups, np.int32)
+        ci = view(cnt_idx, n_groups, np.int32)
+        li = view(wl_idx, n_groups, np.int32)
+        for j in range(n_groups):
+            nrows = min(int(view(_p(cnt) + 4 * int(ci[j]), 1, np.int32)[0]), beam)
+            lid = wl_base + int(li[j])
+            a, b = (int(x) for x in view(_p(wl_off) + 4 * lid, 2, np.int32))
+            words = view(_p(wl) + 4 * a, b - a, np.int32) if b > a else np.zeros(0, np.int32)
+            yield int(g0v[j]), nrows, a, words
+
+    def jlm_edge_logits(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, wl_out, edge,
+                        beam, n_groups, stream):
+        sg = self._segs(segs, n_segs)
+        for gb, nrows, a, words in self._groups(g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
+            if nrows <= 0 or len(words) == 0:
+                continue
+            y = self._word_logits(sg, b2, T, ldt, gb, nrows, words)
+            outs = view(_p(wl_out) + 4 * a, len(words), np.int32)
+            for i, n in enumerate(outs):
+                view(_p(edge) + 4 * int(n) * beam, nrows, np.float32)[:] = y[i]
+        return 0
+
+    def jlm_wordlist_lse(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max,
+                         run_sum, lse, merge, beam, n_groups, stream):
+        sg = self._segs(segs, n_segs)
+        for gb, nrows, a, words in self._groups(g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
+            if nrows <= 0:
+                continue
+            rm = view(_p(run_max) + 4 * gb, nrows, np.float32)
+            rs = view(_p(run_sum) + 8 * gb, nrows, np.float64)
+            ls = view(_p(lse) + 8 * gb, nrows, np.float64)
+            if len(words):
+                y = self._word_logits(sg, b2, T, ldt, gb, nrows, words).astype(np.float64)
+                m = y.max(axis=0)
+                s = np.exp(y - m[None, :]).sum(axis=0)
+            else:
+                m = np.full(nrows, NEG)
+                s = np.zeros(nrows)
+            if merge:
+                M = np.maximum(rm.astype(np.float64), m)
+                s = rs * np.exp(rm - M) + s * np.exp(m - M)
+                m = M
+            rm[:] = m
+            rs[:] = s
+            with np.errstate(divide="ignore"):
+                ls[:] = m + np.log(s)
+        return 0
+
+    # ------------------------------------------------------------------- beam
+    def jlm_beam_step(self, lat, st, frame, mode, max_cands, stream):
+        lat, st = lat._obj if hasattr(lat, "_obj") else lat, st._obj if hasattr(st, "_obj") else st
+        B, beam, F = lat.n_sent, lat.beam, lat.n_frames
+        rmax = B * beam
+        G = F * rmax
+        slen = view(lat.sent_len, B, np.int32)
+        end_off = view(lat.end_off, F * B + 1, np.int32)
+        n_nodes = int(end_off[-1])
+        nstart = view(lat.node_start, n_nodes, np.int32)
+        nword = view(lat.node_word, n_nodes, np.int32)
+        score, lse = view(st.score, G, np.float64), view(st.lse, G, np.float64)
+        ysum = view(st.ysum, G, np.float64) if _p(st.ysum) else None
+        bp, node, word = (view(x, G, np.int32) for x in (st.bp, st.node, st.word))
+        cnt = view(st.cnt, F * B, np.int32)
+        live = view(st.live, G, np.int32)
+        n_live = view(st.n_live, F, np.int32)
+        edge = view(st.edge, max(n_nodes, 1) * beam, np.float32)
+        for s in range(B):
+            fs = frame * B + s
+            if frame > slen[s]:
+                cnt[fs] = 0
+                continue
+            nb, ne = int(end_off[fs]), int(end_off[fs + 1])
+            gout = frame * rmax + s * beam
+            if frame == 0:
+                K = 1
+                score[gout] = 0.0
+                if ysum is not None:
+                    ysum[gout] = 0.0
+                bp[gout], node[gout], word[gout] = -1, nb, nword[nb]
+            else:
+                assert (ne - nb) * beam <= max_cands
+                S = {}
+                if mode == 2:
+                    for f in range(frame):
+                        for k in range(int(cnt[f * B + s])):
+                            g = f * rmax + s * beam + k
+                            p = int(bp[g])
+                            S[g] = 0.0 if p < 0 else S[p] + lse[p]
+                cands = []
+                for n in range(nb, ne):
+                    sf = int(nstart[n])
+                    for k in range(int(cnt[sf * B + s])):
+                        gp = sf * rmax + s * beam + k
+                        e = float(edge[n * beam + k])
+                        if mode == 0:
+                            sc = score[gp] + (lse[gp] - e)
+                        elif mode == 1:
+                            sc = score[gp] - e
+                        else:
+                            sc = (S[gp] + lse[gp]) - (ysum[gp] + e)
+                        cands.append((sc, (n - nb) * beam + k, n, gp, e))
+                cands.sort(key=lambda c: (c[0], c[1]))
+                K = min(beam, len(cands))
+                for r in range(K):
+                    sc, _c, n, gp, e = cands[r]
+                    score[gout + r] = sc
+                    if mode == 2:
+                        ysum[gout + r] = ysum[gp] + e
+                    bp[gout + r], node[gout + r], word[gout + r] = gp, n, nword[n]
+            cnt[fs] = K
+            if frame < slen[s]:
+                base = int(n_live[frame])
+                n_live[frame] = base + K
+                live[frame * rmax + base: frame * rmax + base + K] = np.arange(gout, gout + K)
+        return 0
+
+    def jlm_backtrace(self, lat, st, out_nodes, out_len, out_score, stride, stream):
+        lat, st = lat._obj if hasattr(lat, "_obj") else lat, st._obj if hasattr(st, "_obj") else st
+        B, beam, F = lat.n_sent, lat.beam, lat.n_frames
+        rmax = B * beam
+        G = F * rmax
+        slen = view(lat.sent_len, B, np.int32)
+        score = view(st.score, G, np.float64)
+        bp, node = view(st.bp, G, np.int32), view(st.node, G, np.int32)
+        cnt = view(st.cnt, F * B, np.int32)
+        on = view(out_nodes, rmax * stride, np.int32).reshape(rmax, stride)
+        ol, osc = view(out_len, rmax, np.int32), view(out_score, rmax, np.float64)
+        for idx in range(rmax):
+            s, r = divmod(idx, beam)
+            L = int(slen[s])
+            if r >= cnt[L * B + s]:
+                ol[idx], osc[idx] = 0, 0.0
+                continue
+            g = L * rmax + s * beam + r
+            osc[idx] = score[g]
+            d = 0
+            while g >= 0 and d < stride:
+                on[idx, d] = node[g]
+                d += 1
+                g = int(bp[g])
+            ol[idx] = d
+        return 0
+
+    def jlm_softmax_rows(self, y, pred, ld, n_rows, n_cols, self_norm, stream):
+        yv = view(y, n_rows * ld, np.float32).reshape(n_rows, ld)[:, :n_cols]
+        pv = view(pred, n_rows * ld, np.float32).reshape(n_rows, ld)
+        if self_norm:
+            pv[:, :n_cols] = np.exp(yv)
+        else:
+            e = np.exp(yv - yv.max(axis=1, keepdims=True))
+            pv[:, :n_cols] = e / e.sum(axis=1, keepdims=True)
+        return 0
+
+
+def install(monkeypatch):
+    """Route jlm_amd's library handle and device checks to the CPU double."""
+    import torch
+    from jlm_amd import _lib, model
+
+    fake = FakeLib()
+    monkeypatch.setattr(_lib, "lib", lambda: fake)
+    monkeypatch.setattr(_lib, "require_gpu", lambda: torch.device("cpu"))
+    monkeypatch.setattr(model.DeviceModel, "stream", lambda self: 0)
+    return fake

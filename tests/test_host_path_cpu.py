@@ -1,0 +1,111 @@
+"""CPU-only: the real host code (weight packing, lattice CSR, engine launch
+sequence, read-out, reference-compatible classes) driven end to end with the
+numpy test double of the C ABI (tests/fake_hip.py), checked against the golden
+vectors captured from the reference.  The kernels themselves are checked on the
+GPU box (tests/test_gpu_*.py)."""
+import numpy as np
+import pytest
+
+from jlm_amd import config as jconfig
+from oracle import jlm_oracle as orc
+from tests import fake_hip
+from tests import golden_cases as gc
+
+SMALL = [c for c in gc.DECODE_CASES if c[0].startswith("small-")]
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    return fake_hip.install(monkeypatch)
+
+
+def _decoder(f, kind):
+    jconfig.set_root(f["root"])
+    from jlm_amd.decoder import Decoder
+    from jlm_amd.decoder_dynamic import DynamicDecoder
+    d = (DynamicDecoder if kind == "dynamic" else Decoder)(1)
+    d.perf_timing = False
+    return d
+
+
+@pytest.mark.parametrize("name", ["small-tied", "small-untied", "small-dsoftmax", "small-vtable", "small-tied-sn"])
+def test_lstm_model_api_matches_reference(name, fx, fake, golden_lm):
+    f = fx(name)
+    jconfig.set_root(f["root"])
+    from jlm_amd.model import LSTM_Model
+    lm = LSTM_Model(1)
+    for rows in gc.LM_ROWS:
+        idx, subset, cols, h0, c0 = gc.lm_inputs(f["cfg"], rows)
+        for kind in ("full", "subset"):
+            if kind == "subset" and not f["cfg"]["share_embedding"]:
+                continue
+            vocab = subset if kind == "subset" else None
+            h, c = h0.copy(), c0.copy()
+            for step in range(gc.LM_STEPS):
+                (pred, y, _t1, _t2), h, c = lm.predict_with_context(idx[step], h, c, vocab)
+            key = "%s/%s/R%d" % (name, kind, rows)
+            np.testing.assert_allclose(h, golden_lm[key + "/h"], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(c, golden_lm[key + "/c"], rtol=2e-5, atol=2e-6)
+            ysel = y if kind == "subset" else y[:, cols]
+            psel = pred if kind == "subset" else pred[:, cols]
+            scale = np.abs(golden_lm[key + "/y"]).max()
+            assert np.abs(ysel - golden_lm[key + "/y"]).max() <= 1e-4 * scale
+            np.testing.assert_allclose(psel, golden_lm[key + "/pred"], rtol=2e-4)
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[c[0] for c in SMALL])
+def test_decoders_match_reference_golden(case, fx, fake, golden_decode):
+    name, fixture, kind, kwargs, spec = case
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    sents = gc.case_sentences(spec, f["alphabet"])
+    gold = golden_decode[name]
+    if kwargs.get("random_sampling"):
+        outs = []
+        for si, s in enumerate(sents):
+            np.random.seed(gc.RANDOM_SAMPLING_SEED + si)
+            outs.append(dec.decode(s, **kwargs))
+    else:
+        outs = dec.decode_batch(sents, **kwargs)          # ragged batch in one go
+    dyn_seg = kind == "dynamic" and fixture.split("-")[1] in ("dsoftmax", "vtable")
+    assert not dyn_seg
+    for si, out in enumerate(outs):
+        g = gold[si]["nbest"]
+        assert len(out) == len(g), (name, si)
+        assert [w for _, w in out] == [w for _, w in g], (name, si)
+        np.testing.assert_allclose([sc for sc, _ in out], [sc for sc, _ in g], rtol=1e-5, atol=1e-4)
+
+
+def test_single_sentence_api_and_attrs(fx, fake, golden_decode):
+    f = fx("small-tied")
+    dec = _decoder(f, "static")
+    case = [c for c in gc.DECODE_CASES if c[0] == "small-tied/static-vs"][0]
+    sents = gc.case_sentences(case[4], f["alphabet"])
+    out = dec.decode(sents[2], **case[3])
+    assert [w for _, w in out] == [w for _, w in golden_decode[case[0]][2]["nbest"]]
+    assert dec.perf_sen == 1
+    ends = orc.build_lattice(sents[2], dec.full_lexicon, dec.full_reading_dict, dec.w2i)
+    assert dec.backward_lookup == ends
+    assert dec.lattice_vocab == orc.static_vocab(ends)
+    bl = dec._build_lattice(sents[2])
+    assert [[(n.start_idx, n.reading_length, n.word_idx, n.word) for n in bl[i]] for i in range(len(ends))] == ends
+    assert dec._check_oov("no-such-word") and not dec._check_oov("<eos>")
+
+
+def test_dynamic_requires_vocab_select(fx, fake):
+    f = fx("small-tied")
+    dec = _decoder(f, "dynamic")
+    with pytest.raises(TypeError):
+        dec.decode("アイウ", vocab_select=False)
+    with pytest.raises(ValueError):
+        dec.decode("アイウ", beam_width=None, vocab_select=True)
+
+
+def test_dynamic_lattice_vocab_matches_reference_lists(fx, fake):
+    f = fx("small-tied")
+    dec = _decoder(f, "dynamic")
+    o = orc.OracleDynamicDecoder(f["root"], 1)
+    for s in gc.case_sentences(("ragged", 5, 2, 12, 21), f["alphabet"]):
+        dec.decode(s, vocab_select=True, samples=7, top_sampling=True)
+        o.decode(s, vocab_select=True, samples=7, top_sampling=True)
+        assert dec.lattice_vocab == o.lattice_vocab
