@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: decoded kana chars/sec of the batched lattice decode.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: BASELINE.json configs[1]
+(LSTM h=512, D-softmax* segs (200,100,50) over V=50k, beam=10, 256 synthetic
+20-kana sentences) per GPU; sentences shard across ranks with no collective on
+the data path (weak scaling: every rank decodes its own 256 sentences).  The
+timed region starts with the batch's lattice (CSR) and the weights resident in
+HBM and ends when the n-best back-pointer traces are back on the host; K steps
+are bracketed by barrier + synchronize on both sides and the MAX over ranks is
+reported.  The host-inclusive rate (lattice build from the kana strings, upload,
+string read-out) is reported beside it as "end_to_end_chars_per_s".
+
+One JSON line on rank 0 (contract in the task statement) plus
+  roofline     : dominant kernel (fused vocabulary-projection/log-sum-exp GEMM,
+                 f32 MFMA) -- algorithmic FLOPs / live HIP-event duration
+  gate_gemm    : the same for the fused LSTM gate GEMM (BASELINE metric, part 2)
+  cpu_baseline : the numpy oracle (a port of the reference path) timed on this
+                 node's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU per step")
+    ap.add_argument("--length", type=int, default=20, help="kana per sentence")
+    ap.add_argument("--beam", type=int, default=10)
+    ap.add_argument("--fixture", default="mid-vtable", help="mid-vtable (configs[1]) | mid-tied | big-tied")
+    ap.add_argument("--cpu-sentences", type=int, default=32, help="bounded CPU-baseline sample (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true", help="time the host-inclusive path as the step")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        ge.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+
+    from jlm_amd import config as jconfig, synth
+    from jlm_amd.decoder import Decoder
+    from jlm_amd.lattice import BatchLattice
+    from jlm_amd.model import KernelRecorder
+
+    root = os.path.join(tempfile.gettempdir(), "jlm_bench_%d_%s_r%d" % (os.getuid(), args.fixture, rank))
+    cfg, _lex, _rd, alphabet = synth.build_fixture(root, args.fixture)
+    jconfig.set_root(root)
+    dec = Decoder(1)
+    dec.perf_timing = False
+    eng, m = dec._engine, dec.model.dev
+    # every rank decodes its own sentences (seeded by rank): sentence sharding, no data-path collective
+    sents = synth.make_sentences(args.batch, args.length, seed=4242 + rank, alphabet=alphabet)
+    chars_per_step = sum(len(s) for s in sents)
+
+    def host_step():
+        return dec.decode_batch(sents, beam_width=args.beam)
+
+    lat = BatchLattice(dec._builder, sents, args.beam)
+
+    def device_step():
+        return eng.decode(lat, "static", topN=10)
+
+    step = host_step if args.end_to_end else device_step
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    rec = KernelRecorder(torch)
+    eng.recorder = rec
+    n_live_steps = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        n_live_steps.append(eng.last_n_live)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.recorder = None
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([float(chars_per_step)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_chars_per_step = float(c.item())
+    else:
+        total_chars_per_step = float(chars_per_step)
+
+    # host-inclusive rate (not `value`): kana strings in, n-best strings out
+    barrier()
+    t1 = time.perf_counter()
+    e2e_steps = max(1, min(3, args.steps))
+    for _ in range(e2e_steps):
+        host_step()
+    barrier()
+    e2e = chars_per_step * e2e_steps / (time.perf_counter() - t1) * world
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- per-kernel roofline from the live HIP-event brackets
+    durs = rec.durations_ms()
+    rows = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in n_live_steps])    # live rows per launch
+    H = m.H
+
+    def kernel_stats(name, flops_per_row):
+        d = np.asarray(durs.get(name, []), dtype=np.float64)
+        if d.size == 0:
+            return None
+        n = min(d.size, rows.size)
+        flops = float((rows[:n] * flops_per_row).sum())
+        secs = float(d[:n].sum()) * 1e-3
+        return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12,
+                    flops_per_launch=flops / n)
+
+    seg_stats = []
+    for i, sg in enumerate(m.segments):
+        st = kernel_stats("vocab_lse_seg%d" % i, 2.0 * sg["k"] * (sg["v_end"] - sg["v_start"]))
+        if st:
+            seg_stats.append(st)
+    gate = kernel_stats("gate_gemm", 2.0 * (H + m.E_in) * 4 * H)
+    roofline = None
+    if seg_stats:
+        flops = sum(s["flops_per_launch"] * s["launches"] for s in seg_stats)
+        secs = sum(s["avg_ms"] * s["launches"] for s in seg_stats) * 1e-3
+        n_launch = sum(s["launches"] for s in seg_stats)
+        ach = flops / secs / 1e12
+        roofline = {"kernel": "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(secs * 1e3 / n_launch, 4), "launches": n_launch,
+                    "flops_per_launch": flops / n_launch, "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    gate_obj = None
+    if gate:
+        gate_obj = {"kernel": "gemm_nt_kernel<128x128,EpiGate> (jlm_lstm_step)", "achieved": round(gate["tflops"], 2),
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "mfma_util_pct": round(100.0 * gate["tflops"] / F32_MFMA_PEAK_TFLOPS, 2),
+                    "avg_launch_ms": round(gate["avg_ms"], 4), "launches": gate["launches"]}
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import jlm_oracle as orc
+        o = orc.OracleDecoder(root, 1)
+        n = min(args.cpu_sentences, len(sents))
+        t2 = time.perf_counter()
+        ref_out = [o.decode(s, beam_width=args.beam) for s in sents[:n]]
+        cdt = time.perf_counter() - t2
+        gpu_out = dec.decode_batch(sents[:n], beam_width=args.beam)
+        same = sum(1 for a, b in zip(ref_out, gpu_out) if a[0][1] == b[0][1])
+        cpu = {"value": round(sum(len(s) for s in sents[:n]) / cdt, 2), "unit": "chars/s", "cores": os.cpu_count(),
+               "kind": "port",
+               "sample": "%d of the step's %d sentences, sentence-at-a-time numpy oracle (oracle/jlm_oracle.py), "
+                         "BLAS threads = all cores; lstm %.1f%% / proj+softmax %.1f%% of its time; "
+                         "1-best identical to the GPU path on %d/%d" % (
+                             n, len(sents), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
+
+    value = total_chars_per_step * args.steps / dt
+    line = {
+        "metric": "decoded chars/sec at beam=%d, vocab=%dk (lattice resident in HBM -> n-best traces on host)" % (
+            args.beam, cfg["vocab_size"] // 1000),
+        "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: LSTM h=512, D-softmax* segs=(200,100,50), V=50k, beam=10, "
+                               "batch=256 sentences x 20 kana per GPU" if args.fixture == "mid-vtable" else
+                               "%s batch=%d length=%d beam=%d" % (args.fixture, args.batch, args.length, args.beam),
+                   "fixture": args.fixture, "sentences_per_gpu": args.batch, "kana_per_sentence": args.length,
+                   "beam": args.beam, "timed": "end_to_end" if args.end_to_end else "device",
+                   "parallelism": "sentence-sharded x%d, no collective" % world},
+        "end_to_end_chars_per_s": round(e2e, 1),
+        "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,8 @@ class DecodeEngine:
         self.device = dev_model.device
         self.last_timing = None
         self.last_state = None
+        self.recorder = None            # optional model.KernelRecorder (bench.py)
+        self.last_n_live = None
 
     def _upload_ints(self, arrays):
         """One H2D copy for a dict of int32 arrays -> dict of device pointers."""
@@ -126,7 +128,7 @@ class DecodeEngine:
             if timing:
                 e0, e1, e2 = (_Stamp(torch, dev) for _ in range(3))
                 e0.record()
-            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st)
+            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st, self.recorder)
             if timing:
                 e1.record()
             m.project_T(hp, H, Tp, rows, rmax, ndev, st)
@@ -143,7 +145,7 @@ class DecodeEngine:
                                                   run_max.data_ptr(), run_sum.data_ptr(), lsep, 0, beam, B, st),
                                "jlm_wordlist_lse(vocab_select)")
                 else:
-                    m.full_vocab_lse(Tp, rows, part.data_ptr(), rmax, lsep, rmax, ndev, st)
+                    m.full_vocab_lse(Tp, rows, part.data_ptr(), rmax, lsep, rmax, ndev, st, self.recorder)
             _lib.check(L.jlm_edge_logits(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
                                          ip["sg_word"], ip["sg_off"], ip["sidx"], f * B, ip["sg_node"],
                                          edge.data_ptr(), beam, B, st), "jlm_edge_logits")
@@ -157,6 +159,8 @@ class DecodeEngine:
         out_score = torch.empty(rmax, device=dev, dtype=f64)
         _lib.check(L.jlm_backtrace(latS, stS, out_nodes.data_ptr(), out_len.data_ptr(), out_score.data_ptr(), stride, st),
                    "jlm_backtrace")
+        if self.recorder is not None:
+            self.last_n_live = n_live.cpu().numpy()
         nodes_h = out_nodes.cpu().numpy()
         len_h = out_len.cpu().numpy()
         score_h = out_score.cpu().numpy()

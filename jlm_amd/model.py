@@ -94,6 +94,30 @@ class _Stamp:
         return other.t - self.t
 
 
+class KernelRecorder:
+    """HIP-event brackets around single kernel launches on the launching stream
+    (bench.py's live per-kernel durations).  Events are resolved after the run."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.spans = {}
+        self._open = {}
+
+    def begin(self, name):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._open[name] = e
+
+    def end(self, name):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.spans.setdefault(name, []).append((self._open.pop(name), e))
+
+    def durations_ms(self):
+        """name -> list of per-launch milliseconds (call after a synchronize)."""
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.spans.items()}
+
+
 def _sync(torch, device):
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -219,11 +243,15 @@ class DeviceModel:
     def stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
-    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream):
+    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream, rec=None):
         L = _lib.lib()
+        if rec is not None:
+            rec.begin("gate_gemm")
         _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
                                    self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),
                                    self.kpad, self.H, self.Epad, n_rows_max, n_dev, stream), "jlm_lstm_step")
+        if rec is not None:
+            rec.end("gate_gemm")
 
     def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream):
         """T[g] = h[g].PM (+ the V_table projections).  No-op for untied models
@@ -238,14 +266,18 @@ class DeviceModel:
             _lib.check(L.jlm_gemm_nt(T, self.ldt, rows, vt.data_ptr(), self.E0p, None, T + 4 * t_off, self.ldt, rows,
                                      None, n_rows_max, n_pad, self.E0p, n_dev, stream), "jlm_gemm_nt(VT)")
 
-    def full_vocab_lse(self, T, rows, part, ld_part, lse, n_rows_max, n_dev, stream):
+    def full_vocab_lse(self, T, rows, part, ld_part, lse, n_rows_max, n_dev, stream, rec=None):
         L = _lib.lib()
         tile0 = 0
         for i, sg in enumerate(self.segments):
             nv = sg["v_end"] - sg["v_start"]
+            if rec is not None:
+                rec.begin("vocab_lse_seg%d" % i)
             r = L.jlm_vocab_lse_partials(self.seg_B[i].data_ptr(), sg["ldb"], nv, sg["k"], T + 4 * sg["t_off"], self.ldt,
                                          rows, self.b2.data_ptr() + 4 * sg["v_start"], part, ld_part, tile0,
                                          n_rows_max, n_dev, stream)
+            if rec is not None:
+                rec.end("vocab_lse_seg%d" % i)
             if r < 0:
                 raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
             tile0 += r

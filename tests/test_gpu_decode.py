@@ -1,0 +1,143 @@
+"""GPU: end-to-end parity of the reference-compatible classes, running on the
+HIP library, against (a) the golden vectors captured from the reference and
+(b) the CPU oracle on the same seeded inputs; plus size-independent properties
+at BASELINE.json's full batch sizes.
+
+Bars (BASELINE.json north_star): step logits <= 1e-4 relative, identical 1-best
+decode strings.  Path scores are sums of ~20 float32-derived terms of size ~10,
+so they are compared at 1e-5 relative / 1e-3 absolute."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from jlm_amd import config as jconfig, synth      # noqa: E402
+from oracle import jlm_oracle as orc              # noqa: E402
+from tests import golden_cases as gc              # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+_DEC = {}
+
+
+def _decoder(f, kind):
+    key = (f["root"], kind)
+    if key not in _DEC:
+        jconfig.set_root(f["root"])
+        from jlm_amd.decoder import Decoder
+        from jlm_amd.decoder_dynamic import DynamicDecoder
+        _DEC[key] = (DynamicDecoder if kind == "dynamic" else Decoder)(1)
+    jconfig.set_root(f["root"])
+    return _DEC[key]
+
+
+def _check_nbest(out, gold, tag, strict_nbest=True):
+    assert len(out) == len(gold), tag
+    assert out[0][1] == gold[0][1], ("1-best differs", tag, out[0], gold[0])
+    np.testing.assert_allclose([s for s, _ in out], [s for s, _ in gold], rtol=1e-5, atol=1e-3, err_msg=str(tag))
+    same = [w for _, w in out] == [w for _, w in gold]
+    if strict_nbest:
+        assert same, ("n-best order differs", tag)
+    return same
+
+
+@pytest.mark.parametrize("name", gc.LM_FIXTURES)
+def test_step_logits_within_1e4_of_reference(name, fx, golden_lm):
+    f = fx(name)
+    jconfig.set_root(f["root"])
+    from jlm_amd.model import LSTM_Model
+    lm = LSTM_Model(1)
+    for rows in gc.LM_ROWS:
+        idx, subset, cols, h0, c0 = gc.lm_inputs(f["cfg"], rows)
+        for kind in ("full", "subset"):
+            if kind == "subset" and not f["cfg"]["share_embedding"]:
+                continue
+            vocab = subset if kind == "subset" else None
+            h, c = h0.copy(), c0.copy()
+            for step in range(gc.LM_STEPS):
+                (pred, y, _t1, _t2), h, c = lm.predict_with_context(idx[step], h, c, vocab)
+            key = "%s/%s/R%d" % (name, kind, rows)
+            ysel = y if kind == "subset" else y[:, cols]
+            psel = pred if kind == "subset" else pred[:, cols]
+            yref = golden_lm[key + "/y"]
+            # <= 1e-4 relative on the step logits (relative to the row's logit scale; element-wise
+            # relative error is meaningless for logits that happen to be ~0)
+            scale = np.abs(yref).max(axis=1, keepdims=True)
+            rel = np.abs(ysel - yref) / scale
+            assert rel.max() <= 1e-4, (key, rel.max())
+            np.testing.assert_allclose(h, golden_lm[key + "/h"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(c, golden_lm[key + "/c"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(psel, golden_lm[key + "/pred"], rtol=2e-4)
+            np.testing.assert_allclose(pred.sum(axis=1), golden_lm[key + "/predsum"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", gc.DECODE_CASES, ids=[c[0] for c in gc.DECODE_CASES])
+def test_decode_matches_reference_golden(case, fx, golden_decode):
+    name, fixture, kind, kwargs, spec = case
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    sents = gc.case_sentences(spec, f["alphabet"])
+    gold = golden_decode[name]
+    assert [g["input"] for g in gold] == sents
+    if kwargs.get("random_sampling"):
+        outs = []
+        for si, s in enumerate(sents):
+            np.random.seed(gc.RANDOM_SAMPLING_SEED + si)
+            outs.append(dec.decode(s, **kwargs))
+    else:
+        outs = dec.decode_batch(sents, **kwargs)
+    n_same = 0
+    for si, out in enumerate(outs):
+        n_same += _check_nbest(out, gold[si]["nbest"], (name, si), strict_nbest=False)
+    # n-best ORDER may legitimately flip where two hypotheses tie to ~1e-6; it must be rare
+    assert n_same >= 0.9 * len(outs), (name, n_same, len(outs))
+
+
+def test_single_sentence_equals_batch(fx):
+    f = fx("small-vtable")
+    dec = _decoder(f, "static")
+    sents = synth.make_ragged_sentences(9, 1, 18, seed=31, alphabet=f["alphabet"])
+    batch = dec.decode_batch(sents, beam_width=6)
+    for s, b in zip(sents, batch):
+        one = dec.decode(s, beam_width=6)
+        assert [w for _, w in one] == [w for _, w in b]
+        np.testing.assert_allclose([x for x, _ in one], [x for x, _ in b], rtol=0, atol=1e-9)
+    assert dec.perf_log_lstm and dec.perf_log_softmax and all(t >= 0 for t in dec.perf_log_lstm)
+
+
+def _readings_ok(words, text):
+    r = "".join(w.split("/")[1] if "/" in w else w for w in words)
+    return r == text
+
+
+@pytest.mark.parametrize("fixture,kind,kwargs,n,beam", [
+    ("mid-vtable", "static", {}, 256, 10),                                  # BASELINE.json configs[1]
+    ("mid-tied", "dynamic", dict(vocab_select=True), 256, 10),              # configs[3]
+    ("big-tied", "static", {}, 1024, 20),                                   # configs[2]
+])
+def test_full_size_properties(fixture, kind, kwargs, n, beam, fx):
+    """Size-independent properties at the benchmark's batch sizes + oracle parity on a sample."""
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    dec.perf_timing = False
+    sents = synth.make_sentences(n, 20, seed=2024, alphabet=f["alphabet"])
+    out = dec.decode_batch(sents, beam_width=beam, **kwargs)
+    assert len(out) == n
+    for s, nb in zip(sents, out):
+        assert 1 <= len(nb) <= min(10, beam)
+        sc = [x for x, _ in nb]
+        assert all(np.isfinite(sc)) and sc == sorted(sc)                   # ascending -log p
+        for _, words in nb:
+            assert _readings_ok(words, s), (s, words)                      # every path spells the input
+        assert len({tuple(w) for _, w in nb}) == len(nb)                   # hypotheses are distinct
+    again = dec.decode_batch(sents, beam_width=beam, **kwargs)             # idempotent / deterministic
+    assert [[w for _, w in nb] for nb in again] == [[w for _, w in nb] for nb in out]
+    # batch-composition independence: a sub-batch gives the same answers
+    sub = dec.decode_batch(sents[5:37], beam_width=beam, **kwargs)
+    for a, b in zip(sub, out[5:37]):
+        assert [w for _, w in a] == [w for _, w in b]
+        np.testing.assert_allclose([x for x, _ in a], [x for x, _ in b], rtol=0, atol=1e-9)
+    # oracle on a small sample of the same inputs
+    o = (orc.OracleDynamicDecoder if kind == "dynamic" else orc.OracleDecoder)(f["root"], 1)
+    for si in (0, n // 2, n - 1)[: (2 if fixture == "big-tied" else 3)]:
+        want = o.decode(sents[si], beam_width=beam, **kwargs)
+        _check_nbest(out[si], want, (fixture, si), strict_nbest=False)

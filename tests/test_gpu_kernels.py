@@ -1,0 +1,325 @@
+"""GPU: every entry point of libjlm_hip.so against the numpy restatement of its
+contract (tests/fake_hip.py), same inputs, called through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from jlm_amd import _lib            # noqa: E402
+from tests.fake_hip import FakeLib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    lib = _lib.lib()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.jlm_device_arch(0, buf, 128) == 0
+    assert buf.value.decode().startswith("gfx950"), buf.value
+    return lib
+
+
+FK = FakeLib()
+
+
+def _pair(a):
+    """(cpu tensor, gpu clone)"""
+    t = torch.as_tensor(a).contiguous()
+    return t, t.cuda()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad_rows(rng, n, k, ld, scale=1.0):
+    a = np.zeros((n, ld), dtype=np.float32)
+    a[:, :k] = rng.standard_normal((n, k)).astype(np.float32) * scale
+    return a
+
+
+@pytest.mark.parametrize("M,N,K,maps", [(77, 203, 100, False), (300, 64, 512, True), (1500, 6000, 256, True),
+                                        (2560, 256, 512, True), (1, 8, 4, False)])
+def test_gemm_nt(L, M, N, K, maps):
+    rng = np.random.default_rng(M + N + K)
+    lda, ldb, ldc = K + 4, K, N + 8
+    nA, nB, nC = M + 13, N + 5, M + 9
+    A, Ag = _pair(_pad_rows(rng, nA, K, lda))
+    B, Bg = _pair(_pad_rows(rng, nB, K, ldb))
+    bias, biasg = _pair(rng.standard_normal(N).astype(np.float32))
+    C, Cg = _pair(np.full((nC, ldc), 7.0, dtype=np.float32))
+    if maps:
+        am, amg = _pair(rng.permutation(nA)[:M].astype(np.int32))
+        bm, bmg = _pair(rng.permutation(nB)[:N].astype(np.int32))
+        cm, cmg = _pair(rng.permutation(nC)[:M].astype(np.int32))
+        md, mdg = _pair(np.array([M - 3], dtype=np.int32))
+        pc = (am.data_ptr(), bm.data_ptr(), cm.data_ptr(), md.data_ptr())
+        pg = (amg.data_ptr(), bmg.data_ptr(), cmg.data_ptr(), mdg.data_ptr())
+    else:
+        pc = pg = (None, None, None, None)
+    assert FK.jlm_gemm_nt(A.data_ptr(), lda, pc[0], B.data_ptr(), ldb, pc[1], C.data_ptr(), ldc, pc[2], bias.data_ptr(),
+                          M, N, K, pc[3], 0) == 0
+    assert L.jlm_gemm_nt(Ag.data_ptr(), lda, pg[0], Bg.data_ptr(), ldb, pg[1], Cg.data_ptr(), ldc, pg[2],
+                         biasg.data_ptr(), M, N, K, pg[3], _st()) == 0
+    torch.cuda.synchronize()
+    got, want = Cg.cpu().numpy(), C.numpy()
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert (got == 7.0).sum() == (want == 7.0).sum()        # untouched cells stay untouched
+
+
+@pytest.mark.parametrize("H,E,R,use_rows", [(64, 32, 10, False), (64, 32, 200, True), (512, 256, 700, True),
+                                            (512, 200, 2560, True), (128, 352, 33, True)])
+def test_lstm_step(L, H, E, R, use_rows):
+    rng = np.random.default_rng(H + E + R)
+    V, G = 500, R * 3 + 7
+    kpad = (H + E + 31) // 32 * 32
+    h, hg = _pair(rng.standard_normal((G, H)).astype(np.float32) * 0.5)
+    c, cg = _pair(rng.standard_normal((G, H)).astype(np.float32) * 0.5)
+    emb, embg = _pair(rng.standard_normal((V, E)).astype(np.float32) * 0.3)
+    wt_np = np.zeros((4 * H, kpad), dtype=np.float32)
+    wt_np[:, :H + E] = rng.standard_normal((4 * H, H + E)).astype(np.float32) * 0.08
+    wt, wtg = _pair(wt_np)
+    bias, biasg = _pair(rng.standard_normal(4 * H).astype(np.float32) * 0.1)
+    word, wordg = _pair(rng.integers(0, V, size=G).astype(np.int32))
+    if use_rows:
+        rows_np = (G - 1 - rng.permutation(R)).astype(np.int32)            # rows to write: top of the store
+        prev_np = rng.integers(-1, G - R, size=G).astype(np.int32)         # states read: below them (or zero state)
+        rows, rowsg = _pair(rows_np)
+        nd, ndg = _pair(np.array([R - 1], dtype=np.int32))
+        rp, rpg, ndp, ndpg = rows.data_ptr(), rowsg.data_ptr(), nd.data_ptr(), ndg.data_ptr()
+        ho, hog, co, cog = h, hg, c, cg                                    # in place, like the decoder
+    else:
+        prev_np = np.arange(G, dtype=np.int32)
+        rp = rpg = ndp = ndpg = None
+        ho, hog = _pair(np.zeros((G, H), dtype=np.float32))
+        co, cog = _pair(np.zeros((G, H), dtype=np.float32))
+    prev, prevg = _pair(prev_np)
+    assert FK.jlm_lstm_step(h.data_ptr(), c.data_ptr(), H, ho.data_ptr(), co.data_ptr(), rp, prev.data_ptr(),
+                            word.data_ptr(), emb.data_ptr(), E, wt.data_ptr(), bias.data_ptr(), kpad, H, E, R, ndp, 0) == 0
+    assert L.jlm_lstm_step(hg.data_ptr(), cg.data_ptr(), H, hog.data_ptr(), cog.data_ptr(), rpg, prevg.data_ptr(),
+                           wordg.data_ptr(), embg.data_ptr(), E, wtg.data_ptr(), biasg.data_ptr(), kpad, H, E, R,
+                           ndpg, _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(hog.cpu().numpy(), ho.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(cog.cpu().numpy(), co.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("V,K,R", [(1000, 32, 10), (50000, 256, 300), (12000, 200, 2560), (20000, 52, 777), (130, 100, 129)])
+def test_vocab_lse(L, V, K, R):
+    rng = np.random.default_rng(V + K + R)
+    ldt, G = K + 12, R + 40
+    Bm, Bg = _pair(rng.standard_normal((V, K)).astype(np.float32) * 0.3)
+    T, Tg = _pair(rng.standard_normal((G, ldt)).astype(np.float32))
+    bias, biasg = _pair(rng.standard_normal(V).astype(np.float32))
+    rows, rowsg = _pair(rng.permutation(G)[:R].astype(np.int32))
+    nd, ndg = _pair(np.array([R - 2], dtype=np.int32))
+    ntile = (V + 127) // 128
+    part, partg = _pair(np.zeros((ntile + 3, R, 2), dtype=np.float32))
+    lse, lseg = _pair(np.zeros(G, dtype=np.float64))
+    t_off = 8
+    r0 = FK.jlm_vocab_lse_partials(Bm.data_ptr(), K, V, K, T.data_ptr() + 4 * t_off, ldt, rows.data_ptr(), bias.data_ptr(),
+                                   part.data_ptr(), R, 3, R, nd.data_ptr(), 0)
+    r1 = L.jlm_vocab_lse_partials(Bg.data_ptr(), K, V, K, Tg.data_ptr() + 4 * t_off, ldt, rowsg.data_ptr(),
+                                  biasg.data_ptr(), partg.data_ptr(), R, 3, R, ndg.data_ptr(), _st())
+    assert r0 == r1 == ntile
+    # tile 0..2 left for "another segment": fill with neutral partials
+    for p in (part, partg):
+        p[:3, :, 0] = -3.0e38
+        p[:3, :, 1] = 0.0
+    assert FK.jlm_lse_combine(part.data_ptr(), R, ntile + 3, rows.data_ptr(), lse.data_ptr(), R, nd.data_ptr(), 0) == 0
+    assert L.jlm_lse_combine(partg.data_ptr(), R, ntile + 3, rowsg.data_ptr(), lseg.data_ptr(), R, ndg.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    n = R - 2
+    pg, pc = partg.cpu().numpy()[3:, :n], part.numpy()[3:, :n]
+    np.testing.assert_allclose(pg[..., 0], pc[..., 0], rtol=1e-5, atol=2e-5)
+    lse_tile_g = pg[..., 0] + np.log(pg[..., 1])
+    lse_tile_c = pc[..., 0] + np.log(pc[..., 1])
+    np.testing.assert_allclose(lse_tile_g, lse_tile_c, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(lseg.cpu().numpy(), lse.numpy(), rtol=1e-6, atol=2e-5)
+
+
+def _segments(rng, V, widths, ldt_extra=0):
+    """random multi-segment output side: returns (cpu Segment array, gpu Segment array, keepalive, ldt)"""
+    bounds = np.linspace(0, V, len(widths) + 1).astype(int)
+    segs_c = (_lib.Segment * len(widths))()
+    segs_g = (_lib.Segment * len(widths))()
+    keep, off = [], 0
+    for i, k in enumerate(widths):
+        kp = (k + 3) // 4 * 4
+        blk = np.zeros((bounds[i + 1] - bounds[i], kp), dtype=np.float32)
+        blk[:, :k] = rng.standard_normal((blk.shape[0], k)).astype(np.float32) * 0.3
+        bc, bg = _pair(blk)
+        keep += [bc, bg]
+        segs_c[i] = _lib.Segment(int(bounds[i]), int(bounds[i + 1]), kp, off, bc.data_ptr(), kp)
+        segs_g[i] = _lib.Segment(int(bounds[i]), int(bounds[i + 1]), kp, off, bg.data_ptr(), kp)
+        off += kp
+    return segs_c, segs_g, keep, off + ldt_extra
+
+
+def _wordlist_problem(rng, V, widths, beam, n_groups, max_words, dup=False):
+    segs_c, segs_g, keep, ldt = _segments(rng, V, widths)
+    G = n_groups * beam + 5
+    T = rng.standard_normal((G, ldt)).astype(np.float32)
+    b2 = rng.standard_normal(V).astype(np.float32)
+    cnt = rng.integers(0, beam + 1, size=n_groups).astype(np.int32)
+    cnt[0] = beam
+    g0 = (np.arange(n_groups) * beam).astype(np.int32)
+    lists = []
+    for j in range(n_groups + 3):
+        n = int(rng.integers(0, max_words + 1))
+        w = rng.integers(0, V, size=n)
+        if dup and n > 2:
+            w[1] = w[0]
+        lists.append(w.astype(np.int32))
+    off = np.zeros(len(lists) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    wl = np.concatenate(lists + [np.zeros(1, np.int32)])
+    cidx = rng.permutation(n_groups).astype(np.int32)
+    cnt_store = np.zeros(n_groups, dtype=np.int32)
+    cnt_store[cidx] = cnt
+    wl_idx = rng.integers(0, 3, size=n_groups).astype(np.int32) + np.arange(n_groups, dtype=np.int32) - 2
+    return dict(segs_c=segs_c, segs_g=segs_g, keep=keep, ldt=ldt, T=T, b2=b2, cnt=cnt_store, cidx=cidx, g0=g0, wl=wl,
+                off=off, wl_idx=wl_idx, G=G, n_words=int(off[-1]))
+
+
+@pytest.mark.parametrize("widths,beam,ng,mw", [([32], 10, 20, 40), ([200, 100, 50], 10, 64, 90), ([256], 20, 9, 700),
+                                               ([32, 16, 8], 3, 30, 5)])
+def test_edge_logits(L, widths, beam, ng, mw):
+    rng = np.random.default_rng(sum(widths) + beam + ng)
+    P = _wordlist_problem(rng, 3000, widths, beam, ng, mw)
+    nseg = len(widths)
+    out_ids = rng.permutation(P["n_words"] + 7).astype(np.int32)[:P["n_words"] + 1]
+    ten = {k: _pair(P[k]) for k in ("T", "b2", "cnt", "cidx", "g0", "wl", "off", "wl_idx")}
+    oi, oig = _pair(out_ids)
+    edge, edgeg = _pair(np.full((P["n_words"] + 8) * beam, 5.0, dtype=np.float32))
+    a = lambda k, i: ten[k][i].data_ptr()
+    assert FK.jlm_edge_logits(P["segs_c"], nseg, a("b2", 0), a("T", 0), P["ldt"], a("g0", 0), a("cnt", 0), a("cidx", 0),
+                              a("wl", 0), a("off", 0), a("wl_idx", 0), 2, oi.data_ptr(), edge.data_ptr(), beam, ng, 0) == 0
+    assert L.jlm_edge_logits(P["segs_g"], nseg, a("b2", 1), a("T", 1), P["ldt"], a("g0", 1), a("cnt", 1), a("cidx", 1),
+                             a("wl", 1), a("off", 1), a("wl_idx", 1), 2, oig.data_ptr(), edgeg.data_ptr(), beam, ng,
+                             _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(edgeg.cpu().numpy(), edge.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("widths,beam,ng,mw,merge", [([32], 10, 20, 40, 0), ([200, 100, 50], 10, 64, 90, 1),
+                                                     ([256], 20, 9, 700, 0), ([256], 20, 9, 700, 1),
+                                                     ([32, 16, 8], 3, 30, 5, 1)])
+def test_wordlist_lse(L, widths, beam, ng, mw, merge):
+    rng = np.random.default_rng(sum(widths) + beam + ng + merge)
+    P = _wordlist_problem(rng, 3000, widths, beam, ng, mw, dup=True)
+    nseg = len(widths)
+    ten = {k: _pair(P[k]) for k in ("T", "b2", "cnt", "cidx", "g0", "wl", "off", "wl_idx")}
+    rm, rmg = _pair(rng.standard_normal(P["G"]).astype(np.float32))
+    rs, rsg = _pair(rng.uniform(1.0, 50.0, size=P["G"]))
+    ls, lsg = _pair(np.full(P["G"], 123.0))
+    a = lambda k, i: ten[k][i].data_ptr()
+    assert FK.jlm_wordlist_lse(P["segs_c"], nseg, a("b2", 0), a("T", 0), P["ldt"], a("g0", 0), a("cnt", 0), a("cidx", 0),
+                               a("wl", 0), a("off", 0), a("wl_idx", 0), 2, rm.data_ptr(), rs.data_ptr(), ls.data_ptr(),
+                               merge, beam, ng, 0) == 0
+    assert L.jlm_wordlist_lse(P["segs_g"], nseg, a("b2", 1), a("T", 1), P["ldt"], a("g0", 1), a("cnt", 1), a("cidx", 1),
+                              a("wl", 1), a("off", 1), a("wl_idx", 1), 2, rmg.data_ptr(), rsg.data_ptr(), lsg.data_ptr(),
+                              merge, beam, ng, _st()) == 0
+    torch.cuda.synchronize()
+    got, want = lsg.cpu().numpy(), ls.numpy()
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all()
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-6, atol=3e-5)
+    lg = rmg.cpu().numpy().astype(np.float64) + np.log(rsg.cpu().numpy())
+    lc = rm.numpy().astype(np.float64) + np.log(rs.numpy())
+    np.testing.assert_allclose(lg[fin], lc[fin], rtol=1e-6, atol=3e-5)
+
+
+def _beam_problem(rng, B, beam, F, max_nodes):
+    """random lattice + beam state, consistent up to frame F-1"""
+    rmax, G = B * beam, F * B * beam
+    slen = rng.integers(1, F, size=B).astype(np.int32)
+    slen[0] = F - 1
+    counts = np.zeros(F * B, dtype=np.int64)
+    starts, words = [], []
+    for f in range(F):
+        for s in range(B):
+            if f == 0:
+                n = 1
+            elif f <= slen[s]:
+                n = int(rng.integers(1, max_nodes + 1))
+            else:
+                n = 0
+            counts[f * B + s] = n
+            for _ in range(n):
+                starts.append(-1 if f == 0 else int(rng.integers(max(0, f - 4), f)))
+                words.append(int(rng.integers(0, 1000)))
+    end_off = np.zeros(F * B + 1, dtype=np.int32)
+    end_off[1:] = np.cumsum(counts)
+    N = int(end_off[-1])
+    return dict(B=B, beam=beam, F=F, rmax=rmax, G=G, N=N, slen=slen, end_off=end_off,
+                nstart=np.array(starts, dtype=np.int32), nword=np.array(words, dtype=np.int32),
+                max_cands=int(counts.max()) * beam)
+
+
+def _run_beam(lib, P, mode, cuda, rng_seed):
+    rng = np.random.default_rng(rng_seed)
+    dev = "cuda" if cuda else "cpu"
+    t = lambda a: torch.as_tensor(a).contiguous().to(dev)
+    G, F, B, beam = P["G"], P["F"], P["B"], P["beam"]
+    ints = {k: t(P[k]) for k in ("slen", "end_off", "nstart", "nword")}
+    score, lse, ysum = t(np.zeros(G)), t(rng.uniform(5.0, 9.0, size=G)), t(np.zeros(G))
+    # make some exact ties: quantise the edge logits coarsely
+    edge = t((np.round(rng.standard_normal(max(P["N"], 1) * beam) * 2.0) / 2.0).astype(np.float32))
+    bp, node, word = (t(np.full(G, -7, dtype=np.int32)) for _ in range(3))
+    cnt, live, n_live = t(np.zeros(F * B, dtype=np.int32)), t(np.full(G, -1, dtype=np.int32)), t(np.zeros(F, dtype=np.int32))
+    lat = _lib.Lattice(B, beam, F, ints["slen"].data_ptr(), ints["end_off"].data_ptr(), ints["nstart"].data_ptr(),
+                       ints["nword"].data_ptr())
+    st = _lib.BeamState(score.data_ptr(), lse.data_ptr(), ysum.data_ptr(), bp.data_ptr(), node.data_ptr(), word.data_ptr(),
+                        cnt.data_ptr(), live.data_ptr(), n_live.data_ptr(), edge.data_ptr())
+    stream = _st() if cuda else 0
+    for f in range(F):
+        assert lib.jlm_beam_step(lat, st, f, mode, P["max_cands"], stream) == 0
+    stride = F + 1
+    on, ol, osc = t(np.full((P["rmax"], stride), -1, dtype=np.int32)), t(np.zeros(P["rmax"], dtype=np.int32)), t(np.zeros(P["rmax"]))
+    assert lib.jlm_backtrace(lat, st, on.data_ptr(), ol.data_ptr(), osc.data_ptr(), stride, stream) == 0
+    if cuda:
+        torch.cuda.synchronize()
+    out = dict(score=score, ysum=ysum, bp=bp, node=node, word=word, cnt=cnt, live=live, n_live=n_live, on=on, ol=ol, osc=osc)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,beam,F,max_nodes", [(7, 10, 9, 12), (64, 3, 6, 40), (3, 20, 22, 70)])
+def test_beam_step_and_backtrace(L, mode, B, beam, F, max_nodes):
+    P = _beam_problem(np.random.default_rng(B * 100 + beam + F), B, beam, F, max_nodes)
+    want = _run_beam(FK, P, mode, False, 5)
+    got = _run_beam(L, P, mode, True, 5)
+    np.testing.assert_array_equal(got["cnt"], want["cnt"])
+    np.testing.assert_array_equal(got["n_live"], want["n_live"])
+    rmax = P["rmax"]
+    for f in range(F):
+        for s in range(B):
+            k = int(want["cnt"][f * B + s])
+            sl = slice(f * rmax + s * beam, f * rmax + s * beam + k)
+            for name in ("bp", "node", "word"):
+                np.testing.assert_array_equal(got[name][sl], want[name][sl], err_msg="%s f=%d s=%d" % (name, f, s))
+            np.testing.assert_allclose(got["score"][sl], want["score"][sl], rtol=0, atol=1e-12)
+            if mode == 2:
+                np.testing.assert_allclose(got["ysum"][sl], want["ysum"][sl], rtol=0, atol=1e-12)
+        nl = int(want["n_live"][f])
+        assert sorted(got["live"][f * rmax:f * rmax + nl]) == sorted(want["live"][f * rmax:f * rmax + nl])
+    np.testing.assert_array_equal(got["ol"], want["ol"])
+    np.testing.assert_allclose(got["osc"], want["osc"], rtol=0, atol=1e-12)
+    for i in range(rmax):
+        np.testing.assert_array_equal(got["on"][i, :want["ol"][i]], want["on"][i, :want["ol"][i]])
+
+
+@pytest.mark.parametrize("R,C,sn", [(3, 2000, 0), (10, 50000, 0), (4, 301, 1)])
+def test_softmax_rows(L, R, C, sn):
+    rng = np.random.default_rng(R + C)
+    ld = (C + 3) // 4 * 4
+    y, yg = _pair(rng.standard_normal((R, ld)).astype(np.float32) * 3)
+    p, pg = _pair(np.zeros((R, ld), dtype=np.float32))
+    assert FK.jlm_softmax_rows(y.data_ptr(), p.data_ptr(), ld, R, C, sn, 0) == 0
+    assert L.jlm_softmax_rows(yg.data_ptr(), pg.data_ptr(), ld, R, C, sn, _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pg.cpu().numpy()[:, :C], p.numpy()[:, :C], rtol=3e-5, atol=1e-9)
