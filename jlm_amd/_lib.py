@@ -65,6 +65,10 @@ def lib():
             raise JlmHipError(
                 "libjlm_hip.so is not built (%s).  Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        # torch first: its bundled HIP runtime must be the one in the process before this
+        # library (linked against libamdhip64) is mapped, or the two runtimes disagree
+        # about the device (hipErrorNoDevice on the first launch).
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)

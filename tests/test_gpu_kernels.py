@@ -159,7 +159,7 @@ def _segments(rng, V, widths, ldt_extra=0):
     return segs_c, segs_g, keep, off + ldt_extra
 
 
-def _wordlist_problem(rng, V, widths, beam, n_groups, max_words, dup=False):
+def _wordlist_problem(rng, V, widths, beam, n_groups, max_words, dup=False, share_lists=True):
     segs_c, segs_g, keep, ldt = _segments(rng, V, widths)
     G = n_groups * beam + 5
     T = rng.standard_normal((G, ldt)).astype(np.float32)
@@ -180,7 +180,10 @@ def _wordlist_problem(rng, V, widths, beam, n_groups, max_words, dup=False):
     cidx = rng.permutation(n_groups).astype(np.int32)
     cnt_store = np.zeros(n_groups, dtype=np.int32)
     cnt_store[cidx] = cnt
-    wl_idx = rng.integers(0, 3, size=n_groups).astype(np.int32) + np.arange(n_groups, dtype=np.int32) - 2
+    if share_lists:     # several groups may read the same list (as the incremental decoder's deltas do)
+        wl_idx = rng.integers(0, 3, size=n_groups).astype(np.int32) + np.arange(n_groups, dtype=np.int32) - 2
+    else:               # edge logits: one list per group (every edge is written once)
+        wl_idx = rng.permutation(n_groups + 1)[:n_groups].astype(np.int32) - 2
     return dict(segs_c=segs_c, segs_g=segs_g, keep=keep, ldt=ldt, T=T, b2=b2, cnt=cnt_store, cidx=cidx, g0=g0, wl=wl,
                 off=off, wl_idx=wl_idx, G=G, n_words=int(off[-1]))
 
@@ -189,7 +192,7 @@ def _wordlist_problem(rng, V, widths, beam, n_groups, max_words, dup=False):
                                                ([32, 16, 8], 3, 30, 5)])
 def test_edge_logits(L, widths, beam, ng, mw):
     rng = np.random.default_rng(sum(widths) + beam + ng)
-    P = _wordlist_problem(rng, 3000, widths, beam, ng, mw)
+    P = _wordlist_problem(rng, 3000, widths, beam, ng, mw, share_lists=False)
     nseg = len(widths)
     out_ids = rng.permutation(P["n_words"] + 7).astype(np.int32)[:P["n_words"] + 1]
     ten = {k: _pair(P[k]) for k in ("T", "b2", "cnt", "cidx", "g0", "wl", "off", "wl_idx")}
