@@ -204,6 +204,8 @@ def main():
                    "parallelism": "sentence-sharded x%d, no collective" % world},
         "end_to_end_chars_per_s": round(e2e, 1),
         "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,
+        "vocab_lse_segments": [{"k": sg["k"], "n_vocab": sg["v_end"] - sg["v_start"], "avg_launch_ms": round(s_["avg_ms"], 4),
+                                "tflops": round(s_["tflops"], 2)} for sg, s_ in zip(m.segments, seg_stats)],
     }
     print(json.dumps(line))
     if dist is not None:

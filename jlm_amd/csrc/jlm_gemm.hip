@@ -372,28 +372,47 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
     return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
 }
 
-// lse[g] = log sum exp over the tile partials of one row (float64 accumulation)
-__global__ void lse_combine_kernel(const float2 *part, int ld_part, int n_tiles, const int *rows, double *lse,
-                                   int n_rows_max, const int *n_dev) {
-    int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+// lse[g] = log sum exp over the tile partials of one row.  One lane per row (coalesced
+// float2 reads along the row index), the tiles of a row are split over the 16 waves of
+// the workgroup and merged online, then the 16 partial (max, sum) pairs meet in LDS.
+#define LSEC_WAVES 16
+__global__ __launch_bounds__(LSEC_WAVES * 64) void lse_combine_kernel(const float2 *part, int ld_part, int n_tiles,
+                                                                      const int *rows, double *lse, int n_rows_max,
+                                                                      const int *n_dev) {
+    __shared__ float sm_m[LSEC_WAVES][64];
+    __shared__ double sm_s[LSEC_WAVES][64];
+    const int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n) return;
     float m = JLM_NEG_BIG;
-    for (int t = 0; t < n_tiles; ++t) m = fmaxf(m, part[(size_t)t * ld_part + r].x);
     double s = 0.0;
-    for (int t = 0; t < n_tiles; ++t) {
-        float2 p = part[(size_t)t * ld_part + r];
-        s += (double)p.y * exp((double)p.x - (double)m);
+    if (r < n) {
+        for (int t = wave; t < n_tiles; t += LSEC_WAVES) {
+            const float2 p = part[(size_t)t * ld_part + r];
+            const float mm = fmaxf(m, p.x);
+            s = s * (double)expf(m - mm) + (double)p.y * (double)expf(p.x - mm);
+            m = mm;
+        }
     }
-    int g = rows ? rows[r] : r;
-    lse[g] = (double)m + log(s);
+    sm_m[wave][lane] = m;
+    sm_s[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && r < n) {
+        float M = sm_m[0][lane];
+        for (int w = 1; w < LSEC_WAVES; ++w) M = fmaxf(M, sm_m[w][lane]);
+        double S = 0.0;
+        for (int w = 0; w < LSEC_WAVES; ++w) S += sm_s[w][lane] * exp((double)sm_m[w][lane] - (double)M);
+        const int g = rows ? rows[r] : r;
+        lse[g] = (double)M + log(S);
+    }
 }
 
 extern "C" int jlm_lse_combine(const float *part, int ld_part, int n_tiles, const int *rows, double *lse,
                                int n_rows_max, const int *n_dev, void *stream) {
     if (n_rows_max <= 0) return 0;
-    int bs = 256, grid = (n_rows_max + bs - 1) / bs;
-    hipLaunchKernelGGL(lse_combine_kernel, dim3(grid), dim3(bs), 0, (hipStream_t)stream,
+    const int grid = (n_rows_max + 63) / 64;
+    hipLaunchKernelGGL(lse_combine_kernel, dim3(grid), dim3(LSEC_WAVES * 64), 0, (hipStream_t)stream,
                        reinterpret_cast<const float2 *>(part), ld_part, n_tiles, rows, lse, n_rows_max, n_dev);
     JLM_LAUNCH_CHECK();
     return 0;

@@ -311,3 +311,15 @@ def install(monkeypatch):
     monkeypatch.setattr(_lib, "require_gpu", lambda: torch.device("cpu"))
     monkeypatch.setattr(model.DeviceModel, "stream", lambda self: 0)
     return fake
+
+
+def install_plain():
+    """Same as install() for processes without a pytest monkeypatch (spawned ranks)."""
+    import torch
+    from jlm_amd import _lib, model
+
+    fake = FakeLib()
+    _lib.lib = lambda: fake
+    _lib.require_gpu = lambda: torch.device("cpu")
+    model.DeviceModel.stream = lambda self: 0
+    return fake

@@ -1,0 +1,102 @@
+"""Per-kernel micro-benchmark on the MI355X box (HIP events around single launches,
+random data, shapes of BASELINE configs[1]/[2]).  Usage: python tools/kbench.py [filter]"""
+import os
+import sys
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from jlm_amd import _lib  # noqa: E402
+
+L = _lib.lib()
+dev = torch.device("cuda")
+st = torch.cuda.current_stream().cuda_stream
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+PEAK = 157.3
+
+
+def timeit(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in evs])
+    return float(np.median(t)), float(t.min())
+
+
+def report(name, flops, ms):
+    med, mn = ms
+    print("%-44s median %8.1f us  min %8.1f us  %6.1f TF/s (%4.1f%% of f32 MFMA peak)" % (
+        name, med * 1e3, mn * 1e3, flops / (med * 1e-3) / 1e12, 100 * flops / (med * 1e-3) / 1e12 / PEAK))
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).contiguous()
+
+
+def bench_lse(V, K, R, tag):
+    if flt and flt not in "lse":
+        return
+    Kp = (K + 3) // 4 * 4
+    B, T, bias = rnd(V, Kp, scale=0.05), rnd(R, Kp), rnd(V, scale=0.05)
+    ntile = (V + 127) // 128
+    part = torch.empty((ntile, R, 2), device=dev)
+    lse = torch.empty(R, device=dev, dtype=torch.float64)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    rows = torch.arange(R, device=dev, dtype=torch.int32)
+    f = lambda: L.jlm_vocab_lse_partials(B.data_ptr(), Kp, V, Kp, T.data_ptr(), Kp, rows.data_ptr(), bias.data_ptr(),
+                                         part.data_ptr(), R, 0, R, nd.data_ptr(), st)
+    report("vocab_lse %s V=%d K=%d R=%d" % (tag, V, K, R), 2.0 * V * K * R, timeit(f))
+    g = lambda: L.jlm_lse_combine(part.data_ptr(), R, ntile, rows.data_ptr(), lse.data_ptr(), R, nd.data_ptr(), st)
+    report("lse_combine tiles=%d R=%d" % (ntile, R), 1.0, timeit(g))
+
+
+def bench_gate(H, E, R):
+    if flt and flt not in "gate":
+        return
+    V = 50000
+    kpad = (H + E + 31) // 32 * 32
+    G = 3 * R
+    h, c = rnd(G, H, scale=0.3), rnd(G, H, scale=0.3)
+    emb = rnd(V, E, scale=0.05)
+    wt = rnd(4 * H, kpad, scale=0.05)
+    bias = rnd(4 * H, scale=0.05)
+    rows = (torch.arange(R, device=dev, dtype=torch.int32) + 2 * R).contiguous()
+    prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
+    word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    f = lambda: L.jlm_lstm_step(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
+                                word.data_ptr(), emb.data_ptr(), E, wt.data_ptr(), bias.data_ptr(), kpad, H, E, R,
+                                nd.data_ptr(), st)
+    report("lstm_step H=%d E=%d R=%d" % (H, E, R), 2.0 * (H + E) * 4 * H * R, timeit(f))
+
+
+def bench_gemm(M, N, K, tag):
+    if flt and flt not in "gemm":
+        return
+    A, B, C = rnd(M, K), rnd(N, K), torch.empty((M, N), device=dev)
+    f = lambda: L.jlm_gemm_nt(A.data_ptr(), K, None, B.data_ptr(), K, None, C.data_ptr(), N, None, None, M, N, K, None, st)
+    report("gemm_nt %s M=%d N=%d K=%d" % (tag, M, N, K), 2.0 * M * N * K, timeit(f))
+
+
+if __name__ == "__main__":
+    print(torch.cuda.get_device_name(0))
+    for R in (2560,):
+        bench_gate(512, 200, R)
+        bench_gate(512, 256, R)
+        bench_lse(12000, 200, R, "seg0")
+        bench_lse(18000, 100, R, "seg1")
+        bench_lse(20000, 50, R, "seg2")
+        bench_lse(50000, 256, R, "tied50k")
+        bench_gemm(R, 200, 512, "PM")
+        bench_gemm(R, 100, 200, "VT1")
+        bench_gemm(R, 52, 200, "VT2")
+    bench_gate(512, 256, 20480)
+    bench_lse(100000, 256, 20480, "tied100k-b20")
+    bench_gemm(4096, 4096, 4096, "square")
