@@ -148,26 +148,27 @@ def main():
         return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12,
                     flops_per_launch=flops / n)
 
-    seg_stats = []
-    for i, sg in enumerate(m.segments):
-        st = kernel_stats("vocab_lse_seg%d" % i, 2.0 * sg["k"] * (sg["v_end"] - sg["v_start"]))
-        if st:
-            seg_stats.append(st)
     gate = kernel_stats("gate_gemm", 2.0 * (H + m.E_in) * 4 * H)
+    vstat = kernel_stats("vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
+    if vstat and not m.stationary_ok:
+        # tile form: one launch per segment, rows repeat per segment
+        d = np.asarray(durs["vocab_lse"], dtype=np.float64)
+        per_frame = d[: (d.size // m.n_segs) * m.n_segs].reshape(-1, m.n_segs).sum(axis=1)
+        n = min(per_frame.size, rows.size)
+        fl = float((rows[:n] * m.flops_per_row_vocab).sum())
+        vstat = dict(launches=int(n * m.n_segs), avg_ms=float(d.mean()), tflops=fl / (per_frame[:n].sum() * 1e-3) / 1e12,
+                     flops_per_launch=fl / (n * m.n_segs))
     roofline = None
-    if seg_stats:
-        flops = sum(s["flops_per_launch"] * s["launches"] for s in seg_stats)
-        secs = sum(s["avg_ms"] * s["launches"] for s in seg_stats) * 1e-3
-        n_launch = sum(s["launches"] for s in seg_stats)
-        ach = flops / secs / 1e12
-        roofline = {"kernel": "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(secs * 1e3 / n_launch, 4), "launches": n_launch,
-                    "flops_per_launch": flops / n_launch, "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    if vstat:
+        kname = ("vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
+                 else "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(vstat["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(vstat["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(vstat["avg_ms"], 4), "launches": vstat["launches"],
+                    "flops_per_launch": vstat["flops_per_launch"], "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
     gate_obj = None
     if gate:
-        gate_obj = {"kernel": "gemm_nt_kernel<128x128,EpiGate> (jlm_lstm_step)", "achieved": round(gate["tflops"], 2),
+        gate_obj = {"kernel": "gemm_nt_kernel<64x64,EpiGate> (jlm_lstm_step)", "achieved": round(gate["tflops"], 2),
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "mfma_util_pct": round(100.0 * gate["tflops"] / F32_MFMA_PEAK_TFLOPS, 2),
                     "avg_launch_ms": round(gate["avg_ms"], 4), "launches": gate["launches"]}
@@ -204,8 +205,7 @@ def main():
                    "parallelism": "sentence-sharded x%d, no collective" % world},
         "end_to_end_chars_per_s": round(e2e, 1),
         "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,
-        "vocab_lse_segments": [{"k": sg["k"], "n_vocab": sg["v_end"] - sg["v_start"], "avg_launch_ms": round(s_["avg_ms"], 4),
-                                "tflops": round(s_["tflops"], 2)} for sg, s_ in zip(m.segments, seg_stats)],
+
     }
     print(json.dumps(line))
     if dist is not None:

@@ -50,7 +50,7 @@ int jlm_device_arch(int dev, char *buf, int buflen);
  *   z = x . Wt^T + bias     Wt is the packed [4H, kpad] gate matrix
  *   c[g] = c[p]*sig(z_f) + tanh(z_g)*sig(z_i) ;  h[g] = tanh(c[g])*sig(z_o)
  * Packed gate layout (jlm_amd/model.py packs it): row n of Wt / bias is
- *   n = (u / 32) * 128 + gate * 32 + (u % 32), gate order i,f,o,g
+ *   n = (u / 16) * 64 + gate * 16 + (u % 16), gate order i,f,o,g
  * with Wt[n, 0:H] = HM_gate[:, u], Wt[n, H:H+E] = IM_gate[:, u], zero padded to
  * kpad (multiple of 32).  Requires H % 32 == 0, E % 4 == 0.
  */
@@ -104,6 +104,18 @@ typedef struct {
     int ldb;
 } jlm_segment;
 #define JLM_MAX_SEGMENTS 8
+
+/* Same reduction, rows-stationary form (the one the decoders use): all segments
+ * of the model in ONE launch; a workgroup keeps 128 hypothesis rows' MFMA
+ * fragments in registers and streams a range of vocabulary tiles past them, so
+ * each row gets one (max, sum exp) partial per vocabulary RANGE:
+ *   part[p * ld_part + r],  p < return value  (<= max_parts, <= 96)
+ * Needs every segment's k <= 256; returns -2 otherwise (use the tile form).
+ * Returns the number of partial slices (fold them with jlm_lse_combine) or <0. */
+int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs, const float *b2,
+                             const float *T, int ldt, const int *rows,
+                             float *part, int ld_part, int max_parts,
+                             int n_rows_max, const int *n_dev, void *stream);
 
 /* Word-list groups: one per (sentence, frame).  Group j covers hypothesis rows
  * g0[j] .. g0[j]+cnt[cnt_idx[j]]-1 and the word list number l = wl_base +

@@ -41,6 +41,7 @@ _SIGS = {
     "jlm_gemm_nt": ([P, c_int, P, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_vocab_lse_partials": ([P, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_lse_combine": ([P, c_int, c_int, P, P, c_int, P, P], c_int),
+    "jlm_vocab_lse_stationary": ([POINTER(Segment), c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_edge_logits": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
     "jlm_wordlist_lse": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
                          c_int),

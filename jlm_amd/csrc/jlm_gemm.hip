@@ -30,6 +30,7 @@
 // A and B use the same assignment, hence the sum over k is complete.
 // Accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "jlm_common.h"
+#include <stdlib.h>
 
 #define BK 32
 #define LDS_LD 36
@@ -47,23 +48,27 @@ struct TileCfg {
 };
 
 // ---------------------------------------------------------------- row sources
+// Row sources hand out an always-dereferenceable pointer plus a validity flag: the
+// tile loads are then unconditional (a select zeroes invalid data afterwards) and the
+// compiler does not wrap every load in its own branch.
 struct PlainRows {
     const float *base;
     const int *map;      // row -> storage row (NULL = identity, <0 = zero row)
     int ld;
     int nrows;           // static upper bound
     const int *ndev;     // optional device-side count
-    struct St { const float *p; };
+    struct St { const float *p; bool ok; };
     __device__ int count() const { return ndev ? min(*ndev, nrows) : nrows; }
     __device__ St init(int row, int n) const {
-        St s; s.p = nullptr;
+        St s; s.p = base; s.ok = false;
         if (row < n) {
             int r = map ? map[row] : row;
-            if (r >= 0) s.p = base + (size_t)r * ld;
+            if (r >= 0) { s.p = base + (size_t)r * ld; s.ok = true; }
         }
         return s;
     }
     __device__ const float *ptr(const St &s, int) const { return s.p; }
+    __device__ bool valid(const St &s, int) const { return s.ok; }
 };
 
 // A operand of the gate GEMM: row r -> g = rows[r]; [ h[prev[g]] (k < H) | emb[word[g]] (k >= H) ]
@@ -73,19 +78,22 @@ struct GateRows {
     const float *emb; int lde;
     int H;
     int nrows; const int *ndev;
-    struct St { const float *ph; const float *pe; };
+    struct St { const float *ph; const float *pe; bool okh, oke; };
     __device__ int count() const { return ndev ? min(*ndev, nrows) : nrows; }
     __device__ St init(int row, int n) const {
-        St s; s.ph = nullptr; s.pe = nullptr;
+        St s; s.ph = h; s.pe = emb; s.okh = false; s.oke = false;
         if (row < n) {
             int g = rows ? rows[row] : row;
             int p = prev[g];
-            if (p >= 0) s.ph = h + (size_t)p * ldh;
-            s.pe = emb + (size_t)word[g] * lde - H;    // so that pe + k addresses emb[k - H]
+            if (p >= 0) { s.ph = h + (size_t)p * ldh; s.okh = true; }
+            s.pe = emb + (size_t)word[g] * lde;
+            s.oke = true;
         }
         return s;
     }
-    __device__ const float *ptr(const St &s, int k0) const { return k0 < H ? s.ph : s.pe; }
+    // k-steps never straddle H (H % 32 == 0): a step reads either the state or the embedding
+    __device__ const float *ptr(const St &s, int k0) const { return k0 < H ? s.ph : s.pe - H; }
+    __device__ bool valid(const St &s, int k0) const { return k0 < H ? s.okh : s.oke; }
 };
 
 // ------------------------------------------------------------------ tile map
@@ -96,12 +104,18 @@ struct GateRows {
 struct TileMap {
     int tiles_m, tiles_n, xcd;
     __device__ bool get(int b, int &tm, int &tn) const {
-        if (!xcd) { tm = b / tiles_n; tn = b % tiles_n; return tm < tiles_m; }
+        if (xcd == 0) { tm = b / tiles_n; tn = b % tiles_n; return tm < tiles_m; }
         int x = b & 7, j = b >> 3;
-        tm = (j / tiles_n) * 8 + x; tn = j % tiles_n;
+        if (xcd == 1) {                       // each XCD owns every 8th M tile, walks all N tiles of it
+            tm = (j / tiles_n) * 8 + x; tn = j % tiles_n;
+        } else {                              // xcd == 2: each XCD owns tiles_n/8 N tiles (weights stay in
+            int cpx = tiles_n >> 3;           // its L2), walks the M tiles; the M-side tile is re-read by
+            tn = x * cpx + j % cpx;           // the cpx consecutive workgroups of the same XCD
+            tm = j / cpx;
+        }
         return tm < tiles_m;
     }
-    int grid() const { return xcd ? ((tiles_m + 7) / 8) * 8 * tiles_n : tiles_m * tiles_n; }
+    int grid() const { return xcd == 1 ? ((tiles_m + 7) / 8) * 8 * tiles_n : tiles_m * tiles_n; }
 };
 
 // ------------------------------------------------------------------ epilogues
@@ -127,37 +141,56 @@ struct EpiStore {
     }
 };
 
-// Gate epilogue.  Needs NT == 4 and WAVES_N == 1: the four 32-column MFMA tiles
-// of a wave are the i, f, o, g pre-activations of the same 32 hidden units
-// (packed weight layout, include/jlm_hip.h), so the LSTM cell update is done in
-// registers by the lane that owns (row, unit).
+// Gate epilogue for 64 x 64 tiles.  The 64 columns of a tile are the i, f, o, g
+// pre-activations of the same 16 hidden units (packed weight layout,
+// include/jlm_hip.h).  The accumulators go through LDS once so that one thread
+// owns (row, 4 consecutive units) with all four gates: the LSTM cell update is
+// then 4-wide, and c_prev / c' / h' move as 16-byte accesses.  Small tiles on
+// purpose: at R = 2560 rows the gate GEMM is 40 x 32 = 1280 workgroups = exactly
+// 5 per CU; 128 x 128 tiles (320 workgroups on 256 CUs) cap MFMA use at 62.5 %.
+#define GATE_CT_LD 68
 struct EpiGate {
     const float *c_in; float *h_out; float *c_out; int ld;
     const int *rows; const int *prev; const float *bias;
     template <class Cfg>
-    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int, int lane,
-                        int M, int, float *) const {
-        static_assert(Cfg::NT == 4 && Cfg::WAVES_N == 1, "gate epilogue wants 4 gate tiles per wave");
-        const int u = (n0 >> 2) + (lane & 31);          // hidden unit
-        const float bi = bias[n0 + (lane & 31)], bf = bias[n0 + 32 + (lane & 31)];
-        const float bo = bias[n0 + 64 + (lane & 31)], bg = bias[n0 + 96 + (lane & 31)];
+    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
+                        int M, int, float *smem) const {
+        static_assert(Cfg::BM == 64 && Cfg::BN == 64 && Cfg::MT == 1 && Cfg::NT == 1 && Cfg::NTHREADS == 256,
+                      "gate epilogue is written for the 64 x 64 tile");
+        float *ct = smem;                      // [64][GATE_CT_LD]
 #pragma unroll
-        for (int mt = 0; mt < Cfg::MT; ++mt)
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[0][0][reg];
+        }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        const int r = tid >> 2, uq = (tid & 3) * 4;
+        const int row = m0 + r;
+        if (row >= M) return;
+        const int g = rows ? rows[row] : row;
+        const int p = prev[g];
+        const int u0 = (n0 >> 2) + uq;
+        const f32x4 zi = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + uq) +
+                         *reinterpret_cast<const f32x4 *>(bias + n0 + uq);
+        const f32x4 zf = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 16 + uq) +
+                         *reinterpret_cast<const f32x4 *>(bias + n0 + 16 + uq);
+        const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 32 + uq) +
+                         *reinterpret_cast<const f32x4 *>(bias + n0 + 32 + uq);
+        const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 48 + uq) +
+                         *reinterpret_cast<const f32x4 *>(bias + n0 + 48 + uq);
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+        if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
+        f32x4 cn, hn;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (row >= M) continue;
-                int g = rows ? rows[row] : row;
-                int p = prev[g];
-                float cp = p >= 0 ? c_in[(size_t)p * ld + u] : 0.0f;
-                float gi = jlm_sigmoid(acc[mt][0][reg] + bi);
-                float gf = jlm_sigmoid(acc[mt][1][reg] + bf);
-                float go = jlm_sigmoid(acc[mt][2][reg] + bo);
-                float gg = tanhf(acc[mt][3][reg] + bg);
-                float cn = cp * gf + gg * gi;
-                c_out[(size_t)g * ld + u] = cn;
-                h_out[(size_t)g * ld + u] = tanhf(cn) * go;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float gi = jlm_sigmoid(zi[e]), gf = jlm_sigmoid(zf[e]), go = jlm_sigmoid(zo[e]);
+            const float gg = tanhf(zg[e]);
+            cn[e] = cp[e] * gf + gg * gi;
+            hn[e] = tanhf(cn[e]) * go;
+        }
+        *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
+        *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
     }
 };
 
@@ -212,7 +245,7 @@ struct EpiLse {
 };
 
 // ------------------------------------------------------------------- mainloop
-template <class Cfg, class ARows, class BRows, class Epi>
+template <class Cfg, class ARows, class BRows, class Epi, int ABL = 0>
 __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(ARows A, BRows B, int K, Epi epi, TileMap tmap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = Cfg::BM, BN = Cfg::BN, MT = Cfg::MT, NT = Cfg::NT;
@@ -237,27 +270,35 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(ARows A, BRows B
     for (int j = 0; j < Cfg::B_CHUNKS; ++j) sb[j] = B.init(n0 + (tid >> 3) + j * (Cfg::NTHREADS / 8), N);
 
     f32x4 ra[Cfg::A_CHUNKS], rb[Cfg::B_CHUNKS];
+    unsigned ok_bits = 0;       // validity of the chunks in flight; the zero-select happens at the
+                                // ds_write, so nothing forces a wait on the loads before the MFMAs
     auto load_tile = [&](int k0) {
         const int k = k0 + kc * 4;
+        const bool okk = k < K;
+        const int kk = okk ? k : k0;            // k0 < K always: stays inside the row
+        ok_bits = 0;
 #pragma unroll
         for (int j = 0; j < Cfg::A_CHUNKS; ++j) {
-            const float *p = A.ptr(sa[j], k0);
-            ra[j] = (p && k < K) ? *reinterpret_cast<const f32x4 *>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[j] = *reinterpret_cast<const f32x4 *>(A.ptr(sa[j], k0) + kk);
+            ok_bits |= (okk && A.valid(sa[j], k0)) ? (1u << j) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < Cfg::B_CHUNKS; ++j) {
-            const float *p = B.ptr(sb[j], k0);
-            rb[j] = (p && k < K) ? *reinterpret_cast<const f32x4 *>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = *reinterpret_cast<const f32x4 *>(B.ptr(sb[j], k0) + kk);
+            ok_bits |= (okk && B.valid(sb[j], k0)) ? (1u << (16 + j)) : 0u;
         }
     };
     auto store_tile = [&](int buf) {
         float *as = As + buf * BM * LDS_LD, *bs = Bs + buf * BN * LDS_LD;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < Cfg::A_CHUNKS; ++j)
-            *reinterpret_cast<f32x4 *>(as + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) = ra[j];
+            *reinterpret_cast<f32x4 *>(as + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) =
+                (ok_bits >> j) & 1u ? ra[j] : zero;
 #pragma unroll
         for (int j = 0; j < Cfg::B_CHUNKS; ++j)
-            *reinterpret_cast<f32x4 *>(bs + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) = rb[j];
+            *reinterpret_cast<f32x4 *>(bs + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) =
+                (ok_bits >> (16 + j)) & 1u ? rb[j] : zero;
     };
 
     f32x16 acc[MT][NT];
@@ -275,38 +316,190 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(ARows A, BRows B
     const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 16;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (ABL != 3) { if (kt + 1 < nk) load_tile((kt + 1) * BK); }
+        // keep the prefetch ABOVE this k-step's MFMAs: hipcc otherwise sinks the loads next to
+        // their ds_write and the whole global latency is exposed once per k-step
+        __builtin_amdgcn_sched_barrier(0);
         const float *as = As + cur * BM * LDS_LD + (wm * MT * 32) * LDS_LD + frag_off;
         const float *bs = Bs + cur * BN * LDS_LD + (wn * NT * 32) * LDS_LD + frag_off;
+        // fragment reads run one quad ahead of the MFMAs that consume them
+        f32x4 a[2][MT], b[2][NT];
+        if (ABL == 2) {                        // ablation: no LDS fragment reads (operands from staging registers)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[mt % Cfg::A_CHUNKS][e], rb[nt % Cfg::B_CHUNKS][(e + q) & 3], acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[0][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 a[MT], b[NT];
+            if (q < 3) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD + q * 4);
+                for (int mt = 0; mt < MT; ++mt)
+                    a[(q + 1) & 1][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD + (q + 1) * 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD + q * 4);
+                for (int nt = 0; nt < NT; ++nt)
+                    b[(q + 1) & 1][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD + (q + 1) * 4);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], b[q & 1][nt][e], acc[mt][nt], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        }
+        if (ABL == 1) {                       // ablation: no staging writes, no barrier
+#pragma unroll
+            for (int j = 0; j < Cfg::A_CHUNKS; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+            for (int j = 0; j < Cfg::B_CHUNKS; ++j) asm volatile("" ::"v"(rb[j]));
+        } else if (ABL == 4) {                // ablation: staging writes but no barrier
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+        } else {
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+            __syncthreads();
+        }
     }
     epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
 }
 
-// ------------------------------------------------------------------ launchers
+// ------------------------------------------------------ mainloop, LDS-DMA staging
+// Same tiling and MFMA mapping as above, but the tiles go global -> LDS directly
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass, nothing for the wave
+// to wait on until the end of the k-step).  The DMA writes lane-linear (wave base +
+// 16 B x lane), so an operand tile is stored UNPADDED as [row][8 x 16 B] and the bank
+// spread comes from a swizzle applied to the per-lane SOURCE address and, identically,
+// to the fragment read: 16-B slot = chunk ^ ((row >> 1) & 7).  For ds_read_b128 (64
+// banks, 16-lane service groups) rows 2j, 2j+1 then land on slots c^j and 8+(c^j):
+// 16 distinct slots, conflict free, for every service group of a 32-row fragment.
+// Rows past the edge / chunks past K read a zero page instead of being masked.
+__device__ float jlm_zero_page[64];
+
+#define GLDS16(gp, lp)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
+                                     (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
+
+template <class Cfg>
+struct Lds2 {
+    static constexpr int NW = Cfg::NTHREADS / 64;
+    static constexpr int A_INST = Cfg::BM / 8 / NW;
+    static constexpr int B_INST = Cfg::BN / 8 / NW;
+    static constexpr int BYTES = 2 * (Cfg::BM + Cfg::BN) * 32 * 4;
+    static_assert(Cfg::BM % (8 * NW) == 0 && Cfg::BN % (8 * NW) == 0, "tile rows must split over the waves");
+};
+
 template <class Cfg, class ARows, class BRows, class Epi>
-static int launch_gemm(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm2_kernel(ARows A, BRows B, int K, Epi epi, TileMap tmap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MT = Cfg::MT, NT = Cfg::NT;
+    using L2 = Lds2<Cfg>;
+    int tile_m, tile_n;
+    if (!tmap.get(blockIdx.x, tile_m, tile_n)) return;
+    const int M = A.count(), N = B.count();
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= M || n0 >= N) return;
+    float *As = smem;                         // [2][BM][32]
+    float *Bs = smem + 2 * BM * 32;           // [2][BN][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int lrow = lane >> 3, lslot = lane & 7;
+
+    typename ARows::St sa[L2::A_INST];
+    typename BRows::St sb[L2::B_INST];
+    int ka[L2::A_INST], kb[L2::B_INST];       // source chunk (in floats) of this lane after the swizzle
+#pragma unroll
+    for (int i = 0; i < L2::A_INST; ++i) {
+        const int r = (wave * L2::A_INST + i) * 8 + lrow;
+        sa[i] = A.init(m0 + r, M);
+        ka[i] = (lslot ^ ((r >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < L2::B_INST; ++i) {
+        const int r = (wave * L2::B_INST + i) * 8 + lrow;
+        sb[i] = B.init(n0 + r, N);
+        kb[i] = (lslot ^ ((r >> 1) & 7)) * 4;
+    }
+    auto issue = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < L2::A_INST; ++i) {
+            const int k = k0 + ka[i];
+            const float *p = (k < K && A.valid(sa[i], k0)) ? A.ptr(sa[i], k0) + k : jlm_zero_page;
+            GLDS16(p, As + (buf * BM + (wave * L2::A_INST + i) * 8) * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < L2::B_INST; ++i) {
+            const int k = k0 + kb[i];
+            const float *p = (k < K && B.valid(sb[i], k0)) ? B.ptr(sb[i], k0) + k : jlm_zero_page;
+            GLDS16(p, Bs + (buf * BN + (wave * L2::B_INST + i) * 8) * 32);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    const int li = lane & 31, h = lane >> 5;
+    int qoff[4];                               // float offset of quad q inside the lane's row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue((kt + 1) * BK, cur ^ 1);
+        const float *as = As + (cur * BM + wm * MT * 32) * 32;
+        const float *bs = Bs + (cur * BN + wn * NT * 32) * 32;
+        f32x4 a[2][MT], b[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 1024 + qoff[0]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[0][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 1024 + qoff[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a[(q + 1) & 1][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 1024 + qoff[q + 1]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[(q + 1) & 1][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 1024 + qoff[q + 1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], b[q & 1][nt][e], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();          // hipcc drains the DMA (vmcnt(0)) here: the next buffer is complete
+    }
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+}
+
+template <class Cfg, class ARows, class BRows, class Epi>
+static int launch_gemm2(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm_nt_kernel<Cfg, ARows, BRows, Epi>;
+    auto kern = gemm2_kernel<Cfg, ARows, BRows, Epi>;
+    constexpr int lds = Lds2<Cfg>::BYTES;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
@@ -315,21 +508,47 @@ static int launch_gemm(const ARows &A, const BRows &B, int K, const Epi &epi, in
     tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
     tm.xcd = xcd;
     if (tm.tiles_m == 0 || tm.tiles_n == 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), Cfg::LDS_BYTES, st, A, B, K, epi, tm);
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), lds, st, A, B, K, epi, tm);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int gemm_v2_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("JLM_GEMM_V2"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+// ------------------------------------------------------------------ launchers
+template <class Cfg, class ARows, class BRows, class Epi, int ABL = 0>
+static int launch_gemm(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st, int lds_extra = 0) {
+    static bool attr_done = false;
+    auto kern = gemm_nt_kernel<Cfg, ARows, BRows, Epi, ABL>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 30000);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    TileMap tm;
+    tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
+    tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
+    tm.xcd = xcd;
+    if (tm.tiles_m == 0 || tm.tiles_n == 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), Cfg::LDS_BYTES + lds_extra, st, A, B, K, epi, tm);
     JLM_LAUNCH_CHECK();
     return 0;
 }
 
 typedef TileCfg<2, 2, 2, 2> Cfg128;     // 128 x 128, wave 64 x 64
 typedef TileCfg<2, 2, 1, 1> Cfg64;      //  64 x  64, wave 32 x 32
-typedef TileCfg<4, 1, 1, 4> CfgGate;    // 128 x 128, wave 32 x 128 (4 gate tiles)
-typedef TileCfg<2, 1, 1, 4> CfgGate64;  //  64 x 128
 
 extern "C" int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state, float *h_out, float *c_out,
                              const int *rows, const int *prev, const int *word, const float *emb, int ld_emb,
                              const float *wt, const float *bias, int kpad, int H, int E, int n_rows_max,
                              const int *n_dev, void *stream) {
     if (H % 32 != 0 || E % 4 != 0 || kpad % BK != 0 || kpad < H + E || ld_state % 4 || ld_emb % 4) return -1;
+    // (H % 32: the [h | emb] switch of the A loader must fall on a k-step boundary)
     GateRows A;
     A.h = h_in; A.ldh = ld_state; A.rows = rows; A.prev = prev; A.word = word;
     A.emb = emb; A.lde = ld_emb; A.H = H; A.nrows = n_rows_max; A.ndev = n_dev;
@@ -339,8 +558,9 @@ extern "C" int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state,
     epi.c_in = c_in; epi.h_out = h_out; epi.c_out = c_out; epi.ld = ld_state;
     epi.rows = rows; epi.prev = prev; epi.bias = bias;
     // K = H + E: chunks past it are zero filled, the packed weights are zero padded
-    if (n_rows_max <= 64) return launch_gemm<CfgGate64>(A, B, H + E, epi, 0, (hipStream_t)stream);
-    return launch_gemm<CfgGate>(A, B, H + E, epi, 0, (hipStream_t)stream);
+    const int tiles_n = 4 * H / Cfg64::BN;
+    if (gemm_v2_enabled()) return launch_gemm2<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
+    return launch_gemm<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
 }
 
 extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const float *Bp, int ldb, const int *b_rows,
@@ -354,6 +574,26 @@ extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const fl
     epi.C = C; epi.c_map = c_rows; epi.ldc = ldc; epi.bias = bias;
     // small problems: 64 x 64 tiles give 4x the workgroups (K4: [R,512]x[512,256] is only 40 tiles of 128^2)
     long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    static int variant = -1;
+    if (variant < 0) { const char *v = getenv("JLM_GEMM_VARIANT"); variant = v ? atoi(v) : 0; }
+    if (variant == 1) return launch_gemm<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream, 30000);       // 1 block / CU
+    if (variant == 2) return launch_gemm<TileCfg<2, 4, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);  // 8 waves 64x32
+    if (variant == 3) return launch_gemm<TileCfg<4, 2, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);  // 8 waves 32x64
+    if (variant == 11) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 1>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
+    if (variant == 12) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 2>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
+    if (variant == 13) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 3>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
+    if (variant == 14) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 4>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
+    if (variant == 21) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 1>(A, B, K, epi, 0, (hipStream_t)stream);
+    if (variant == 22) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 2>(A, B, K, epi, 0, (hipStream_t)stream);
+    if (variant == 6) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
+    if (variant == 7) return launch_gemm2<TileCfg<2, 2, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);   // 128 x 64
+    if (variant == 8) return launch_gemm2<TileCfg<2, 2, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);   // 64 x 128
+    if (variant == 9) return launch_gemm2<TileCfg<4, 1, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);   // 128 x 64, waves stacked on M
+    if (variant == 10) return launch_gemm2<TileCfg<2, 4, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);  // 128 x 128, 8 waves
+    if (gemm_v2_enabled() && variant == 0) {
+        if (tiles128 < 512) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
+        return launch_gemm2<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
+    }
     if (tiles128 < 512) return launch_gemm<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
     return launch_gemm<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
 }
@@ -367,9 +607,238 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
     B.base = T; B.map = rows; B.ld = ldt; B.nrows = n_rows_max; B.ndev = n_dev;
     EpiLse epi;
     epi.bias = bias; epi.part = part; epi.ld_part = ld_part; epi.tile0 = tile0;
-    int r = launch_gemm<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
+    int r = gemm_v2_enabled() ? launch_gemm2<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream)
+                              : launch_gemm<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
     if (r != 0) return r > 0 ? -r : r;
     return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
+}
+
+// ------------------------------------------------- rows-stationary vocabulary LSE
+// The D-softmax* segments have short contractions (k = 200 / 100 / 50): one output
+// tile per workgroup pays a cold prologue and an epilogue per 7 / 4 / 2 k-steps.
+// Here a workgroup keeps its 128 hypothesis rows STATIONARY -- each wave holds the
+// MFMA B-fragments of its 32 rows for the whole contraction in registers (k/2
+// floats per lane) -- and streams a contiguous range of vocabulary tiles (32*MT
+// words each) through a double-buffered LDS ring in one continuous (tile, k-step)
+// pipeline.  Each lane owns the running (max, sum exp) of one row; a vocabulary
+// tile ends with 16*MT in-register updates and no cross-lane traffic.  One
+// (max, sum) pair per (row, vocabulary range) is written at the very end.
+// One kernel instantiation per number of k-steps NK (its own register budget);
+// the grid of a launch is sized to ONE resident round of workgroups.
+template <int NK, int MT, int OCC, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
+    jlm_segment sg, const float *__restrict__ bias, int n_parts, const float *__restrict__ T, int ldt,
+    const int *__restrict__ rows, float2 *__restrict__ part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
+    constexpr int NINST = BMV / 32;                // LDS-DMA instructions per wave per k-step (8 rows each, 4 waves)
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    // XCD-aware order (n_parts is a multiple of 8 then): one XCD walks all row tiles of a vocabulary
+    // range, which stays in its L2, and every XCD gets the same number of ranges.  With fewer than 8
+    // ranges the workgroups of a range are simply dealt round-robin over the XCDs.
+    const int b = blockIdx.x;
+    int p, pt;
+    if ((n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { p = b / n_ptiles; pt = b % n_ptiles; }
+    if (p >= n_parts || pt * 128 >= n_paths) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
+    const int ntiles = (n_vocab + BMV - 1) / BMV;
+    const int vt0 = (int)((long)ntiles * p / n_parts), vt1 = (int)((long)ntiles * (p + 1) / n_parts);
+    const float *__restrict__ Bp = sg.B;
+    // 1. this lane's row fragments for the whole contraction, pre-scaled by log2(e): the logits come
+    //    out of the matrix pipe in base-2 units and the fold uses the bare v_exp_f32
+    const int prow = pt * 128 + wave * 32 + li;
+    const bool row_ok = prow < n_paths;
+    const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
+    f32x4 tf[NK][4];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kt * 32 + h * 16 + q * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+            tf[kt][q] = (row_ok && k < K) ? v * LOG2E : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // 2. stream vocabulary tiles: LDS-DMA, unpadded [row][8 x 16 B] tiles, source-side swizzle (see gemm2_kernel)
+    float *Bs = smem;                              // [2][BMV][32]
+    float *bias_s = smem + 2 * BMV * 32;           // [3][BMV], base-2 units
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int srow[NINST], skk[NINST];
+#pragma unroll
+    for (int i = 0; i < NINST; ++i) {
+        srow[i] = (wave * NINST + i) * 8 + lrow;
+        skk[i] = (lslot ^ ((srow[i] >> 1) & 7)) * 4;
+    }
+    auto issue = [&](int t, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) {
+            const int vrow = t * BMV + srow[i], k = kt * 32 + skk[i];
+            const float *src = (vrow < n_vocab && k < K) ? Bp + (size_t)vrow * ldb + k : jlm_zero_page;
+            GLDS16(src, Bs + (buf * BMV + (wave * NINST + i) * 8) * 32);
+        }
+    };
+    // bias of rows past the vocabulary is a huge negative number: padded rows (zero-page data,
+    // accumulator 0) then fold to 2^(-inf) = 0 with no masking code in the fold
+    auto bias_stage = [&](int t) {
+        if (tid < BMV) {
+            const int vrow = t * BMV + tid;
+            bias_s[((t - vt0) % 3) * BMV + tid] = vrow < n_vocab ? bias[vrow] * LOG2E : JLM_NEG_BIG;
+        }
+    };
+    float m = JLM_NEG_BIG, s = 0.0f;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    int qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
+    issue(vt0, 0, 0);
+    bias_stage(vt0);
+    __syncthreads();
+    int buf = 0;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = vt0; t < vt1; ++t) {
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            const bool last_k = (kt == NK - 1);
+            issue(last_k ? t + 1 : t, last_k ? 0 : kt + 1, buf ^ 1);   // past the range: harmless (zero page / next range)
+            const float *bs = Bs + buf * BMV * 32;
+            f32x4 a[2][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + qoff[0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[(q + 1) & 1][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + qoff[q + 1]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)      // a tile's first MFMA starts from C = 0: no accumulator reset pass
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], tf[kt][q][e],
+                                                                       (kt == 0 && q == 0 && e == 0) ? zero16 : acc[mt], 0, 0, 0);
+            }
+            // bias of the next tile: its global load is waited for together with the DMA at the barrier
+            // (a wait placed before the MFMAs would also drain the DMA just issued: vmcnt is in-order)
+            if (last_k) bias_stage(t + 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (ABL == 1) {          // ablation: keep every accumulator live with one add each, skip the fold
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[mt][r];
+            continue;
+        }
+        // 3. fold this tile's 16*MT base-2 logits of the lane's row into (m, s): branch free,
+        //    ~4 VALU + 1 v_exp per logit
+        const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
+        float tmax = JLM_NEG_BIG;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + mt * 32 + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[mt][4 * j + e] + b4[e];
+                    acc[mt][4 * j + e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+        const float mn = fmaxf(m, tmax);
+        float add0 = 0.0f, add1 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                add0 += __builtin_amdgcn_exp2f(acc[mt][r] - mn);
+                add1 += __builtin_amdgcn_exp2f(acc[mt][r + 1] - mn);
+            }
+        s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
+        m = mn;
+    }
+    if (ABL == 1) { m = 0.0f; }
+    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+    {   // merge the two lane halves (base-2 units), then hand out natural-log units
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm * LN2;
+    }
+    if (h == 0 && row_ok) part[(size_t)p * ld_part + prow] = make_float2(m, s);
+}
+
+template <int NK, int MT, int OCC>
+static int launch_lse_stat(const jlm_segment &sg, const float *bias, int max_parts, const float *T, int ldt,
+                           const int *rows, float *part, int ld_part, int n_rows_max, const int *n_dev, hipStream_t st) {
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("JLM_LSE_ABL"); abl = e ? atoi(e) : 0; }
+    auto kern = abl == 1 ? vocab_lse_stationary_kernel<NK, MT, OCC, 1> : vocab_lse_stationary_kernel<NK, MT, OCC, 0>;
+    constexpr int lds = (2 * 32 * MT * 32 + 3 * 32 * MT) * 4;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds) != hipSuccess || nb < 1)
+            nb = 1;
+        per_cu = nb > 4 ? 4 : nb;
+    }
+    const int n_ptiles = (n_rows_max + 127) / 128;
+    const int ntiles = (sg.v_end - sg.v_start + 32 * MT - 1) / (32 * MT);
+    int np = (per_cu * 256) / n_ptiles;          // one resident round of workgroups
+    if (np < 1) np = 1;
+    if (np > ntiles) np = ntiles;
+    if (np > max_parts) np = max_parts;
+    if (np < 1) return -1;
+    if (np >= 8) np &= ~7;                        // whole ranges per XCD, the same number on each (see kernel)
+    const int grid = np * n_ptiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, sg, bias, np, T, ldt, rows,
+                       reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e - 100;
+    return np;
+}
+
+// Returns the number of partial slices written (to be folded by jlm_lse_combine), or <0.
+extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
+                                        const int *rows, float *part, int ld_part, int max_parts, int n_rows_max,
+                                        const int *n_dev, void *stream) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
+    for (int i = 0; i < n_segs; ++i) {
+        const int nk = (segs_host[i].k + BK - 1) / BK;
+        if (nk > 8 || segs_host[i].k % 4 || segs_host[i].ldb % 4 || segs_host[i].t_off % 4) return -2;   // caller falls back
+    }
+    if (max_parts < n_segs) return -1;
+    int done = 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_segs; ++i) {
+        const jlm_segment &sg = segs_host[i];
+        const float *bias = b2 + sg.v_start;
+        float *pp = part + (size_t)done * ld_part * 2;
+        const int budget = max_parts - done - (n_segs - 1 - i);
+        const int nk = (sg.k + BK - 1) / BK;
+        int r;
+        switch (nk) {
+            case 1: r = launch_lse_stat<2, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 2: r = launch_lse_stat<2, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 3: r = launch_lse_stat<3, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 4: r = launch_lse_stat<4, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 5: r = launch_lse_stat<5, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 6: r = launch_lse_stat<6, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 7: r = launch_lse_stat<7, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            default: r = launch_lse_stat<8, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+        }
+        if (r < 0) return r;
+        done += r;
+    }
+    return done;
 }
 
 // lse[g] = log sum exp over the tile partials of one row.  One lane per row (coalesced

@@ -101,7 +101,8 @@ class DecodeEngine:
                 run_max = torch.empty(G, device=dev, dtype=f32)
                 run_sum = torch.empty(G, device=dev, dtype=f64)
             else:
-                part = torch.empty((max(m.n_vocab_tiles, 1), rmax, 2), device=dev, dtype=f32)
+                n_part = max(m.n_vocab_tiles, 1)
+                part = torch.empty((n_part, rmax, 2), device=dev, dtype=f32)
 
         latS = _lib.Lattice(B, beam, F, ip["sent_len"], ip["end_off"], ip["node_start"], ip["node_word"])
         stS = _lib.BeamState(score.data_ptr(), lse.data_ptr(), ysum.data_ptr() if dynamic else None,
@@ -145,7 +146,7 @@ class DecodeEngine:
                                                   run_max.data_ptr(), run_sum.data_ptr(), lsep, 0, beam, B, st),
                                "jlm_wordlist_lse(vocab_select)")
                 else:
-                    m.full_vocab_lse(Tp, rows, part.data_ptr(), rmax, lsep, rmax, ndev, st, self.recorder)
+                    m.full_vocab_lse(Tp, rows, part.data_ptr(), rmax, n_part, lsep, rmax, ndev, st, self.recorder)
             _lib.check(L.jlm_edge_logits(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
                                          ip["sg_word"], ip["sg_off"], ip["sidx"], f * B, ip["sg_node"],
                                          edge.data_ptr(), beam, B, st), "jlm_edge_logits")

@@ -164,7 +164,7 @@ class DeviceModel:
         bias = np.zeros(4 * H, dtype=f32)
         u = np.arange(H)
         for gi, g in enumerate(GATES):
-            n = (u // 32) * 128 + gi * 32 + (u % 32)
+            n = (u // 16) * 64 + gi * 16 + (u % 16)
             wt[n, :H] = np.asarray(weights["HM" + g], dtype=f32).T
             wt[n, H:H + E_in] = np.asarray(weights["IM" + g], dtype=f32).T
             bias[n] = np.asarray(weights["b" + g], dtype=f32)
@@ -233,6 +233,8 @@ class DeviceModel:
                 pmt[:E0] = PM.T
             self.pmt = dev(pmt)
         self.n_vocab_tiles = sum((sg["v_end"] - sg["v_start"] + 127) // 128 for sg in self.segments)
+        self.stationary_ok = all(sg["k"] <= 256 for sg in self.segments)
+        self.flops_per_row_vocab = sum(2.0 * sg["k"] * (sg["v_end"] - sg["v_start"]) for sg in self.segments)
         arr = (_lib.Segment * len(self.segments))()
         for i, sg in enumerate(self.segments):
             arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], sg["k"], sg["t_off"], self.seg_B[i].data_ptr(), sg["ldb"])
@@ -266,22 +268,36 @@ class DeviceModel:
             _lib.check(L.jlm_gemm_nt(T, self.ldt, rows, vt.data_ptr(), self.E0p, None, T + 4 * t_off, self.ldt, rows,
                                      None, n_rows_max, n_pad, self.E0p, n_dev, stream), "jlm_gemm_nt(VT)")
 
-    def full_vocab_lse(self, T, rows, part, ld_part, lse, n_rows_max, n_dev, stream, rec=None):
+    def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None):
+        """lse[g] over the full vocabulary for the listed rows (K5+K6 fused).
+        Rows-stationary kernel when every segment's k <= 256, else one tile GEMM
+        per segment."""
         L = _lib.lib()
-        tile0 = 0
-        for i, sg in enumerate(self.segments):
-            nv = sg["v_end"] - sg["v_start"]
+        if self.stationary_ok:
             if rec is not None:
-                rec.begin("vocab_lse_seg%d" % i)
-            r = L.jlm_vocab_lse_partials(self.seg_B[i].data_ptr(), sg["ldb"], nv, sg["k"], T + 4 * sg["t_off"], self.ldt,
-                                         rows, self.b2.data_ptr() + 4 * sg["v_start"], part, ld_part, tile0,
-                                         n_rows_max, n_dev, stream)
+                rec.begin("vocab_lse")
+            r = L.jlm_vocab_lse_stationary(self.seg_array, self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part,
+                                           ld_part, max_parts, n_rows_max, n_dev, stream)
             if rec is not None:
-                rec.end("vocab_lse_seg%d" % i)
+                rec.end("vocab_lse")
             if r < 0:
-                raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
-            tile0 += r
-        _lib.check(L.jlm_lse_combine(part, ld_part, tile0, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
+                raise _lib.JlmHipError("jlm_vocab_lse_stationary failed with code %d" % r)
+            n_parts = r
+        else:
+            n_parts = 0
+            for i, sg in enumerate(self.segments):
+                nv = sg["v_end"] - sg["v_start"]
+                if rec is not None:
+                    rec.begin("vocab_lse")
+                r = L.jlm_vocab_lse_partials(self.seg_B[i].data_ptr(), sg["ldb"], nv, sg["k"], T + 4 * sg["t_off"],
+                                             self.ldt, rows, self.b2.data_ptr() + 4 * sg["v_start"], part, ld_part,
+                                             n_parts, n_rows_max, n_dev, stream)
+                if rec is not None:
+                    rec.end("vocab_lse")
+                if r < 0:
+                    raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
+                n_parts += r
+        _lib.check(L.jlm_lse_combine(part, ld_part, n_parts, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
 
 
 class LSTM_Model():

@@ -69,7 +69,7 @@ class FakeLib:
         b = view(bias, 4 * H, np.float32)
         z = (x.astype(np.float64) @ W.T.astype(np.float64)).astype(np.float32) + b
         u = np.arange(H)
-        zi, zf, zo, zg = (z[:, (u // 32) * 128 + k * 32 + (u % 32)] for k in range(4))
+        zi, zf, zo, zg = (z[:, (u // 16) * 64 + k * 16 + (u % 16)] for k in range(4))
         sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
         cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
         hn = np.tanh(cn) * sig(zo)
@@ -115,6 +115,29 @@ class FakeLib:
             pv[tile0 + t, :n, 0] = mx
             pv[tile0 + t, :n, 1] = np.exp(yt - mx[:, None]).sum(axis=1)
         return ntiles
+
+    def jlm_vocab_lse_stationary(self, segs, n_segs, b2, T, ldt, rows, part, ld_part, max_parts, n_rows_max, n_dev,
+                                 stream):
+        """Contract: any partition of the vocabulary into <= max_parts slices; here one per segment."""
+        if n_segs > max_parts:
+            return -1
+        n = _n(n_rows_max, n_dev)
+        pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
+        if n == 0:
+            return n_segs
+        g = _rows(rows, n)
+        for i in range(n_segs):
+            sg = segs[i]
+            if sg.k > 256:
+                return -2
+            nv = sg.v_end - sg.v_start
+            Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g]).astype(np.float64)
+            Bv = view(sg.B, nv * sg.ldb, np.float32).reshape(nv, sg.ldb)[:, :sg.k].astype(np.float64)
+            y = (Tv @ Bv.T).astype(np.float32) + view(_p(b2) + 4 * sg.v_start, nv, np.float32)
+            mx = y.max(axis=1)
+            pv[i, :n, 0] = mx
+            pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
+        return n_segs
 
     def jlm_lse_combine(self, part, ld_part, n_tiles, rows, lse, n_rows_max, n_dev, stream):
         n = _n(n_rows_max, n_dev)

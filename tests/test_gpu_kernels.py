@@ -141,6 +141,33 @@ def test_vocab_lse(L, V, K, R):
     np.testing.assert_allclose(lseg.cpu().numpy(), lse.numpy(), rtol=1e-6, atol=2e-5)
 
 
+@pytest.mark.parametrize("V,widths,R", [(2000, [32], 10), (3000, [32, 16, 8], 300), (50000, [200, 100, 52], 2560),
+                                        (50000, [256], 1000), (700, [100], 129), (5000, [8, 256, 40], 64)])
+def test_vocab_lse_stationary(L, V, widths, R):
+    rng = np.random.default_rng(V + R + len(widths))
+    segs_c, segs_g, keep, ldt = _segments(rng, V, widths, ldt_extra=8)
+    G = R + 50
+    T, Tg = _pair(rng.standard_normal((G, ldt)).astype(np.float32))
+    b2, b2g = _pair(rng.standard_normal(V).astype(np.float32))
+    rows, rowsg = _pair(rng.permutation(G)[:R].astype(np.int32))
+    nd, ndg = _pair(np.array([R - 1], dtype=np.int32))
+    maxp = 96
+    part, partg = _pair(np.zeros((maxp, R, 2), dtype=np.float32))
+    lse, lseg = _pair(np.zeros(G, dtype=np.float64))
+    n0 = FK.jlm_vocab_lse_stationary(segs_c, len(widths), b2.data_ptr(), T.data_ptr(), ldt, rows.data_ptr(), part.data_ptr(),
+                                     R, maxp, R, nd.data_ptr(), 0)
+    n1 = L.jlm_vocab_lse_stationary(segs_g, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
+                                    partg.data_ptr(), R, maxp, R, ndg.data_ptr(), _st())
+    assert n0 == len(widths) and len(widths) <= n1 <= maxp, (n0, n1)
+    assert FK.jlm_lse_combine(part.data_ptr(), R, n0, rows.data_ptr(), lse.data_ptr(), R, nd.data_ptr(), 0) == 0
+    assert L.jlm_lse_combine(partg.data_ptr(), R, n1, rowsg.data_ptr(), lseg.data_ptr(), R, ndg.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lseg.cpu().numpy(), lse.numpy(), rtol=1e-6, atol=3e-5)
+    # a slice budget smaller than the segment count is an error, k > 256 asks for the tile form
+    assert L.jlm_vocab_lse_stationary(segs_g, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
+                                      partg.data_ptr(), R, 0, R, ndg.data_ptr(), _st()) < 0
+
+
 def _segments(rng, V, widths, ldt_extra=0):
     """random multi-segment output side: returns (cpu Segment array, gpu Segment array, keepalive, ldt)"""
     bounds = np.linspace(0, V, len(widths) + 1).astype(int)

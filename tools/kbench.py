@@ -57,6 +57,30 @@ def bench_lse(V, K, R, tag):
     report("lse_combine tiles=%d R=%d" % (ntile, R), 1.0, timeit(g))
 
 
+def bench_lse_stat(V, widths, R, tag):
+    if flt and flt not in "lse":
+        return
+    bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
+    segs = (_lib.Segment * len(widths))()
+    keep, off, flops = [], 0, 0.0
+    for i, k in enumerate(widths):
+        kp = (k + 3) // 4 * 4
+        nv = bounds[i + 1] - bounds[i]
+        Bm = rnd(nv, kp, scale=0.05)
+        keep.append(Bm)
+        segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bm.data_ptr(), kp)
+        off += kp
+        flops += 2.0 * k * nv * R
+    T, b2 = rnd(R, off), rnd(V, scale=0.05)
+    part = torch.empty((96, R, 2), device=dev)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    rows = torch.arange(R, device=dev, dtype=torch.int32)
+    f = lambda: L.jlm_vocab_lse_stationary(segs, len(widths), b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
+                                           part.data_ptr(), R, 96, R, nd.data_ptr(), st)
+    print("parts:", f())
+    report("vocab_lse_stationary %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+
+
 def bench_gate(H, E, R):
     if flt and flt not in "gate":
         return
@@ -86,10 +110,18 @@ def bench_gemm(M, N, K, tag):
 
 
 if __name__ == "__main__":
-    print(torch.cuda.get_device_name(0))
+    print(torch.cuda.get_device_name(0), "variant", os.environ.get("JLM_GEMM_VARIANT"))
+    if flt == "variants":
+        flt = ""
+        bench_gemm(4096, 4096, 4096, "square")
+        bench_gemm(2560, 8192, 256, "lse-like")
+        bench_gemm(2560, 2048, 736, "gate-like")
+        sys.exit(0)
     for R in (2560,):
         bench_gate(512, 200, R)
         bench_gate(512, 256, R)
+        bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
+        bench_lse_stat(50000, [256], R, "tied50k")
         bench_lse(12000, 200, R, "seg0")
         bench_lse(18000, 100, R, "seg1")
         bench_lse(20000, 50, R, "seg2")
@@ -99,4 +131,5 @@ if __name__ == "__main__":
         bench_gemm(R, 52, 200, "VT2")
     bench_gate(512, 256, 20480)
     bench_lse(100000, 256, 20480, "tied100k-b20")
+    bench_lse_stat(100000, [256], 20480, "tied100k-b20")
     bench_gemm(4096, 4096, 4096, "square")
