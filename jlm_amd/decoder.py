@@ -66,6 +66,7 @@ class Decoder():
         self.perf_log_lstm = []
         self.perf_log_softmax = []
         self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
+        self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
 
     def _load_vocab(self):
@@ -98,14 +99,21 @@ class Decoder():
         inputs = list(inputs)
         if any(len(x) == 0 for x in inputs):
             raise ValueError("empty input string")
-        lat = BatchLattice(self._builder, inputs, beam_width)
-        self.last_lattice = lat
-        vocab = None
-        if vocab_select:
-            words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
-            vocab = (words, off)
-            self.lattice_vocab = lists[-1]
-        out = self._engine.decode(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
+        out, prev = [], None
+        for i in range(0, len(inputs), self.max_batch):
+            lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
+            self.last_lattice = lat
+            vocab = None
+            if vocab_select:
+                words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+                vocab = (words, off)
+                self.lattice_vocab = lists[-1]
+            ticket = self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
+            if prev is not None:             # strings of chunk i-1 are built while the GPU decodes chunk i
+                out.extend(self._engine.collect(prev))
+                self._log_perf()
+            prev = ticket
+        out.extend(self._engine.collect(prev))
         self._log_perf()
         self.perf_sen += len(inputs)
         return out

@@ -35,16 +35,26 @@ class DynamicDecoder(Decoder):
         inputs = list(inputs)
         if any(len(x) == 0 for x in inputs):
             raise ValueError("empty input string")
-        lat = BatchLattice(self._builder, inputs, beam_width)
-        self.last_lattice = lat
-        iw, io, dw, do, lv_final = lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i))
-        self.lattice_vocab = lv_final[-1]
-        out = self._engine.decode(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN, timing=self.perf_timing)
-        self._log_perf()
-        # the vocabulary fix-up and the path re-scoring are fused into the frame's
-        # kernels; their cost is inside perf_log_softmax.  eval.py takes np.mean of these.
-        n = len(self._engine.last_timing or [])
-        self.perf_log_fix_vocab.extend([0.0] * max(n, 1))
-        self.perf_log_fix_lattice_path_prob.extend([0.0] * max(n, 1))
+        out, prev = [], None
+
+        def finish(ticket):
+            out.extend(self._engine.collect(ticket))
+            self._log_perf()
+            # the vocabulary fix-up and the path re-scoring are fused into the frame's
+            # kernels; their cost is inside perf_log_softmax.  eval.py takes np.mean of these.
+            n = len(self._engine.last_timing or [])
+            self.perf_log_fix_vocab.extend([0.0] * max(n, 1))
+            self.perf_log_fix_lattice_path_prob.extend([0.0] * max(n, 1))
+
+        for i in range(0, len(inputs), self.max_batch):
+            lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
+            self.last_lattice = lat
+            iw, io, dw, do, lv_final = lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+            self.lattice_vocab = lv_final[-1]
+            ticket = self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN, timing=self.perf_timing)
+            if prev is not None:
+                finish(prev)
+            prev = ticket
+        finish(prev)
         self.perf_sen += len(inputs)
         return out

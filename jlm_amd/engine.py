@@ -1,8 +1,8 @@
 """Frame-synchronous batched lattice decode on one MI355X.
 
 All sentences of a batch advance one kana frame at a time; every frame is a
-fixed sequence of kernel launches on one HIP stream with no host
-synchronisation until the n-best read-out:
+fixed sequence of kernel launches with no host synchronisation until the
+n-best read-out:
 
   static (Decoder.decode, reference decoder.py:220-241), frame f:
     beam_step(f)                     K7+K8  candidates, stable top-k, back pointers
@@ -10,6 +10,7 @@ synchronisation until the n-best read-out:
     project_T                        K4 (+ V_table projections)
     full_vocab_lse | wordlist_lse    K5+K6 fused log-normaliser (never the logits)
     edge_logits(nodes starting at f) logits the lattice can consume next
+                                     (side stream: independent of the normaliser)
 
   dynamic (DynamicDecoder.decode, reference decoder_dynamic.py:177-194), frame f:
     wordlist_lse(merge) on frames <= f-2 with the words new at f   (K11)
@@ -19,36 +20,299 @@ synchronisation until the n-best read-out:
 The reference evaluates frame i-1 lazily at step i (decoder_dynamic.py:130);
 stepping it eagerly is the same arithmetic.  The final frame is never stepped
 (decoder_dynamic.py never does; decoder.py does and discards the result).
+
+Buffers live in per-shape plans that are reused across batches (no allocation or
+re-upload of constants per batch).  submit()/collect() split a decode into the
+asynchronous device part and the host read-out, so the strings of batch i are
+built while the GPU decodes batch i+1 (two plans of the same shape alternate).
+
+hipGraph capture of the launch sequence is available (JLM_GRAPH=1) but off by
+default: measured on MI355X the host enqueues well ahead of the device, the GPU is
+already back-to-back busy (9.1 ms of kernels in a 9.15 ms step), so replay gains
+nothing and graph instantiation adds one-off 70 ms stalls.
 """
+import os
+
 import numpy as np
 
 from . import _lib
 from .model import _Stamp
 
 
+def _round_up(x, m):
+    return (int(x) + m - 1) // m * m
+
+
+class _Plan:
+    """Device buffers + captured graph for one decode shape."""
+
+    INT_ARRAYS = ("sent_len", "end_off", "node_start", "node_word", "sg_off", "sg_word", "sg_node", "g0", "cidx", "sidx",
+                  "vs_words", "vs_off", "di_words", "di_off", "dd_words", "dd_off")
+
+    def __init__(self, eng, key, caps):
+        torch, m, dev = eng.torch, eng.m, eng.device
+        self.key, self.caps = key, dict(caps)
+        kind, vmode, B, beam, F = key
+        self.B, self.beam, self.F = B, beam, F
+        rmax, ncell = B * beam, F * B
+        G = F * rmax
+        self.rmax, self.G, self.ncell = rmax, G, ncell
+        sizes = dict(sent_len=B, end_off=ncell + 1, node_start=caps["nodes"], node_word=caps["nodes"], sg_off=ncell + 1,
+                     sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell,
+                     vs_words=caps["vs"], vs_off=B + 1, di_words=caps["di"], di_off=ncell + 1, dd_words=caps["dd"],
+                     dd_off=ncell + 1)
+        off, self.ioff = 0, {}
+        for n in self.INT_ARRAYS:
+            self.ioff[n] = off
+            off += _round_up(max(sizes[n], 1), 4)
+        self.isize = {n: sizes[n] for n in self.INT_ARRAYS}
+        self.host_ints = torch.zeros(off + 4, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.host_ints = self.host_ints.pin_memory()
+        self.host_np = self.host_ints.numpy()
+        self.dev_ints = torch.zeros(off + 4, dtype=torch.int32, device=dev)
+        base = self.dev_ints.data_ptr()
+        self.ip = {n: base + 4 * o for n, o in self.ioff.items()}
+        # constant index arrays
+        self._set("g0", (np.arange(F, dtype=np.int32)[:, None] * rmax + np.arange(B, dtype=np.int32)[None, :] * beam))
+        self._set("cidx", np.arange(ncell, dtype=np.int32))
+        self._set("sidx", np.tile(np.arange(B, dtype=np.int32), F))
+        f64, f32, i32 = torch.float64, torch.float32, torch.int32
+        dynamic = kind == "dynamic"
+        e = lambda n, dt: torch.empty(n, device=dev, dtype=dt)
+        self.score, self.lse = e(G, f64), e(G, f64)
+        self.ysum = e(G, f64) if dynamic else None
+        self.bp, self.node, self.word = e(G, i32), e(G, i32), e(G, i32)
+        self.cnt = torch.zeros(ncell, device=dev, dtype=i32)
+        self.live = e(G, i32)
+        self.n_live = torch.zeros(F, device=dev, dtype=i32)
+        self.edge = e(max(caps["nodes"], 1) * beam, f32)
+        H, ldt = m.H, m.ldt
+        self.h, self.c = e((G, H), f32), e((G, H), f32)
+        self.T = self.h if m.mode == "untied" else e((G, ldt), f32)
+        self.run_max = self.run_sum = self.part = None
+        self.n_part = 0
+        if not m.self_norm:
+            if vmode != "full":
+                self.run_max, self.run_sum = e(G, f32), e(G, f64)
+            else:
+                self.n_part = max(m.n_vocab_tiles, 1)
+                self.part = e((self.n_part, rmax, 2), f32)
+        self.stride = F + 1
+        self.out_nodes = e((rmax, self.stride), i32)
+        self.out_len = e(rmax, i32)
+        self.out_score = e(rmax, f64)
+        pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+        self.h_nodes = pin(torch.empty((rmax, self.stride), dtype=i32))
+        self.h_len = pin(torch.empty(rmax, dtype=i32))
+        self.h_score = pin(torch.empty(rmax, dtype=f64))
+        self.h_nlive = pin(torch.empty(F, dtype=i32))
+        self.busy = False
+        self.latS = _lib.Lattice(B, beam, F, self.ip["sent_len"], self.ip["end_off"], self.ip["node_start"],
+                                 self.ip["node_word"])
+        self.stS = _lib.BeamState(self.score.data_ptr(), self.lse.data_ptr(),
+                                  self.ysum.data_ptr() if dynamic else None, self.bp.data_ptr(), self.node.data_ptr(),
+                                  self.word.data_ptr(), self.cnt.data_ptr(), self.live.data_ptr(), self.n_live.data_ptr(),
+                                  self.edge.data_ptr())
+        self.graph = None
+        self.warm = False
+
+    def _set(self, name, arr):
+        arr = np.asarray(arr, dtype=np.int32).reshape(-1)
+        assert arr.size <= self.isize[name], (name, arr.size, self.isize[name])
+        o = self.ioff[name]
+        self.host_np[o:o + arr.size] = arr
+
+    def fits(self, need):
+        return all(self.caps[k] >= v for k, v in need.items())
+
+
 class DecodeEngine:
+    MAX_PLANS = 4
+
     def __init__(self, dev_model):
         self.m = dev_model
         self.torch = dev_model.torch
         self.device = dev_model.device
         self.last_timing = None
         self.last_state = None
-        self.recorder = None            # optional model.KernelRecorder (bench.py)
+        self.recorder = None            # optional model.KernelRecorder (bench.py): forces eager launches
         self.last_n_live = None
+        self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "0") == "1"
+        self.use_side = os.environ.get("JLM_SIDE", "1") != "0"
+        self.plans = []
+        self._side = None
 
-    def _upload_ints(self, arrays):
-        """One H2D copy for a dict of int32 arrays -> dict of device pointers."""
+    # ------------------------------------------------------------------ plans
+    def _plan_for(self, kind, vmode, lat, need):
+        key = (kind, vmode, lat.n_sent, lat.beam, lat.n_frames)
+        for i, p in enumerate(self.plans):
+            if p.key == key and p.fits(need) and not p.busy:
+                self.plans.append(self.plans.pop(i))
+                return p
+        caps = {k: _round_up(int(v * 1.25) + 64, 1024) for k, v in need.items()}
+        caps["cands"] = max(_round_up(need["cands"], 256), 1024)
+        self.plans = [p for p in self.plans if p.busy or p.key != key or p.fits(need)]
+        idle = [p for p in self.plans if not p.busy]
+        while len(self.plans) >= self.MAX_PLANS and idle:
+            self.plans.remove(idle.pop(0))
+        p = _Plan(self, key, caps)
+        self.plans.append(p)
+        return p
+
+    # ---------------------------------------------------------------- enqueue
+    def _enqueue(self, p, timing):
+        """The whole launch sequence of one batch (no host synchronisation inside)."""
+        torch, m, L = self.torch, self.m, _lib.lib()
+        kind, vmode, B, beam, F = p.key
+        rmax = p.rmax
+        dynamic = kind == "dynamic"
+        self_norm = m.self_norm
+        mode = 1 if self_norm else (2 if dynamic else 0)
+        cuda = self.device.type == "cuda"
+        main = torch.cuda.current_stream() if cuda else None
+        st = main.cuda_stream if cuda else 0
+        side = None
+        if cuda and self.use_side and self.recorder is None and not timing:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+        ip = p.ip
+        H, ldt = m.H, m.ldt
+        hp, cp, Tp = p.h.data_ptr(), p.c.data_ptr(), p.T.data_ptr()
+        bpp, wordp, cntp = p.bp.data_ptr(), p.word.data_ptr(), p.cnt.data_ptr()
+        livep, nlivep, lsep = p.live.data_ptr(), p.n_live.data_ptr(), p.lse.data_ptr()
+        b2p = m.b2.data_ptr()
+        segs, nsegs = m.seg_array, m.n_segs
+        cands = p.caps["cands"]
+        p.cnt.zero_()
+        p.n_live.zero_()
+        ev = []
+        join = None
+        for f in range(F):
+            if join is not None:
+                main.wait_event(join)
+                join = None
+            if dynamic and not self_norm and f >= 2:
+                # K11: older frames learn the words that first appear at frame f
+                _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"], cntp, ip["cidx"],
+                                              ip["dd_words"], ip["dd_off"], ip["sidx"], f * B,
+                                              p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 1, beam, (f - 1) * B, st),
+                           "jlm_wordlist_lse(merge)")
+            _lib.check(L.jlm_beam_step(p.latS, p.stS, f, mode, cands, st), "jlm_beam_step")
+            if f == F - 1:
+                break
+            rows = livep + 4 * f * rmax
+            ndev = nlivep + 4 * f
+            if timing:
+                e0, e1, e2 = (_Stamp(torch, self.device) for _ in range(3))
+                e0.record()
+            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st, self.recorder)
+            if timing:
+                e1.record()
+            m.project_T(hp, H, Tp, rows, rmax, ndev, st)
+            cell = 4 * f * B
+            est = st
+            if side is not None:       # edge logits need only T: run them beside the normaliser
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)
+                est = side.cuda_stream
+            _lib.check(L.jlm_edge_logits(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
+                                         ip["sg_word"], ip["sg_off"], ip["sidx"], f * B, ip["sg_node"],
+                                         p.edge.data_ptr(), beam, B, est), "jlm_edge_logits")
+            if side is not None:
+                join = torch.cuda.Event()
+                join.record(side)
+            if not self_norm:
+                if dynamic:
+                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
+                                                  ip["di_words"], ip["di_off"], ip["sidx"], f * B,
+                                                  p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 0, beam, B, st),
+                               "jlm_wordlist_lse(init)")
+                elif vmode == "select":
+                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
+                                                  ip["vs_words"], ip["vs_off"], ip["sidx"], 0,
+                                                  p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 0, beam, B, st),
+                               "jlm_wordlist_lse(vocab_select)")
+                else:
+                    m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, rmax, ndev, st, self.recorder)
+            if timing:
+                e2.record()
+                ev.append((e0, e1, e2))
+        if join is not None:
+            main.wait_event(join)
+        _lib.check(L.jlm_backtrace(p.latS, p.stS, p.out_nodes.data_ptr(), p.out_len.data_ptr(), p.out_score.data_ptr(),
+                                   p.stride, st), "jlm_backtrace")
+        return ev
+
+    # ----------------------------------------------------------------- decode
+    def submit(self, lat, kind="static", vocab=None, dyn_lists=None, topN=10, timing=False):
+        """Enqueue one batch (upload, launch sequence, asynchronous read-back) and return a
+        ticket for :meth:`collect`.  Nothing here waits for the GPU."""
         torch = self.torch
-        names = list(arrays)
-        sizes = [int(arrays[n].size) for n in names]
-        offs = np.zeros(len(names) + 1, dtype=np.int64)
-        np.cumsum([(s + 3) // 4 * 4 for s in sizes], out=offs[1:])
-        host = np.zeros(int(offs[-1]) + 4, dtype=np.int32)
-        for n, o, s in zip(names, offs[:-1], sizes):
-            host[o:o + s] = arrays[n].reshape(-1)
-        buf = torch.from_numpy(host).to(self.device)
-        base = buf.data_ptr()
-        return buf, {n: base + 4 * int(o) for n, o in zip(names, offs[:-1])}
+        dynamic = kind == "dynamic"
+        vmode = "dynamic" if dynamic else ("select" if vocab is not None else "full")
+        need = dict(nodes=lat.n_nodes, vs=len(vocab[0]) if vocab is not None else 0,
+                    di=len(dyn_lists[0]) if dynamic else 0, dd=len(dyn_lists[2]) if dynamic else 0, cands=lat.max_cands)
+        p = self._plan_for(kind, vmode, lat, need)
+        p.busy = True
+        p._set("sent_len", lat.sent_len)
+        p._set("end_off", lat.end_off)
+        p._set("node_start", lat.node_start)
+        p._set("node_word", lat.node_word)
+        p._set("sg_off", lat.sg_off)
+        p._set("sg_word", lat.sg_word)
+        p._set("sg_node", lat.sg_node)
+        if vocab is not None:
+            p._set("vs_words", vocab[0])
+            p._set("vs_off", vocab[1])
+        if dynamic:
+            p._set("di_words", dyn_lists[0])
+            p._set("di_off", dyn_lists[1])
+            p._set("dd_words", dyn_lists[2])
+            p._set("dd_off", dyn_lists[3])
+        p.dev_ints.copy_(p.host_ints, non_blocking=True)
+        eager = (not self.use_graph) or timing or (self.recorder is not None)
+        ev = []
+        if eager:
+            ev = self._enqueue(p, timing)
+            p.warm = True
+        else:
+            if p.graph is None:
+                if not p.warm:                     # first use of this shape: lazy kernel attributes, allocator warm-up
+                    self._enqueue(p, False)
+                    torch.cuda.synchronize()
+                    p.warm = True
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue(p, False)
+                p.graph = g
+            p.graph.replay()
+        p.h_nodes.copy_(p.out_nodes, non_blocking=True)
+        p.h_len.copy_(p.out_len, non_blocking=True)
+        p.h_score.copy_(p.out_score, non_blocking=True)
+        if self.recorder is not None:
+            p.h_nlive.copy_(p.n_live, non_blocking=True)
+        done = None
+        if self.device.type == "cuda":
+            done = torch.cuda.Event()
+            done.record()
+        return (p, lat, topN, ev, timing, done)
+
+    def collect(self, ticket):
+        """Wait for a submitted batch and build its n-best lists."""
+        p, lat, topN, ev, timing, done = ticket
+        if done is not None:
+            done.synchronize()
+        if self.recorder is not None:
+            self.last_n_live = p.h_nlive.numpy().copy()
+        if timing:
+            self.last_timing = [(a.seconds_to(b), b.seconds_to(c2)) for a, b, c2 in ev]
+        self.last_state = p
+        out = self._read_out(lat, p.h_nodes.numpy(), p.h_len.numpy(), p.h_score.numpy(), topN)
+        p.busy = False
+        return out
 
     def decode(self, lat, kind="static", vocab=None, dyn_lists=None, topN=10, timing=False, keep_state=False):
         """lat: BatchLattice.  kind: 'static' | 'dynamic'.
@@ -56,127 +320,15 @@ class DecodeEngine:
         vocab_select) or None for the full vocabulary.
         dyn_lists: (init_words, init_off, delta_words, delta_off) for 'dynamic'.
         -> list (per sentence) of [(neg_log_prob, [word, ...])][:topN]"""
-        torch, m, L = self.torch, self.m, _lib.lib()
-        B, beam, F = lat.n_sent, lat.beam, lat.n_frames
-        if B == 0:
+        if lat.n_sent == 0:
             return []
-        rmax = B * beam
-        G = F * rmax
-        ncell = F * B
-        dev = self.device
-        st = m.stream()
-        self_norm = m.self_norm
-        dynamic = kind == "dynamic"
-        mode = 1 if self_norm else (2 if dynamic else 0)
-
-        ints = dict(sent_len=lat.sent_len, end_off=lat.end_off, node_start=lat.node_start, node_word=lat.node_word,
-                    sg_off=lat.sg_off, sg_word=lat.sg_word, sg_node=lat.sg_node,
-                    g0=(np.arange(F, dtype=np.int32)[:, None] * rmax + np.arange(B, dtype=np.int32)[None, :] * beam),
-                    cidx=np.arange(ncell, dtype=np.int32),
-                    sidx=np.tile(np.arange(B, dtype=np.int32), F))
-        if vocab is not None:
-            ints["vs_words"], ints["vs_off"] = vocab
-        if dynamic:
-            ints["di_words"], ints["di_off"], ints["dd_words"], ints["dd_off"] = dyn_lists
-        ibuf, ip = self._upload_ints(ints)
-
-        H, ldt = m.H, m.ldt
-        f64, f32, i32 = torch.float64, torch.float32, torch.int32
-        score = torch.empty(G, device=dev, dtype=f64)
-        lse = torch.empty(G, device=dev, dtype=f64)
-        ysum = torch.empty(G, device=dev, dtype=f64) if dynamic else None
-        bp = torch.empty(G, device=dev, dtype=i32)
-        node = torch.empty(G, device=dev, dtype=i32)
-        word = torch.empty(G, device=dev, dtype=i32)
-        cnt = torch.zeros(ncell, device=dev, dtype=i32)
-        live = torch.empty(G, device=dev, dtype=i32)
-        n_live = torch.zeros(F, device=dev, dtype=i32)
-        edge = torch.empty(max(lat.n_nodes, 1) * beam, device=dev, dtype=f32)
-        h = torch.empty((G, H), device=dev, dtype=f32)
-        c = torch.empty((G, H), device=dev, dtype=f32)
-        T = h if m.mode == "untied" else torch.empty((G, ldt), device=dev, dtype=f32)
-        use_wordlist = (vocab is not None) or dynamic
-        if not self_norm:
-            if use_wordlist:
-                run_max = torch.empty(G, device=dev, dtype=f32)
-                run_sum = torch.empty(G, device=dev, dtype=f64)
-            else:
-                n_part = max(m.n_vocab_tiles, 1)
-                part = torch.empty((n_part, rmax, 2), device=dev, dtype=f32)
-
-        latS = _lib.Lattice(B, beam, F, ip["sent_len"], ip["end_off"], ip["node_start"], ip["node_word"])
-        stS = _lib.BeamState(score.data_ptr(), lse.data_ptr(), ysum.data_ptr() if dynamic else None,
-                             bp.data_ptr(), node.data_ptr(), word.data_ptr(), cnt.data_ptr(), live.data_ptr(),
-                             n_live.data_ptr(), edge.data_ptr())
-        hp, cp, Tp = h.data_ptr(), c.data_ptr(), T.data_ptr()
-        bpp, wordp, cntp = bp.data_ptr(), word.data_ptr(), cnt.data_ptr()
-        livep, nlivep, lsep = live.data_ptr(), n_live.data_ptr(), lse.data_ptr()
-        b2p = m.b2.data_ptr()
-        segs, nsegs = m.seg_array, m.n_segs
-        ev = []
-        for f in range(F):
-            if dynamic and not self_norm and f >= 2:
-                # K11: older frames learn the words that first appear at frame f
-                _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"], cntp, ip["cidx"],
-                                              ip["dd_words"], ip["dd_off"], ip["sidx"], f * B,
-                                              run_max.data_ptr(), run_sum.data_ptr(), lsep, 1, beam, (f - 1) * B, st),
-                           "jlm_wordlist_lse(merge)")
-            _lib.check(L.jlm_beam_step(latS, stS, f, mode, lat.max_cands, st), "jlm_beam_step")
-            if f == F - 1:
-                break
-            rows = livep + 4 * f * rmax
-            ndev = nlivep + 4 * f
-            if timing:
-                e0, e1, e2 = (_Stamp(torch, dev) for _ in range(3))
-                e0.record()
-            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st, self.recorder)
-            if timing:
-                e1.record()
-            m.project_T(hp, H, Tp, rows, rmax, ndev, st)
-            cell = 4 * f * B
-            if not self_norm:
-                if dynamic:
-                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
-                                                  ip["di_words"], ip["di_off"], ip["sidx"], f * B,
-                                                  run_max.data_ptr(), run_sum.data_ptr(), lsep, 0, beam, B, st),
-                               "jlm_wordlist_lse(init)")
-                elif vocab is not None:
-                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
-                                                  ip["vs_words"], ip["vs_off"], ip["sidx"], 0,
-                                                  run_max.data_ptr(), run_sum.data_ptr(), lsep, 0, beam, B, st),
-                               "jlm_wordlist_lse(vocab_select)")
-                else:
-                    m.full_vocab_lse(Tp, rows, part.data_ptr(), rmax, n_part, lsep, rmax, ndev, st, self.recorder)
-            _lib.check(L.jlm_edge_logits(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
-                                         ip["sg_word"], ip["sg_off"], ip["sidx"], f * B, ip["sg_node"],
-                                         edge.data_ptr(), beam, B, st), "jlm_edge_logits")
-            if timing:
-                e2.record()
-                ev.append((e0, e1, e2))
-
-        stride = F + 1
-        out_nodes = torch.empty((rmax, stride), device=dev, dtype=i32)
-        out_len = torch.empty(rmax, device=dev, dtype=i32)
-        out_score = torch.empty(rmax, device=dev, dtype=f64)
-        _lib.check(L.jlm_backtrace(latS, stS, out_nodes.data_ptr(), out_len.data_ptr(), out_score.data_ptr(), stride, st),
-                   "jlm_backtrace")
-        if self.recorder is not None:
-            self.last_n_live = n_live.cpu().numpy()
-        nodes_h = out_nodes.cpu().numpy()
-        len_h = out_len.cpu().numpy()
-        score_h = out_score.cpu().numpy()
-        if timing:
-            self.last_timing = [(a.seconds_to(b), b.seconds_to(c2)) for a, b, c2 in ev]
-        if keep_state:
-            self.last_state = dict(score=score, lse=lse, ysum=ysum, bp=bp, node=node, word=word, cnt=cnt, live=live,
-                                   n_live=n_live, edge=edge, h=h, c=c, T=T, ints=ibuf)
-        return self._read_out(lat, nodes_h, len_h, score_h, topN)
+        return self.collect(self.submit(lat, kind, vocab, dyn_lists, topN, timing))
 
     @staticmethod
     def _read_out(lat, nodes_h, len_h, score_h, topN):
         B, beam = lat.n_sent, lat.beam
         # flatten every path (reversed: last word first), drop the <eos> root
-        sel, lens = [], []
+        sel = []
         for s in range(B):
             for r in range(min(beam, topN)):
                 i = s * beam + r
@@ -184,9 +336,10 @@ class DecodeEngine:
                 if n == 0:
                     break
                 sel.append((i, n))
-        if sel:
-            flat = np.concatenate([nodes_h[i, :n - 1][::-1] for i, n in sel]) if any(n > 1 for _, n in sel) else np.zeros(0, np.int64)
-            words = lat.words_of(flat) if flat.size else np.zeros(0, dtype=object)
+        words = np.zeros(0, dtype=object)
+        if sel and any(n > 1 for _, n in sel):
+            flat = np.concatenate([nodes_h[i, :n - 1][::-1] for i, n in sel])
+            words = lat.words_of(flat)
         out = [[] for _ in range(B)]
         pos = 0
         for i, n in sel:
