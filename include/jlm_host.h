@@ -1,0 +1,62 @@
+/*
+ * jlm_host.h -- C ABI of libjlm_host.so: the native (host-side, multi-threaded)
+ * lattice builder.  It replaces the Python dictionary scan of
+ * Decoder._build_lattice / _build_lattice_vocab (reference decoder/decoder.py:
+ * 79-151) for whole batches; no GPU, no torch.  jlm_amd/lattice.py binds it with
+ * ctypes and falls back to nothing: the pure-Python builder in the same file is
+ * the specification the native one is tested against (tests/test_lattice_native.py).
+ *
+ * All arrays are int32 unless stated; text and readings are UTF-32 code points.
+ */
+#ifndef JLM_HOST_H
+#define JLM_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JLM_HOST_ABI_VERSION 1
+int jlm_host_abi_version(void);
+
+typedef struct jlm_lexicon jlm_lexicon;
+
+/* Reading dictionary (reference data/reading_dict.pkl, data.py:57-76) restricted to
+ * in-vocabulary words: reading r = code points reading_cp[reading_off[r] ..
+ * reading_off[r+1]), entries entry_off[r] .. entry_off[r+1] with softmax row
+ * entry_word[] and lexicon index entry_lex[], already sorted by lexicon index
+ * (decoder.py:95).  eos_word / unk_word = w2i['<eos>'] / w2i['<unk>']. */
+jlm_lexicon *jlm_lexicon_create(const uint32_t *reading_cp, const int32_t *reading_off,
+                                const int32_t *entry_off, const int32_t *entry_word,
+                                const int32_t *entry_lex, int32_t n_readings,
+                                int32_t eos_word, int32_t unk_word);
+void jlm_lexicon_destroy(jlm_lexicon *lx);
+
+/* Lattice of a batch as CSR (layout: jlm_amd/lattice.py).
+ * Sentence s = text[text_off[s] .. text_off[s+1]); n_frames = longest sentence + 1;
+ * cells are frame-major: cell = frame * n_sent + sentence.
+ * Node ids follow (end frame, sentence, generation order) -- the reference's
+ * backward_lookup order (decoder.py:79-135), which is the beam's tie-break order.
+ * node_lex: lexicon index, -1 = <eos>, -2 = raw-symbol <unk> fallback (decoder.py:128-130).
+ * end_off / sg_off have n_frames*n_sent + 1 entries; sg_* list the nodes STARTING in a cell.
+ * Returns the number of nodes; if it exceeds node_cap only the offsets and
+ * *max_nodes_per_cell are valid and the call must be repeated with larger arrays. */
+int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text, const int32_t *text_off,
+                          int32_t n_sent, int32_t n_frames, int64_t node_cap,
+                          int32_t *node_start, int32_t *node_word, int32_t *node_lex,
+                          int32_t *node_sent, int32_t *node_end, int32_t *end_off,
+                          int32_t *sg_off, int32_t *sg_node, int32_t *sg_word,
+                          int32_t *max_nodes_per_cell, int32_t n_threads);
+
+/* Static vocabulary selection (decoder.py:137-151): per sentence the sorted unique
+ * softmax rows of its lattice, united with rows 0 .. top_samples-1 (top_sampling).
+ * vs_off has n_sent + 1 entries.  Returns the total length (retry if > cap). */
+int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int64_t n_nodes,
+                         int32_t n_sent, int32_t top_samples, int64_t cap,
+                         int32_t *vs_words, int32_t *vs_off, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JLM_HOST_H */

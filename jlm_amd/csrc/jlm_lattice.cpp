@@ -1,0 +1,202 @@
+// Native (host, multi-threaded) word-lattice builder: the C++ counterpart of
+// jlm_amd/lattice.py's BatchLattice, i.e. of Decoder._build_lattice /
+// _build_lattice_vocab in the reference (decoder/decoder.py:79-151).  C ABI in
+// include/jlm_host.h; no GPU, no torch.
+//
+// The reading dictionary becomes a trie over code points held in one flat
+// open-addressing hash table keyed by (parent node, code point): the reference's
+// O(L^2) substring look-ups become one trie walk per start position.  Entries of a
+// reading are pre-filtered to in-vocabulary words and pre-sorted by lexicon id,
+// which is the order the reference adds nodes in (decoder.py:95-126).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/jlm_host.h"
+
+namespace {
+
+struct Trie {
+    // node 0 = root.  children: hash (parent << 32 | cp) -> child id
+    std::vector<uint64_t> keys;      // 0 = empty slot (key is stored + 1)
+    std::vector<int32_t> vals;
+    uint64_t mask = 0;
+    std::vector<int32_t> ent_off;    // per trie node: entries [ent_off[n], ent_off[n+1])
+    std::vector<int32_t> ent_word, ent_lex;
+    int32_t eos_word = 0, unk_word = 0, max_len = 1;
+
+    static uint64_t mix(uint64_t x) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    }
+    int32_t child(int32_t parent, uint32_t cp) const {
+        const uint64_t key = (((uint64_t)(uint32_t)parent) << 32 | cp) + 1;
+        for (uint64_t i = mix(key) & mask;; i = (i + 1) & mask) {
+            if (keys[i] == key) return vals[i];
+            if (keys[i] == 0) return -1;
+        }
+    }
+    void insert(int32_t parent, uint32_t cp, int32_t id) {
+        const uint64_t key = (((uint64_t)(uint32_t)parent) << 32 | cp) + 1;
+        uint64_t i = mix(key) & mask;
+        while (keys[i] != 0) i = (i + 1) & mask;
+        keys[i] = key;
+        vals[i] = id;
+    }
+};
+
+struct SentNodes {
+    std::vector<int32_t> end, start, word, lex;   // generation order
+};
+
+void sentence_nodes(const Trie &t, const uint32_t *text, int L, SentNodes &out) {
+    out.end.clear(); out.start.clear(); out.word.clear(); out.lex.clear();
+    out.end.push_back(0); out.start.push_back(-1); out.word.push_back(t.eos_word); out.lex.push_back(-1);
+    std::vector<char> has(L + 2, 0);
+    for (int i = 0; i < L; ++i) {
+        int32_t n = 0;
+        const int jmax = std::min(L - i, (int)t.max_len);
+        for (int j = 0; j < jmax; ++j) {
+            if (n >= 0) n = t.child(n, text[i + j]);
+            if (n >= 0) {
+                for (int32_t e = t.ent_off[n]; e < t.ent_off[n + 1]; ++e) {
+                    out.end.push_back(i + j + 1); out.start.push_back(i);
+                    out.word.push_back(t.ent_word[e]); out.lex.push_back(t.ent_lex[e]);
+                    has[i + j + 1] = 1;
+                }
+            }
+            if (j == 0 && !has[i + 1]) {          // raw-symbol fallback, decoder.py:128-130
+                out.end.push_back(i + 1); out.start.push_back(i);
+                out.word.push_back(t.unk_word); out.lex.push_back(-2);
+                has[i + 1] = 1;
+            }
+            if (n < 0 && j > 0) break;            // no longer reading can match
+        }
+    }
+}
+
+template <class F>
+void parallel_for(int n, int n_threads, F f) {
+    if (n_threads <= 1 || n < 2 * n_threads) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_threads; ++w)
+        th.emplace_back([=]() { for (int i = w; i < n; i += n_threads) f(i); });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+struct jlm_lexicon {
+    Trie t;
+};
+
+extern "C" jlm_lexicon *jlm_lexicon_create(const uint32_t *reading_cp, const int32_t *reading_off, const int32_t *entry_off,
+                                           const int32_t *entry_word, const int32_t *entry_lex, int32_t n_readings,
+                                           int32_t eos_word, int32_t unk_word) {
+    auto *lx = new jlm_lexicon();
+    Trie &t = lx->t;
+    t.eos_word = eos_word; t.unk_word = unk_word;
+    const int64_t total_cp = reading_off[n_readings];
+    uint64_t cap = 16;
+    while (cap < (uint64_t)(total_cp + 1) * 2) cap <<= 1;
+    t.keys.assign(cap, 0); t.vals.assign(cap, 0); t.mask = cap - 1;
+    int32_t n_nodes = 1;
+    std::vector<int32_t> node_of_reading(n_readings);
+    for (int32_t r = 0; r < n_readings; ++r) {
+        int32_t n = 0;
+        const int len = reading_off[r + 1] - reading_off[r];
+        if (len > t.max_len) t.max_len = len;
+        for (int k = 0; k < len; ++k) {
+            const uint32_t cp = reading_cp[reading_off[r] + k];
+            int32_t c = t.child(n, cp);
+            if (c < 0) { c = n_nodes++; t.insert(n, cp, c); }
+            n = c;
+        }
+        node_of_reading[r] = n;
+    }
+    // entries per trie node (a reading is unique, so a node gets at most one reading's entries)
+    std::vector<int32_t> cnt(n_nodes + 1, 0);
+    for (int32_t r = 0; r < n_readings; ++r) cnt[node_of_reading[r] + 1] += entry_off[r + 1] - entry_off[r];
+    t.ent_off.assign(n_nodes + 1, 0);
+    for (int32_t n = 0; n < n_nodes; ++n) t.ent_off[n + 1] = t.ent_off[n] + cnt[n + 1];
+    t.ent_word.resize(t.ent_off[n_nodes]); t.ent_lex.resize(t.ent_off[n_nodes]);
+    for (int32_t r = 0; r < n_readings; ++r) {
+        int32_t o = t.ent_off[node_of_reading[r]];
+        for (int32_t e = entry_off[r]; e < entry_off[r + 1]; ++e, ++o) { t.ent_word[o] = entry_word[e]; t.ent_lex[o] = entry_lex[e]; }
+    }
+    return lx;
+}
+
+extern "C" void jlm_lexicon_destroy(jlm_lexicon *lx) { delete lx; }
+
+extern "C" int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text, const int32_t *text_off, int32_t n_sent,
+                                     int32_t n_frames, int64_t node_cap, int32_t *node_start, int32_t *node_word,
+                                     int32_t *node_lex, int32_t *node_sent, int32_t *node_end, int32_t *end_off,
+                                     int32_t *sg_off, int32_t *sg_node, int32_t *sg_word, int32_t *max_nodes_per_cell,
+                                     int32_t n_threads) {
+    const Trie &t = lx->t;
+    const int B = n_sent, F = n_frames;
+    std::vector<SentNodes> sn(B);
+    parallel_for(B, n_threads, [&](int s) { sentence_nodes(t, text + text_off[s], text_off[s + 1] - text_off[s], sn[s]); });
+    const int64_t ncell = (int64_t)F * B;
+    std::vector<int32_t> ecount(ncell, 0), scount(ncell, 0);
+    int64_t total = 0;
+    for (int s = 0; s < B; ++s) {
+        const SentNodes &x = sn[s];
+        total += (int64_t)x.end.size();
+        for (size_t i = 0; i < x.end.size(); ++i) {
+            ++ecount[(int64_t)x.end[i] * B + s];
+            if (x.start[i] >= 0) ++scount[(int64_t)x.start[i] * B + s];
+        }
+    }
+    end_off[0] = 0; sg_off[0] = 0;
+    int32_t mx = 0;
+    for (int64_t c = 0; c < ncell; ++c) {
+        end_off[c + 1] = end_off[c] + ecount[c];
+        sg_off[c + 1] = sg_off[c] + scount[c];
+        if (ecount[c] > mx) mx = ecount[c];
+    }
+    *max_nodes_per_cell = mx;
+    if (total > node_cap) return total;
+    // scatter in generation order: stable inside an (end frame, sentence) cell
+    std::vector<int32_t> ecur(end_off, end_off + ncell);
+    parallel_for(B, n_threads, [&](int s) {
+        const SentNodes &x = sn[s];
+        for (size_t i = 0; i < x.end.size(); ++i) {
+            const int32_t id = ecur[(int64_t)x.end[i] * B + s]++;
+            node_start[id] = x.start[i]; node_word[id] = x.word[i]; node_lex[id] = x.lex[i];
+            node_sent[id] = s; node_end[id] = x.end[i];
+        }
+    });
+    // nodes grouped by the cell they START in, ascending node id inside a cell
+    std::vector<int32_t> scur(sg_off, sg_off + ncell);
+    for (int64_t id = 0; id < total; ++id) {
+        if (node_start[id] < 0) continue;
+        const int32_t o = scur[(int64_t)node_start[id] * B + node_sent[id]]++;
+        sg_node[o] = (int32_t)id; sg_word[o] = node_word[id];
+    }
+    return total;
+}
+
+// per sentence sorted unique word ids over its lattice (+ the first `top_samples` ids), decoder.py:137-151
+extern "C" int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int64_t n_nodes, int32_t n_sent,
+                                    int32_t top_samples, int64_t cap, int32_t *vs_words, int32_t *vs_off, int32_t n_threads) {
+    std::vector<std::vector<int32_t>> per(n_sent);
+    for (int64_t i = 0; i < n_nodes; ++i) per[node_sent[i]].push_back(node_word[i]);
+    parallel_for(n_sent, n_threads, [&](int s) {
+        auto &v = per[s];
+        for (int32_t k = 0; k < top_samples; ++k) v.push_back(k);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    });
+    int64_t total = 0;
+    vs_off[0] = 0;
+    for (int s = 0; s < n_sent; ++s) { total += (int64_t)per[s].size(); vs_off[s + 1] = (int32_t)total; }
+    if (total > cap) return total;
+    for (int s = 0; s < n_sent; ++s) std::memcpy(vs_words + vs_off[s], per[s].data(), per[s].size() * sizeof(int32_t));
+    return total;
+}
+
+extern "C" int jlm_host_abi_version(void) { return JLM_HOST_ABI_VERSION; }

@@ -15,7 +15,42 @@ Arrays (int32, frame-major cells ``cell = frame * n_sent + sentence``):
   end_off[cell .. cell+1]       nodes ENDING in the cell (node ids are in this order)
   sg_off / sg_word / sg_node    nodes STARTING in the cell (edge-logit work lists)
 """
+import ctypes
+import os
+
 import numpy as np
+
+_HOST_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libjlm_host.so")
+_host = None
+
+
+def host_lib():
+    """libjlm_host.so (include/jlm_host.h) or None when it has not been built."""
+    global _host
+    if _host is None:
+        if not os.path.exists(_HOST_LIB):
+            _host = False
+        else:
+            l = ctypes.CDLL(_HOST_LIB)
+            P, I, L64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+            l.jlm_host_abi_version.restype = ctypes.c_int
+            l.jlm_lexicon_create.argtypes = [P, P, P, P, P, I, I, I]
+            l.jlm_lexicon_create.restype = P
+            l.jlm_lexicon_destroy.argtypes = [P]
+            l.jlm_lattice_build.argtypes = [P, P, P, I, I, L64, P, P, P, P, P, P, P, P, P, P, I]
+            l.jlm_lattice_build.restype = L64
+            l.jlm_static_vocab.argtypes = [P, P, L64, I, I, L64, P, P, I]
+            l.jlm_static_vocab.restype = L64
+            _host = l if l.jlm_host_abi_version() == 1 else False
+    return _host or None
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _utf32(s):
+    return np.frombuffer(s.encode("utf-32-le"), dtype=np.uint32)
 
 
 class LatticeBuilder:
@@ -43,6 +78,37 @@ class LatticeBuilder:
                 self.table[reading] = (words, lex)
                 if len(reading) > self.max_len:
                     self.max_len = len(reading)
+        self._native = None
+        self.n_threads = min(16, os.cpu_count() or 1)
+        self.use_native = os.environ.get("JLM_NATIVE_LATTICE", "1") != "0"
+
+    def native(self):
+        """Handle of the C++ trie (built on first use), or None."""
+        if not self.use_native or host_lib() is None:
+            return None
+        if self._native is None:
+            readings = list(self.table)
+            cps = [_utf32(r) for r in readings]
+            r_off = np.zeros(len(readings) + 1, dtype=np.int32)
+            np.cumsum([len(c) for c in cps], out=r_off[1:])
+            e_off = np.zeros(len(readings) + 1, dtype=np.int32)
+            np.cumsum([len(self.table[r][0]) for r in readings], out=e_off[1:])
+            self._nat_arrays = (np.concatenate(cps) if cps else np.zeros(1, np.uint32), r_off, e_off,
+                                np.fromiter((w for r in readings for w in self.table[r][0]), dtype=np.int32,
+                                            count=int(e_off[-1])),
+                                np.fromiter((x for r in readings for x in self.table[r][1]), dtype=np.int32,
+                                            count=int(e_off[-1])))
+            a = self._nat_arrays
+            self._native = host_lib().jlm_lexicon_create(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]),
+                                                         len(readings), self.eos, self.unk)
+        return self._native
+
+    def __del__(self):
+        try:
+            if getattr(self, "_native", None) and host_lib() is not None:
+                host_lib().jlm_lexicon_destroy(self._native)
+        except Exception:
+            pass
 
     def sentence_nodes(self, text):
         """-> (end, start, word, lex) python lists in generation order."""
@@ -78,6 +144,10 @@ class BatchLattice:
         self.beam = int(beam)
         self.sent_len = np.array([len(t) for t in self.texts], dtype=np.int32)
         self.n_frames = int(self.sent_len.max()) + 1 if B else 1
+        nat = builder.native() if B else None
+        if nat is not None:
+            self._build_native(nat)
+            return
         ends, starts, words, lexs, sents = [], [], [], [], []
         for s, t in enumerate(self.texts):
             e, st, w, lx = builder.sentence_nodes(t)
@@ -113,6 +183,34 @@ class BatchLattice:
         scount = np.bincount(scell, minlength=ncell)
         self.sg_off = np.zeros(ncell + 1, dtype=np.int32)
         np.cumsum(scount, out=self.sg_off[1:])
+
+    def _build_native(self, nat):
+        """Same arrays through libjlm_host.so (trie walk, threads over sentences)."""
+        lib = host_lib()
+        B, F = self.n_sent, self.n_frames
+        text = _utf32("".join(self.texts))
+        t_off = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(self.sent_len, out=t_off[1:])
+        assert int(t_off[-1]) == text.size, "non-BMP / surrogate input is not supported by the native builder"
+        ncell = F * B
+        self.end_off = np.zeros(ncell + 1, dtype=np.int32)
+        self.sg_off = np.zeros(ncell + 1, dtype=np.int32)
+        mx = np.zeros(1, dtype=np.int32)
+        cap = max(1024, int(text.size) * 48 + B)
+        while True:
+            arrs = [np.empty(cap, dtype=np.int32) for _ in range(7)]
+            n = lib.jlm_lattice_build(nat, _ptr(text), _ptr(t_off), B, F, cap, *[_ptr(a) for a in arrs[:5]],
+                                      _ptr(self.end_off), _ptr(self.sg_off), _ptr(arrs[5]), _ptr(arrs[6]), _ptr(mx),
+                                      self.builder.n_threads)
+            if n <= cap:
+                break
+            cap = int(n)
+        n = int(n)
+        self.n_nodes = n
+        self.node_start, self.node_word, self.node_lex, self.node_sent, self.node_end = (a[:n] for a in arrs[:5])
+        ns = int(self.sg_off[-1])
+        self.sg_node, self.sg_word = arrs[5][:ns], arrs[6][:ns]
+        self.max_cands = int(mx[0]) * self.beam
 
     # ---- per sentence views (used by vocabulary selection and by the tests)
     def frame_nodes(self, s, f):
@@ -152,6 +250,17 @@ class BatchLattice:
     def static_vocab(self, samples=0, top_sampling=False, random_sampling=False, vocab_len=None):
         """Per sentence sorted unique word ids over its lattice (+ samples),
         reference decoder.py:137-151.  -> (vs_words, vs_off, python lists)"""
+        lib = host_lib()
+        if lib is not None and self.builder.use_native and not (samples and random_sampling):
+            top = int(samples) if (samples and top_sampling) else 0
+            off = np.zeros(self.n_sent + 1, dtype=np.int32)
+            cap = self.n_nodes + (top + 1) * self.n_sent
+            words = np.empty(cap, dtype=np.int32)
+            n = lib.jlm_static_vocab(_ptr(np.ascontiguousarray(self.node_word)), _ptr(np.ascontiguousarray(self.node_sent)),
+                                     self.n_nodes, self.n_sent, top, cap, _ptr(words), _ptr(off), self.builder.n_threads)
+            assert n <= cap
+            words = words[:int(n)]
+            return words, off, _LazyLists(words, off)
         lists = []
         order = np.argsort(self.node_sent, kind="stable")
         bounds = np.searchsorted(self.node_sent[order], np.arange(self.n_sent + 1))
@@ -207,6 +316,21 @@ class BatchLattice:
         iw, io = _csr(init)
         dw, do = _csr(delta)
         return iw, io, dw, do, lv_final
+
+
+class _LazyLists:
+    """list-of-lists view over a CSR pair (only materialises what is asked for)."""
+
+    def __init__(self, flat, off):
+        self.flat, self.off = flat, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += len(self)
+        return self.flat[self.off[i]:self.off[i + 1]].tolist()
 
 
 def _csr(lists):
