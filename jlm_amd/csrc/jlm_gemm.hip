@@ -653,14 +653,19 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
     const int prow = pt * 128 + wave * 32 + li;
     const bool row_ok = prow < n_paths;
     const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
+    // The last k-step may be short: with kv = valid k rounded up to 8, lane-half h owns k = h*kv/2 ..
+    // and only nq_last = kv/8 of the four MFMA quads are issued (k = 200 / 104 / 56 cost 6.25 / 3.25 /
+    // 1.75 k-steps of MFMAs instead of 7 / 4 / 2).  Full k-steps are the nq = 4 case of the same map.
+    const int nq_last = (K - 32 * (NK - 1) + 7) >> 3;
     f32x4 tf[NK][4];
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = kt * 32 + h * 16 + q * 4;
+            const int nq = (kt == NK - 1) ? nq_last : 4;
+            const int k = kt * 32 + (h * nq + q) * 4;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
-            tf[kt][q] = (row_ok && k < K) ? v * LOG2E : f32x4{0.f, 0.f, 0.f, 0.f};
+            tf[kt][q] = (row_ok && q < nq && k < K) ? v * LOG2E : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     // 2. stream vocabulary tiles: LDS-DMA, unpadded [row][8 x 16 B] tiles, source-side swizzle (see gemm2_kernel)
     float *Bs = smem;                              // [2][BMV][32]
@@ -694,9 +699,12 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
-    int qoff[4];
+    int qoff[4], qoff_last[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
+    for (int q = 0; q < 4; ++q) {
+        qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
+        qoff_last[q] = li * 32 + ((((h * nq_last + q) & 7) ^ ((li >> 1) & 7)) * 4);
+    }
     issue(vt0, 0, 0);
     bias_stage(vt0);
     __syncthreads();
@@ -710,13 +718,16 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
             const float *bs = Bs + buf * BMV * 32;
             f32x4 a[2][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + qoff[0]);
+            for (int mt = 0; mt < MT; ++mt)
+                a[0][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + (last_k ? qoff_last[0] : qoff[0]));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (last_k && q >= nq_last) break;       // short last k-step (uniform)
                 if (q < 3) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        a[(q + 1) & 1][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + qoff[q + 1]);
+                        a[(q + 1) & 1][mt] =
+                            *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + (last_k ? qoff_last[q + 1] : qoff[q + 1]));
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -831,8 +842,8 @@ extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs
             case 3: r = launch_lse_stat<3, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
             case 4: r = launch_lse_stat<4, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
             case 5: r = launch_lse_stat<5, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 6: r = launch_lse_stat<6, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 7: r = launch_lse_stat<7, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 6: r = launch_lse_stat<6, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
+            case 7: r = launch_lse_stat<7, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
             default: r = launch_lse_stat<8, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
         }
         if (r < 0) return r;

@@ -175,7 +175,7 @@ class DeviceModel:
         segs_cfg = [tuple(s) for s in config["embedding_seg"]]
         self.seg_B = []          # device blocks [V_i, pad4(k_i)]
         self.segments = []       # dicts: v_start v_end k t_off ldb
-        self.vt_packed = []      # V_table: (t_off, n_pad, tensor [n_pad, Epad0]) for segments > 0
+        self.vt_packed = []      # (unused since the V-tables are folded into the T GEMM)
         self.pmt = None
         if self.mode == "untied":
             self.ldt = H
@@ -212,9 +212,13 @@ class DeviceModel:
                     self.seg_B.append(dev(blk))
                     self.segments.append(dict(v_start=s, v_end=e, k=kp, t_off=offs[i], ldb=kp))
             else:  # vtable
+                # T = [h.PM | h.(PM.VT1^T) | h.(PM.VT2^T)]: the reference computes (h.PM).VT^T
+                # (model.py:175); folding PM into the V-tables (float64 product, rounded once)
+                # makes all of T ONE GEMM per frame instead of a dependent chain of three.
                 E0 = PM.shape[1]
                 E0p = _pad(E0, 4)
                 off = 0
+                rows = []
                 for i, (size, s, e) in enumerate(segs_cfg):
                     e = self.V if e is None else e
                     kp = _pad(size, 4)
@@ -222,15 +226,17 @@ class DeviceModel:
                     blk[:, :size] = np.asarray(blocks[i], dtype=f32)
                     self.seg_B.append(dev(blk))
                     self.segments.append(dict(v_start=s, v_end=e, k=kp, t_off=off, ldb=kp))
-                    if i != 0:
-                        vt = np.zeros((kp, E0p), dtype=f32)
-                        vt[:size, :E0] = np.asarray(v_tables[i], dtype=f32)
-                        self.vt_packed.append((off, kp, dev(vt)))
+                    part = np.zeros((kp if i != 0 else E0p, H), dtype=f32)
+                    if i == 0:
+                        part[:E0] = PM.T
+                    else:
+                        pvt = np.asarray(v_tables[i], dtype=np.float64) @ PM.T.astype(np.float64)     # [size, H]
+                        part[:size] = pvt.astype(f32)
+                    rows.append(part)
                     off += kp if i != 0 else E0p
                 self.ldt = off
                 self.E0p = E0p
-                pmt = np.zeros((E0p, H), dtype=f32)
-                pmt[:E0] = PM.T
+                pmt = np.concatenate(rows, axis=0)
             self.pmt = dev(pmt)
         self.n_vocab_tiles = sum((sg["v_end"] - sg["v_start"] + 127) // 128 for sg in self.segments)
         self.stationary_ok = all(sg["k"] <= 256 for sg in self.segments)
@@ -256,7 +262,7 @@ class DeviceModel:
             rec.end("gate_gemm")
 
     def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream):
-        """T[g] = h[g].PM (+ the V_table projections).  No-op for untied models
+        """T[g] = h[g].[PM | PM.VT_i^T ...]: one GEMM.  No-op for untied models
         (T aliases h there)."""
         if self.mode == "untied":
             return
@@ -264,9 +270,6 @@ class DeviceModel:
         n_t = self.pmt.shape[0]
         _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
                                  n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
-        for (t_off, n_pad, vt) in self.vt_packed:
-            _lib.check(L.jlm_gemm_nt(T, self.ldt, rows, vt.data_ptr(), self.E0p, None, T + 4 * t_off, self.ldt, rows,
-                                     None, n_rows_max, n_pad, self.E0p, n_dev, stream), "jlm_gemm_nt(VT)")
 
     def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None):
         """lse[g] over the full vocabulary for the listed rows (K5+K6 fused).
