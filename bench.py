@@ -191,8 +191,14 @@ def main():
     if vstat:
         kname = ("vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                  else "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
+        traffic, traffic_note = None, None
+        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+        if m.stationary_ok and args.fixture == "mid-vtable" and os.path.exists(tpath):
+            with open(tpath) as tf:
+                tj = json.load(tf)
+            traffic, traffic_note = tj["vocab_lse_hbm_bytes_per_call"], tj["note"]
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(vstat["tflops"], 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(vstat["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(vstat["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                     "avg_launch_ms": round(vstat["avg_ms"], 4), "launches": vstat["launches"],
                     "flops_per_launch": vstat["flops_per_launch"], "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)",
                     "measured": "HIP events around every launch of the dominant kernel, in a repeat of the timed steps"}
