@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--cpu-sentences", type=int, default=32, help="bounded CPU-baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--end-to-end", action="store_true", help="time the host-inclusive path as the step")
+    ap.add_argument("--decoder", default="static", choices=["static", "static-vs", "dynamic"],
+                    help="static = Decoder full vocabulary (headline); static-vs = vocab_select; dynamic = DynamicDecoder (configs[3])")
     args = ap.parse_args()
 
     import numpy as np
@@ -68,26 +70,34 @@ def main():
 
     from jlm_amd import config as jconfig, synth
     from jlm_amd.decoder import Decoder
+    from jlm_amd.decoder_dynamic import DynamicDecoder
     from jlm_amd.lattice import BatchLattice
     from jlm_amd.model import KernelRecorder
 
     root = os.path.join(tempfile.gettempdir(), "jlm_bench_%d_%s_r%d" % (os.getuid(), args.fixture, rank))
     cfg, _lex, _rd, alphabet = synth.build_fixture(root, args.fixture)
     jconfig.set_root(root)
-    dec = Decoder(1)
+    dec = DynamicDecoder(1) if args.decoder == "dynamic" else Decoder(1)
     dec.perf_timing = False
+    dkw = dict(vocab_select=True) if args.decoder != "static" else {}
     eng, m = dec._engine, dec.model.dev
     # every rank decodes its own sentences (seeded by rank): sentence sharding, no data-path collective
     sents = synth.make_sentences(args.batch, args.length, seed=4242 + rank, alphabet=alphabet)
     chars_per_step = sum(len(s) for s in sents)
 
     def host_step():
-        return dec.decode_batch(sents, beam_width=args.beam)
+        return dec.decode_batch(sents, beam_width=args.beam, **dkw)
 
     lat = BatchLattice(dec._builder, sents, args.beam)
+    ekind, ekw = "static", {}
+    if args.decoder == "static-vs":
+        w_, o_, _l = lat.static_vocab()
+        ekw = dict(vocab=(w_, o_))
+    elif args.decoder == "dynamic":
+        ekind, ekw = "dynamic", dict(dyn_lists=lat.dynamic_vocab()[:4])
 
     def device_step():
-        return eng.decode(lat, "static", topN=10)
+        return eng.decode(lat, ekind, topN=10, **ekw)
 
     step = host_step if args.end_to_end else device_step
 
@@ -99,7 +109,7 @@ def main():
             return
         prev = None
         for _ in range(n):
-            t = eng.submit(lat, "static", topN=10)
+            t = eng.submit(lat, ekind, topN=10, **ekw)
             if prev is not None:
                 eng.collect(prev)
             prev = t
@@ -150,10 +160,10 @@ def main():
     # string read-out of chunk i-1 run while the GPU decodes chunk i)
     e2e_steps = max(2, min(6, args.steps))
     dec.max_batch = args.batch
-    dec.decode_batch(sents * 2, beam_width=args.beam)
+    dec.decode_batch(sents * 2, beam_width=args.beam, **dkw)
     barrier()
     t1 = time.perf_counter()
-    dec.decode_batch(sents * e2e_steps, beam_width=args.beam)
+    dec.decode_batch(sents * e2e_steps, beam_width=args.beam, **dkw)
     barrier()
     e2e = chars_per_step * e2e_steps / (time.perf_counter() - t1) * world
 
@@ -212,12 +222,12 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import jlm_oracle as orc
-        o = orc.OracleDecoder(root, 1)
+        o = (orc.OracleDynamicDecoder if args.decoder == "dynamic" else orc.OracleDecoder)(root, 1)
         n = min(args.cpu_sentences, len(sents))
         t2 = time.perf_counter()
-        ref_out = [o.decode(s, beam_width=args.beam) for s in sents[:n]]
+        ref_out = [o.decode(s, beam_width=args.beam, **dkw) for s in sents[:n]]
         cdt = time.perf_counter() - t2
-        gpu_out = dec.decode_batch(sents[:n], beam_width=args.beam)
+        gpu_out = dec.decode_batch(sents[:n], beam_width=args.beam, **dkw)
         same = sum(1 for a, b in zip(ref_out, gpu_out) if a[0][1] == b[0][1])
         cpu = {"value": round(sum(len(s) for s in sents[:n]) / cdt, 2), "unit": "chars/s", "cores": os.cpu_count(),
                "kind": "port",
@@ -235,10 +245,11 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: LSTM h=512, D-softmax* segs=(200,100,50), V=50k, beam=10, "
-                               "batch=256 sentences x 20 kana per GPU" if args.fixture == "mid-vtable" else
+                               "batch=256 sentences x 20 kana per GPU"
+                   if (args.fixture == "mid-vtable" and args.decoder == "static" and args.batch == 256) else
                                "%s batch=%d length=%d beam=%d" % (args.fixture, args.batch, args.length, args.beam),
                    "fixture": args.fixture, "sentences_per_gpu": args.batch, "kana_per_sentence": args.length,
-                   "beam": args.beam, "timed": "end_to_end" if args.end_to_end else "device",
+                   "beam": args.beam, "decoder": args.decoder, "timed": "end_to_end" if args.end_to_end else "device",
                    "parallelism": "sentence-sharded x%d, no collective" % world},
         "end_to_end_chars_per_s": round(e2e, 1),
         "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,

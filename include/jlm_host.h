@@ -56,6 +56,24 @@ int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int
                          int32_t n_sent, int32_t top_samples, int64_t cap,
                          int32_t *vs_words, int32_t *vs_off, int32_t n_threads);
 
+/* Word lists of the incremental-vocabulary decoder (decoder_dynamic.py:30-46,112-127) for a
+ * batch lattice (node_word / end_off from jlm_lattice_build).  With lv[k] the reference's
+ * cumulative per-frame vocabulary list and delta[i] = sorted(set(lv[i]) - set(lv[i-1])):
+ *   init list  of cell (k, s) = lv[k] + delta[k+1]   (what frame k's rows are first normalised over;
+ *                                frame 0 keeps duplicated sampled ids, as the reference does)
+ *   delta list of cell (i, s) = delta[i]             (appended to every older frame at step i)
+ * extra_ids / extra_off (may be NULL): per-sentence sampled ids appended to lv[0] in the given
+ * order (top_sampling: 0..samples-1; random_sampling: the caller's np.random draw).
+ * Offsets have n_frames*n_sent + 1 entries.  Returns the init total; *delta_total the delta
+ * total; if either exceeds its capacity only the offsets are valid (retry with larger arrays). */
+int64_t jlm_dynamic_vocab(const int32_t *node_word, const int32_t *end_off, const int32_t *sent_len,
+                          int32_t n_sent, int32_t n_frames,
+                          const int32_t *extra_ids, const int32_t *extra_off,
+                          int64_t init_cap, int64_t delta_cap,
+                          int32_t *init_words, int32_t *init_off,
+                          int32_t *delta_words, int32_t *delta_off, int64_t *delta_total,
+                          int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 // reading are pre-filtered to in-vocabulary words and pre-sorted by lexicon id,
 // which is the order the reference adds nodes in (decoder.py:95-126).
 #include <algorithm>
+#include <iterator>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -197,6 +198,76 @@ extern "C" int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *nod
     if (total > cap) return total;
     for (int s = 0; s < n_sent; ++s) std::memcpy(vs_words + vs_off[s], per[s].data(), per[s].size() * sizeof(int32_t));
     return total;
+}
+
+// Word lists of the incremental-vocabulary decoder (decoder_dynamic.py:30-46,112-127), see
+// include/jlm_host.h.  Pass 1 (sizes) and pass 2 (fill) share the per-sentence computation.
+namespace {
+struct DynLists {
+    std::vector<std::vector<int32_t>> init, delta;   // per frame
+};
+void dyn_sentence(const int32_t *node_word, const int32_t *end_off, int B, int s, int L, const int32_t *extra, int n_extra,
+                  DynLists &out) {
+    out.init.assign(L + 1, {});
+    out.delta.assign(L + 1, {});
+    auto frame_words = [&](int f, std::vector<int32_t> &v) {
+        v.assign(node_word + end_off[(int64_t)f * B + s], node_word + end_off[(int64_t)f * B + s + 1]);
+        std::sort(v.begin(), v.end());
+    };
+    std::vector<int32_t> lv0, seen, fw, d, merged;
+    frame_words(0, lv0);                                    // sorted, NOT de-duplicated (decoder_dynamic.py:34-43)
+    lv0.insert(lv0.end(), extra, extra + n_extra);
+    seen = lv0;
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    std::vector<int32_t> prev_list = lv0;                   // lv[k] as the reference's list (k = 0 keeps duplicates)
+    for (int i = 1; i <= L; ++i) {
+        frame_words(i, fw);
+        fw.erase(std::unique(fw.begin(), fw.end()), fw.end());
+        d.clear();
+        std::set_difference(fw.begin(), fw.end(), seen.begin(), seen.end(), std::back_inserter(d));
+        out.delta[i] = d;
+        out.init[i - 1] = prev_list;                        // init[k] = lv[k] + delta[k+1]
+        out.init[i - 1].insert(out.init[i - 1].end(), d.begin(), d.end());
+        merged.clear();
+        std::merge(seen.begin(), seen.end(), d.begin(), d.end(), std::back_inserter(merged));
+        seen.swap(merged);
+        prev_list = seen;                                   // lv[i] = sorted(set(lv[i-1]) | frame words)
+    }
+}
+}  // namespace
+
+extern "C" int64_t jlm_dynamic_vocab(const int32_t *node_word, const int32_t *end_off, const int32_t *sent_len,
+                                     int32_t n_sent, int32_t n_frames, const int32_t *extra_ids, const int32_t *extra_off,
+                                     int64_t init_cap, int64_t delta_cap, int32_t *init_words, int32_t *init_off,
+                                     int32_t *delta_words, int32_t *delta_off, int64_t *delta_total, int32_t n_threads) {
+    const int B = n_sent, F = n_frames;
+    std::vector<DynLists> all(B);
+    parallel_for(B, n_threads, [&](int s) {
+        const int32_t *ex = extra_ids ? extra_ids + extra_off[s] : nullptr;
+        const int nex = extra_ids ? extra_off[s + 1] - extra_off[s] : 0;
+        dyn_sentence(node_word, end_off, B, s, sent_len[s], ex, nex, all[s]);
+    });
+    const int64_t ncell = (int64_t)F * B;
+    int64_t ti = 0, td = 0;
+    init_off[0] = 0; delta_off[0] = 0;
+    for (int f = 0; f < F; ++f)
+        for (int s = 0; s < B; ++s) {
+            const int64_t c = (int64_t)f * B + s;
+            if (f <= sent_len[s]) { ti += (int64_t)all[s].init[f].size(); td += (int64_t)all[s].delta[f].size(); }
+            init_off[c + 1] = (int32_t)ti; delta_off[c + 1] = (int32_t)td;
+        }
+    (void)ncell;
+    *delta_total = td;
+    if (ti > init_cap || td > delta_cap) return ti;
+    parallel_for(B, n_threads, [&](int s) {
+        for (int f = 0; f <= sent_len[s]; ++f) {
+            const int64_t c = (int64_t)f * B + s;
+            std::memcpy(init_words + init_off[c], all[s].init[f].data(), all[s].init[f].size() * sizeof(int32_t));
+            std::memcpy(delta_words + delta_off[c], all[s].delta[f].data(), all[s].delta[f].size() * sizeof(int32_t));
+        }
+    });
+    return ti;
 }
 
 extern "C" int jlm_host_abi_version(void) { return JLM_HOST_ABI_VERSION; }

@@ -41,6 +41,8 @@ def host_lib():
             l.jlm_lattice_build.restype = L64
             l.jlm_static_vocab.argtypes = [P, P, L64, I, I, L64, P, P, I]
             l.jlm_static_vocab.restype = L64
+            l.jlm_dynamic_vocab.argtypes = [P, P, P, I, I, P, P, L64, L64, P, P, P, P, P, I]
+            l.jlm_dynamic_vocab.restype = L64
             _host = l if l.jlm_host_abi_version() == 1 else False
     return _host or None
 
@@ -288,34 +290,88 @@ class BatchLattice:
         lv_final[s][k] is the reference's ``lattice_vocab[k]`` list after the
         decode (original order + appended deltas)."""
         B, F = self.n_sent, self.n_frames
+        extra = None
+        if samples:
+            if random_sampling:      # one draw per sentence, in sentence order, like sentence-at-a-time calls of the reference
+                extra = [[int(x) for x in np.random.randint(vocab_len, size=samples)] for _ in range(B)]
+            elif top_sampling:
+                extra = [list(range(samples))] * B
+        lib = host_lib()
+        if lib is not None and self.builder.use_native:
+            return self._dynamic_vocab_native(lib, extra)
         init = [[] for _ in range(F * B)]
         delta = [[] for _ in range(F * B)]
-        lv_final = []
         for s in range(B):
+            lv, d = self._dyn_lists_python(s, extra[s] if extra else [])
             L = int(self.sent_len[s])
-            fw = [sorted(int(self.node_word[n]) for n in self.frame_nodes(s, f)) for f in range(L + 1)]
-            lv = {0: list(fw[0])}
-            if samples:
-                if random_sampling:
-                    lv[0] += [int(x) for x in np.random.randint(vocab_len, size=samples)]
-                elif top_sampling:
-                    lv[0] += [x for x in range(samples)]
-            for i in range(1, L + 1):
-                lv[i] = sorted(set(lv[i - 1]) | set(fw[i]))
-            d = {i: sorted(set(lv[i]) - set(lv[i - 1])) for i in range(1, L + 1)}
             for i in range(1, L + 1):
                 delta[i * B + s] = d[i]
             for k in range(L):
                 init[k * B + s] = lv[k] + d[k + 1]
-            final = {}
-            for k in range(L + 1):
-                final[k] = list(lv[k])
-                for i in range(k + 1, L + 1):
-                    final[k] += d[i]
-            lv_final.append(final)
         iw, io = _csr(init)
         dw, do = _csr(delta)
-        return iw, io, dw, do, lv_final
+        return iw, io, dw, do, _LazyFinal(self, extra)
+
+    def _dyn_lists_python(self, s, extra):
+        L = int(self.sent_len[s])
+        fw = [sorted(int(self.node_word[n]) for n in self.frame_nodes(s, f)) for f in range(L + 1)]
+        lv = {0: list(fw[0]) + list(extra)}
+        for i in range(1, L + 1):
+            lv[i] = sorted(set(lv[i - 1]) | set(fw[i]))
+        d = {i: sorted(set(lv[i]) - set(lv[i - 1])) for i in range(1, L + 1)}
+        return lv, d
+
+    def dynamic_final_vocab(self, s, extra):
+        """The reference's ``lattice_vocab`` dict of sentence ``s`` after its decode
+        (original per-frame lists + the appended deltas, decoder_dynamic.py:112-127)."""
+        lv, d = self._dyn_lists_python(s, extra)
+        L = int(self.sent_len[s])
+        final = {}
+        for k in range(L + 1):
+            final[k] = list(lv[k])
+            for i in range(k + 1, L + 1):
+                final[k] += d[i]
+        return final
+
+    def _dynamic_vocab_native(self, lib, extra):
+        B, F = self.n_sent, self.n_frames
+        ncell = F * B
+        ex_ids = ex_off = None
+        if extra:
+            ex_off = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum([len(e) for e in extra], out=ex_off[1:])
+            ex_ids = np.fromiter((x for e in extra for x in e), dtype=np.int32, count=int(ex_off[-1]))
+        io = np.zeros(ncell + 1, dtype=np.int32)
+        do = np.zeros(ncell + 1, dtype=np.int32)
+        dtot = np.zeros(1, dtype=np.int64)
+        nw = np.ascontiguousarray(self.node_word)
+        icap, dcap = max(1024, self.n_nodes * 8), max(1024, self.n_nodes + B)
+        while True:
+            iw = np.empty(icap, dtype=np.int32)
+            dw = np.empty(dcap, dtype=np.int32)
+            n = lib.jlm_dynamic_vocab(_ptr(nw), _ptr(self.end_off), _ptr(self.sent_len), B, F,
+                                      _ptr(ex_ids) if ex_ids is not None else None,
+                                      _ptr(ex_off) if ex_off is not None else None, icap, dcap, _ptr(iw), _ptr(io),
+                                      _ptr(dw), _ptr(do), _ptr(dtot), self.builder.n_threads)
+            if n <= icap and int(dtot[0]) <= dcap:
+                break
+            icap, dcap = max(icap, int(n)), max(dcap, int(dtot[0]))
+        return iw[:int(n)], io, dw[:int(dtot[0])], do, _LazyFinal(self, extra)
+
+
+class _LazyFinal:
+    """lv_final[s] computed on demand (the decoders only expose the last sentence's)."""
+
+    def __init__(self, lat, extra):
+        self.lat, self.extra = lat, extra
+
+    def __len__(self):
+        return self.lat.n_sent
+
+    def __getitem__(self, s):
+        if s < 0:
+            s += self.lat.n_sent
+        return self.lat.dynamic_final_vocab(s, self.extra[s] if self.extra else [])
 
 
 class _LazyLists:

@@ -54,3 +54,25 @@ def test_native_retry_when_capacity_is_short(fx, monkeypatch):
     b.use_native = True
     l1 = lattice.BatchLattice(b, sents, 3)
     np.testing.assert_array_equal(l0.node_word, l1.node_word)
+
+
+@pytest.mark.skipif(lattice.host_lib() is None, reason="libjlm_host.so not built")
+@pytest.mark.parametrize("kw", [dict(), dict(samples=6, top_sampling=True), dict(samples=5, random_sampling=True)])
+def test_native_dynamic_vocab_lists(kw, fx):
+    f = fx("small-tied")
+    b, v = _builder(f)
+    sents = synth.make_ragged_sentences(23, 1, 18, seed=77, alphabet=f["alphabet"])
+    outs = []
+    for native in (False, True):
+        b.use_native = native
+        lat = lattice.BatchLattice(b, sents, 5)
+        np.random.seed(11)
+        outs.append(lat.dynamic_vocab(vocab_len=len(v.w2i), **kw))
+    for a, c in zip(outs[0][:4], outs[1][:4]):
+        np.testing.assert_array_equal(a, c)
+    assert outs[0][4][-1] == outs[1][4][-1]
+    # the final per-frame lists of a sentence equal the reference's lattice_vocab after its decode
+    if not kw.get("random_sampling"):
+        o = orc.OracleDynamicDecoder(f["root"], 1)
+        o.decode(sents[3], vocab_select=True, beam_width=5, **kw)
+        assert outs[1][4][3] == o.lattice_vocab
