@@ -99,6 +99,8 @@ class Decoder():
         inputs = list(inputs)
         if any(len(x) == 0 for x in inputs):
             raise ValueError("empty input string")
+        if not inputs:
+            return []
         out, prev = [], None
         for i in range(0, len(inputs), self.max_batch):
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)

@@ -35,6 +35,8 @@ class DynamicDecoder(Decoder):
         inputs = list(inputs)
         if any(len(x) == 0 for x in inputs):
             raise ValueError("empty input string")
+        if not inputs:
+            return []
         out, prev = [], None
 
         def finish(ticket):

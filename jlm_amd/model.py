@@ -403,6 +403,9 @@ class LSTM_Model():
             if hid.shape[0] == 1:        # numpy broadcasting of a [1,H] state against R embeddings
                 hid = np.repeat(hid, R, axis=0)
                 cel = np.repeat(cel, R, axis=0)
+            elif R == 1:                 # ... and of one embedding against an [n,H] state
+                index = index * hid.shape[0]
+                R = len(index)
             else:
                 raise ValueError("operands could not be broadcast together with shapes {} ({},)".format(hid.shape, R))
         ev0, ev1, ev2 = (_Stamp(torch, self.device) for _ in range(3))
@@ -445,7 +448,9 @@ class LSTM_Model():
         (model.py:200-206) indexes the predict() tuple and raises TypeError;
         this is the evidently intended computation."""
         probs = []
-        pred = self.predict([start], vocab=None, reset=True)[0]
+        self.hidden = np.zeros((1, self.hidden_size))
+        self.cell = np.zeros((1, self.hidden_size))
+        pred = self.predict([start], vocab=None)[0]
         for inp in inputs:
             probs.append(pred[0, inp])
             pred = self.predict([inp])[0]

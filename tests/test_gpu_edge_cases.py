@@ -1,0 +1,113 @@
+"""GPU: edge cases of the decoders against the oracle -- beam 1, beam larger than the
+candidate count, one-kana and long sentences, raw-symbol (<unk>) fallbacks, empty
+batch, a vocabulary whose size is not a multiple of any tile, LSTM_Model helpers."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from jlm_amd import config as jconfig, synth       # noqa: E402
+from oracle import jlm_oracle as orc               # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(f, kind):
+    jconfig.set_root(f["root"])
+    from jlm_amd.decoder import Decoder
+    from jlm_amd.decoder_dynamic import DynamicDecoder
+    d = (DynamicDecoder if kind == "dynamic" else Decoder)(1)
+    o = (orc.OracleDynamicDecoder if kind == "dynamic" else orc.OracleDecoder)(f["root"], 1)
+    return d, o
+
+
+def _same(got, want, tag):
+    assert len(got) == len(want), tag
+    assert got[0][1] == want[0][1], (tag, got[0], want[0])
+    np.testing.assert_allclose([s for s, _ in got], [s for s, _ in want], rtol=1e-5, atol=1e-3, err_msg=str(tag))
+
+
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+@pytest.mark.parametrize("beam,topN", [(1, 10), (2, 1), (64, 10), (33, 40)])
+def test_beam_extremes(kind, beam, topN, fx):
+    f = fx("small-tied")
+    d, o = _pair(f, kind)
+    kw = dict(vocab_select=True) if kind == "dynamic" else {}
+    sents = synth.make_ragged_sentences(7, 1, 14, seed=beam + 3, alphabet=f["alphabet"])
+    got = d.decode_batch(sents, beam_width=beam, topN=topN, **kw)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=beam, topN=topN, **kw), (kind, beam, s))
+
+
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+def test_one_kana_long_and_unknown_symbols(kind, fx):
+    f = fx("small-vtable" if kind == "static" else "small-tied")
+    d, o = _pair(f, kind)
+    kw = dict(vocab_select=True) if kind == "dynamic" else {}
+    a = f["alphabet"]
+    long_s = synth.make_sentences(1, 90, seed=5, alphabet=a)[0]
+    foreign = "".join(synth.KANA[c] for c in (40, 41, 3, 70, 2, 2, 55))        # symbols outside the 12-kana lexicon: <unk> nodes
+    sents = [synth.KANA[0], long_s, foreign, synth.KANA[50], synth.KANA[1] * 30]
+    got = d.decode_batch(sents, beam_width=8, **kw)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=8, **kw), (kind, s[:8]))
+    assert any(len(w) == 1 and "/" not in w for _, ws in got[2] for w in ws)    # raw kana came through as words
+
+
+def test_empty_batch_and_bad_input(fx):
+    f = fx("small-tied")
+    d, _ = _pair(f, "static")
+    assert d.decode_batch([]) == []
+    with pytest.raises(ValueError):
+        d.decode_batch(["アイ", ""])
+    with pytest.raises(ValueError):
+        d.decode("アイ", beam_width=None)
+
+
+def test_odd_vocabulary_size(tmp_path):
+    """V = 1237 (no tile divides it), H = 96, E = 20 (k padded to 4, single short k-step)."""
+    root = str(tmp_path)
+    cfg = synth.make_config(1237, 96, 20, "tied")
+    lexicon, _rd = synth.write_lexicon(root, 1237, alphabet=10)
+    synth.write_experiment(root, 1, cfg, scale=0.3)
+    jconfig.set_root(root)
+    from jlm_amd.decoder import Decoder
+    d = Decoder(1)
+    o = orc.OracleDecoder(root, 1)
+    sents = synth.make_ragged_sentences(9, 2, 15, seed=8, alphabet=10)
+    for s, g in zip(sents, d.decode_batch(sents, beam_width=7)):
+        _same(g, o.decode(s, beam_width=7), s)
+    # materialised logits of the same model (predict API) on an odd row count
+    rng = np.random.RandomState(3)
+    idx = [int(x) for x in rng.randint(0, 1237, size=13)]
+    h0, c0 = rng.normal(0, 0.3, (13, 96)), rng.normal(0, 0.3, (13, 96))
+    (pred, y, _a, _b), h, c = d.model.predict_with_context(idx, h0, c0)
+    pr, yr, hr, cr, _, _ = o.model.predict(idx, h0, c0)
+    assert np.abs(y - yr).max() <= 1e-4 * np.abs(yr).max()
+    np.testing.assert_allclose(h, hr, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pred.sum(axis=1), 1.0, rtol=1e-4)
+
+
+def test_model_helpers(fx):
+    f = fx("small-tied")
+    jconfig.set_root(f["root"])
+    from jlm_amd.model import LSTM_Model
+    lm = LSTM_Model(1)
+    o = orc.OracleDecoder(f["root"], 1).model
+    # project() on a 1-D hidden vector, float32 input
+    hvec = np.random.RandomState(0).normal(0, 0.3, 64).astype(np.float32)
+    y = lm.project(hvec, vocab=[5, 3, 9])
+    yr = o.project(hvec[None].astype(np.float64), [5, 3, 9])
+    assert np.abs(y - yr).max() <= 1e-4 * np.abs(yr).max()
+    # reset=True keeps the previous row count (reference model.py:107-109)
+    lm.predict([1, 2, 3])
+    pred, _y, _t1, _t2 = lm.predict([4, 5, 6], reset=True)
+    assert pred.shape[0] == 3
+    # evaluate(): per-word -log p of a sequence (the reference's version is broken)
+    nll = lm.evaluate(1, [7, 8, 9])
+    h, c = o.zero_state(1)
+    want, prev = [], 1
+    for w in [7, 8, 9]:
+        p, _yy, h, c, _, _ = o.predict([prev], h, c)
+        want.append(-np.log(p[0, w]))
+        prev = w
+    np.testing.assert_allclose(nll, want, rtol=1e-4)
