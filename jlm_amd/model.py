@@ -33,12 +33,11 @@ def _pad(x, m):
     return (x + m - 1) // m * m
 
 
-def load_weights(experiment_id=0, comp=0):
-    """reference model.py:73-104 (the hard-wired-off hash-code branch is not
-    reproduced).  ``comp`` > 0 picks the k-means file, same layout."""
-    name = "lstm_weights_comp_{}.pkl".format(comp) if comp else "lstm_weights.pkl"
-    with open(os.path.join(_config.experiment_path, str(experiment_id), "weights", name), "rb") as f:
-        return pickle.load(f)
+def load_weights(experiment_id=0, comp=0, config=None):
+    """reference model.py:73-104 (the hard-wired-off hash-code branch is not reproduced);
+    every on-disk format of train/weights.py and train/comp.py: see jlm_amd/weights.py."""
+    from . import weights as _w
+    return _w.load_weights(experiment_id, comp, config)
 
 
 def prepare_weights(config, weights):
@@ -309,7 +308,7 @@ class LSTM_Model():
     def __init__(self, experiment_id=0, comp=0, device=None):
         print('LSTM model: exp {} comp {}'.format(experiment_id, comp))
         self.config = _config.load_config_dict(experiment_id)
-        raw = load_weights(experiment_id, comp)
+        raw = load_weights(experiment_id, comp, self.config)
         self.weights, self.embed_size, self.blocks, self.v_tables = prepare_weights(self.config, raw)
         if not (self.config['D_softmax'] or self.config['V_table']):
             self.embed_size = self.config['embed_size']

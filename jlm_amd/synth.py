@@ -208,3 +208,51 @@ def build_fixture(root, name, exp_id=1):
     lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet)
     write_experiment(root, exp_id, cfg, scale=scale)
     return cfg, lexicon, reading_dict, alphabet
+
+
+def write_compressed(root, exp_id, bit=8, seed=3, formats=("pkl", "dump", "txt")):
+    """k-means-style compressed copies of an experiment's weights in the formats of
+    reference train/comp.py:52-80.  The codebook here is a quantile grid (sklearn's KMeans
+    is slow and its n_jobs argument no longer exists); the FILE FORMATS are the point:
+    code uint8 with the tensor's shape, codebook float32 [2**bit, 1].
+    -> dict name -> decoded array (what inference must see)."""
+    d = os.path.join(root, "train", "experiments", str(exp_id), "weights")
+    with open(os.path.join(d, "lstm_weights.pkl"), "rb") as f:
+        weights = pickle.load(f)
+    cdir = os.path.join(d, "comp_{}".format(bit))
+    os.makedirs(cdir, exist_ok=True)
+    decoded, dump = {}, {}
+    for k, v in weights.items():
+        if isinstance(v, list):
+            raise ValueError("train/comp.py cannot compress the D_softmax block list either")
+        flat = v.reshape(-1).astype(np.float64)
+        book = np.quantile(flat, (np.arange(2 ** bit) + 0.5) / 2 ** bit).astype(np.float32).reshape(-1, 1)
+        mids = (book[1:, 0].astype(np.float64) + book[:-1, 0]) / 2
+        code = np.searchsorted(mids, flat).astype(np.uint8 if bit <= 8 else np.int64).reshape(v.shape)
+        dump[k] = (code, book)
+        decoded[k] = np.take(book, code)
+        if "txt" in formats:
+            np.savetxt(os.path.join(cdir, "{}_code.txt".format(k)), code.astype(int), fmt="%i")
+            np.savetxt(os.path.join(cdir, "{}_codebook.txt".format(k)), book)
+    if "pkl" in formats:
+        with open(os.path.join(d, "lstm_weights_comp_{}.pkl".format(bit)), "wb") as f:
+            pickle.dump(decoded, f)
+    if "dump" in formats:
+        with open(os.path.join(cdir, "lstm_weights_comp_dump.pkl"), "wb") as f:
+            pickle.dump(dump, f)
+    return decoded
+
+
+def write_verbose_dumps(root, exp_id, npy=True):
+    """The .txt/.npy per-tensor dumps of reference train/weights.py:76-87."""
+    d = os.path.join(root, "train", "experiments", str(exp_id), "weights")
+    with open(os.path.join(d, "lstm_weights.pkl"), "rb") as f:
+        weights = pickle.load(f)
+    for name, m in weights.items():
+        if isinstance(m, list):
+            for i, item in enumerate(m):
+                np.savetxt(os.path.join(d, "{}{}.txt".format(name, i)), item)
+        else:
+            np.savetxt(os.path.join(d, name + ".txt"), m)
+            if npy:
+                np.save(os.path.join(d, name + ".npy"), m)
