@@ -4,6 +4,7 @@
 // bound integer + scalar work: one 64-lane wave (or one workgroup) per sentence,
 // wavefront shuffles for the reductions, no MFMA.
 #include "jlm_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------ word-list logits
 // One workgroup per (sentence, frame) group.  The group's <= beam hypothesis
@@ -168,6 +169,12 @@ extern "C" int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const f
     return 0;
 }
 
+// matrix-pipe form for single-segment models (jlm_gemm.hip)
+extern "C" int jlm_wordlist_lse_mfma(const jlm_segment *seg_host, const float *b2, const float *T, int ldt, const int *g0,
+                                     const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
+                                     const int *wl_idx, int wl_base, float *run_max, double *run_sum, double *lse,
+                                     int merge, int beam, int n_groups, void *stream);
+
 extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
                                 const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
                                 const int *wl_idx, int wl_base, float *run_max, double *run_sum, double *lse, int merge,
@@ -175,6 +182,13 @@ extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const 
     SegTable t;
     if (seg_table(segs_host, n_segs, t) || ldt % 4) return -1;
     if (n_groups <= 0) return 0;
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char *e = getenv("JLM_WORDLIST_MFMA"); use_mfma = e ? atoi(e) : 1; }
+    if (use_mfma && n_segs == 1 && beam <= 32 && segs_host[0].k <= 256) {
+        int r = jlm_wordlist_lse_mfma(segs_host, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum,
+                                      lse, merge, beam, n_groups, stream);
+        if (r != -2) return r;
+    }
     size_t lds = wl_lds_bytes(beam, ldt);
     if (lds > 160 * 1024) return -1;
     static size_t attr = 0;

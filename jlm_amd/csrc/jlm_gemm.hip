@@ -852,6 +852,194 @@ extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs
     return done;
 }
 
+// ------------------------------------------------------- word-list LSE on the matrix pipe
+// Selected-vocabulary / incremental-vocabulary normaliser (jlm_wordlist_lse) for single-segment
+// models: one workgroup per (sentence, frame) group, its <= 32 hypothesis rows stationary in
+// registers (as in vocab_lse_stationary_kernel), the group's word list walked in 32-word tiles that
+// are GATHERED row by row straight into LDS by the DMA (the per-lane source address is the word's
+// weight row).  The four waves take every fourth tile, each with a private double buffer -- no
+// workgroup barrier in the loop, only the wave's own vmcnt -- and meet once at the end.
+template <int NK>
+__global__ __launch_bounds__(256) void wordlist_lse_mfma_kernel(
+    jlm_segment sg, const float *__restrict__ b2, const float *__restrict__ T, int ldt,
+    const int *__restrict__ g0v, const int *__restrict__ cnt, const int *__restrict__ cnt_idx,
+    const int *__restrict__ wl, const int *__restrict__ wl_off, const int *__restrict__ wl_idx, int wl_base,
+    float *__restrict__ run_max, double *__restrict__ run_sum, double *__restrict__ lse, int merge, int beam) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const int j = blockIdx.x;
+    const int nrows = min(cnt[cnt_idx[j]], min(beam, 32));
+    if (nrows <= 0) return;
+    const int gbase = g0v[j];
+    const int lid = wl_base + wl_idx[j];
+    const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, ldb = sg.ldb;
+    const float *__restrict__ Bp = sg.B;
+    const int ntiles = (nw + 31) >> 5;
+    float *Bs = smem + wave * (2 * 32 * 32 + 2 * 32);      // this wave's [2][32][32] ring + [2][32] bias
+    float *bias_s = Bs + 2 * 32 * 32;
+    float m = JLM_NEG_BIG, s = 0.0f;
+    if (wave < ntiles) {
+        const bool row_ok = li < nrows;
+        const float *trow = T + (size_t)(gbase + (row_ok ? li : 0)) * ldt + sg.t_off;
+        const int nq_last = (K - 32 * (NK - 1) + 7) >> 3;
+        f32x4 tf[NK][4];
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nq = (kt == NK - 1) ? nq_last : 4;
+                const int k = kt * 32 + (h * nq + q) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+                tf[kt][q] = (row_ok && q < nq && k < K) ? v * LOG2E : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        const int lrow = lane >> 3, lslot = lane & 7;
+        int skk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) skk[i] = (lslot ^ (((i * 8 + lrow) >> 1) & 7)) * 4;
+        int qoff[4], qoff_last[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
+            qoff_last[q] = li * 32 + ((((h * nq_last + q) & 7) ^ ((li >> 1) & 7)) * 4);
+        }
+        // word ids of a tile: rows i*8 + lrow for the DMA, row li for the bias
+        auto load_wids = [&](int t, int (&wd)[4], int &wb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = t * 32 + i * 8 + lrow;
+                wd[i] = r < nw ? wl[w0 + r] : -1;
+            }
+            const int r = t * 32 + li;
+            wb = r < nw ? wl[w0 + r] : -1;
+        };
+        auto issue = [&](const int (&wd)[4], int kt, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kt * 32 + skk[i];
+                const float *src = (wd[i] >= 0 && k < K) ? Bp + (size_t)(wd[i] - sg.v_start) * ldb + k : jlm_zero_page;
+                GLDS16(src, Bs + (buf * 32 + i * 8) * 32);
+            }
+        };
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int wd[4], wb, wdn[4], wbn;
+        load_wids(wave, wd, wb);
+        issue(wd, 0, 0);
+        int buf = 0;
+        f32x16 acc = zero16;
+        for (int t = wave; t < ntiles; t += 4) {
+            const bool more_tiles = t + 4 < ntiles;
+            if (more_tiles) load_wids(t + 4, wdn, wbn);
+            if (h == 0) bias_s[((t >> 2) & 1) * 32 + li] = wb >= 0 ? b2[wb] * LOG2E : JLM_NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                const bool last_k = (kt == NK - 1);
+                // this chunk's DMA (and everything older) has landed; same-wave visibility needs only the count
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!last_k) issue(wd, kt + 1, buf ^ 1);
+                else if (more_tiles) issue(wdn, 0, buf ^ 1);
+                const float *bs = Bs + buf * 32 * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (last_k && q >= nq_last) break;
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(bs + (last_k ? qoff_last[q] : qoff[q]));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], tf[kt][q][e],
+                                                                   (kt == 0 && q == 0 && e == 0) ? zero16 : acc, 0, 0, 0);
+                }
+                buf ^= 1;
+            }
+            // fold the tile's 16 base-2 logits of this lane's row
+            const float *bt = bias_s + ((t >> 2) & 1) * 32 + 4 * h;
+            float tmax = JLM_NEG_BIG;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + 8 * jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[4 * jj + e] + b4[e];
+                    acc[4 * jj + e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+            const float mn = fmaxf(m, tmax);
+            float add = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(acc[r] - mn);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+            m = mn;
+            if (more_tiles) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wd[i] = wdn[i];
+                wb = wbn;
+            }
+        }
+        const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm;
+    }
+    // the four waves' partial (max, sum) per row meet in LDS (base-2 units)
+    __syncthreads();
+    float *red = smem;                     // [4][32][2], reuses wave 0's ring
+    if (h == 0) { red[(wave * 32 + li) * 2] = m; red[(wave * 32 + li) * 2 + 1] = s; }
+    __syncthreads();
+    if (tid < nrows) {
+        float M = red[tid * 2], S = red[tid * 2 + 1];
+        for (int w = 1; w < 4; ++w) {
+            const float m2 = red[(w * 32 + tid) * 2], s2 = red[(w * 32 + tid) * 2 + 1];
+            const float mm = fmaxf(M, m2);
+            S = S * __builtin_amdgcn_exp2f(M - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+            M = mm;
+        }
+        const int g = gbase + tid;
+        float Mn = M * LN2;                // natural-log units from here on
+        double Sd = (double)S;
+        if (merge) {
+            const float pm = run_max[g];
+            const double ps = run_sum[g];
+            const float mm = fmaxf(pm, Mn);
+            Sd = ps * exp((double)pm - (double)mm) + Sd * exp((double)Mn - (double)mm);
+            Mn = mm;
+        }
+        run_max[g] = Mn;
+        run_sum[g] = Sd;
+        lse[g] = (double)Mn + log(Sd);
+    }
+}
+
+// Single-segment fast path of jlm_wordlist_lse (declared in jlm_beam.hip's launcher).
+extern "C" int jlm_wordlist_lse_mfma(const jlm_segment *seg_host, const float *b2, const float *T, int ldt, const int *g0,
+                                     const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
+                                     const int *wl_idx, int wl_base, float *run_max, double *run_sum, double *lse,
+                                     int merge, int beam, int n_groups, void *stream) {
+    const jlm_segment sg = *seg_host;
+    const int nk = (sg.k + BK - 1) / BK;
+    if (nk < 1 || nk > 8 || sg.k % 4 || sg.ldb % 4 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (n_groups <= 0) return 0;
+    const int lds = 4 * (2 * 32 * 32 + 2 * 32) * 4;
+    hipStream_t st = (hipStream_t)stream;
+#define JLM_WL_LAUNCH(N)                                                                                              \
+    hipLaunchKernelGGL(wordlist_lse_mfma_kernel<N>, dim3(n_groups), dim3(256), lds, st, sg, b2, T, ldt, g0, cnt, cnt_idx, \
+                       wl, wl_off, wl_idx, wl_base, run_max, run_sum, lse, merge, beam)
+    switch (nk) {
+        case 1: JLM_WL_LAUNCH(1); break;
+        case 2: JLM_WL_LAUNCH(2); break;
+        case 3: JLM_WL_LAUNCH(3); break;
+        case 4: JLM_WL_LAUNCH(4); break;
+        case 5: JLM_WL_LAUNCH(5); break;
+        case 6: JLM_WL_LAUNCH(6); break;
+        case 7: JLM_WL_LAUNCH(7); break;
+        default: JLM_WL_LAUNCH(8); break;
+    }
+#undef JLM_WL_LAUNCH
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
 // lse[g] = log sum exp over the tile partials of one row.  One lane per row (coalesced
 // float2 reads along the row index), the tiles of a row are split over the 16 waves of
 // the workgroup and merged online, then the 16 partial (max, sum) pairs meet in LDS.
