@@ -625,28 +625,18 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
 // (max, sum) pair per (row, vocabulary range) is written at the very end.
 // One kernel instantiation per number of k-steps NK (its own register budget);
 // the grid of a launch is sized to ONE resident round of workgroups.
-template <int NK, int MT, int OCC, int ABL = 0>
-__global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
-    jlm_segment sg, const float *__restrict__ bias, int n_parts, const float *__restrict__ T, int ldt,
-    const int *__restrict__ rows, float2 *__restrict__ part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int NK, int MT, int ABL = 0>
+__device__ __forceinline__ void lse_stat_body(
+    const jlm_segment &sg, const float *__restrict__ bias, int p_in_seg, int parts_in_seg, int pt, int n_paths,
+    const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row, float *smem) {
     constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
     constexpr int NINST = BMV / 32;                // LDS-DMA instructions per wave per k-step (8 rows each, 4 waves)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
-    // XCD-aware order (n_parts is a multiple of 8 then): one XCD walks all row tiles of a vocabulary
-    // range, which stays in its L2, and every XCD gets the same number of ranges.  With fewer than 8
-    // ranges the workgroups of a range are simply dealt round-robin over the XCDs.
-    const int b = blockIdx.x;
-    int p, pt;
-    if ((n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
-    else { p = b / n_ptiles; pt = b % n_ptiles; }
-    if (p >= n_parts || pt * 128 >= n_paths) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
     const int ntiles = (n_vocab + BMV - 1) / BMV;
-    const int vt0 = (int)((long)ntiles * p / n_parts), vt1 = (int)((long)ntiles * (p + 1) / n_parts);
+    const int vt0 = (int)((long)ntiles * p_in_seg / parts_in_seg), vt1 = (int)((long)ntiles * (p_in_seg + 1) / parts_in_seg);
     const float *__restrict__ Bp = sg.B;
     // 1. this lane's row fragments for the whole contraction, pre-scaled by log2(e): the logits come
     //    out of the matrix pipe in base-2 units and the fold uses the bare v_exp_f32
@@ -720,6 +710,7 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 a[0][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + (last_k ? qoff_last[0] : qoff[0]));
+            if (ABL == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (last_k && q >= nq_last) break;       // short last k-step (uniform)
@@ -736,6 +727,7 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], tf[kt][q][e],
                                                                        (kt == 0 && q == 0 && e == 0) ? zero16 : acc[mt], 0, 0, 0);
             }
+            if (ABL == 2) __builtin_amdgcn_s_setprio(0);
             // bias of the next tile: its global load is waited for together with the DMA at the barrier
             // (a wait placed before the MFMAs would also drain the DMA just issued: vmcnt is in-order)
             if (last_k) bias_stage(t + 1);
@@ -784,37 +776,50 @@ __global__ __launch_bounds__(256, OCC) void vocab_lse_stationary_kernel(
         s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
         m = mm * LN2;
     }
-    if (h == 0 && row_ok) part[(size_t)p * ld_part + prow] = make_float2(m, s);
+    if (h == 0 && row_ok) part_row[prow] = make_float2(m, s);
 }
 
-template <int NK, int MT, int OCC>
-static int launch_lse_stat(const jlm_segment &sg, const float *bias, int max_parts, const float *T, int ldt,
-                           const int *rows, float *part, int ld_part, int n_rows_max, const int *n_dev, hipStream_t st) {
-    static int abl = -1;
-    if (abl < 0) { const char *e = getenv("JLM_LSE_ABL"); abl = e ? atoi(e) : 0; }
-    auto kern = abl == 1 ? vocab_lse_stationary_kernel<NK, MT, OCC, 1> : vocab_lse_stationary_kernel<NK, MT, OCC, 0>;
-    constexpr int lds = (2 * 32 * MT * 32 + 3 * 32 * MT) * 4;
-    static int per_cu = 0;
-    if (per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 256, lds) != hipSuccess || nb < 1)
-            nb = 1;
-        per_cu = nb > 4 ? 4 : nb;
+// All segments of a model in ONE launch (one resident round of workgroups): range p belongs to
+// segment part_seg[p]; ranges are handed to segments in proportion to their MFMA work.
+#define LSES_MAX_PARTS 96
+struct LseStatArgs {
+    int n_parts, n_segs;
+    jlm_segment seg[JLM_MAX_SEGMENTS];
+    const float *bias[JLM_MAX_SEGMENTS];
+    short part_first[JLM_MAX_SEGMENTS + 1];     // ranges [part_first[i], part_first[i+1]) belong to segment i
+};
+
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void vocab_lse_stationary_kernel(LseStatArgs a, const float *__restrict__ T, int ldt,
+                                                                       const int *__restrict__ rows, float2 *__restrict__ part,
+                                                                       int ld_part, int n_rows_max, const int *n_dev,
+                                                                       int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    // XCD-aware order (n_parts is a multiple of 8 then): one XCD walks all row tiles of a vocabulary
+    // range, which stays in its L2, and every XCD gets the same number of ranges.  With fewer than 8
+    // ranges the workgroups of a range are simply dealt round-robin over the XCDs.
+    const int b = blockIdx.x;
+    int p, pt;
+    if ((a.n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { p = b / n_ptiles; pt = b % n_ptiles; }
+    if (p >= a.n_parts || pt * 128 >= n_paths) return;
+    int si = 0;
+    while (si + 1 < a.n_segs && p >= a.part_first[si + 1]) ++si;
+    const jlm_segment sg = a.seg[si];
+    const float *bias = a.bias[si];
+    const int pis = p - a.part_first[si], npis = a.part_first[si + 1] - a.part_first[si];
+    float2 *prow = part + (size_t)p * ld_part;
+    switch ((sg.k + BK - 1) / BK) {
+        case 1:
+        case 2: lse_stat_body<2, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 3: lse_stat_body<3, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 4: lse_stat_body<4, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 5: lse_stat_body<5, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 6: lse_stat_body<6, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 7: lse_stat_body<7, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        default: lse_stat_body<8, 2, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
     }
-    const int n_ptiles = (n_rows_max + 127) / 128;
-    const int ntiles = (sg.v_end - sg.v_start + 32 * MT - 1) / (32 * MT);
-    int np = (per_cu * 256) / n_ptiles;          // one resident round of workgroups
-    if (np < 1) np = 1;
-    if (np > ntiles) np = ntiles;
-    if (np > max_parts) np = max_parts;
-    if (np < 1) return -1;
-    if (np >= 8) np &= ~7;                        // whole ranges per XCD, the same number on each (see kernel)
-    const int grid = np * n_ptiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, sg, bias, np, T, ldt, rows,
-                       reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return -(int)e - 100;
-    return np;
 }
 
 // Returns the number of partial slices written (to be folded by jlm_lse_combine), or <0.
@@ -822,34 +827,66 @@ extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs
                                         const int *rows, float *part, int ld_part, int max_parts, int n_rows_max,
                                         const int *n_dev, void *stream) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
-    for (int i = 0; i < n_segs; ++i) {
-        const int nk = (segs_host[i].k + BK - 1) / BK;
-        if (nk > 8 || segs_host[i].k % 4 || segs_host[i].ldb % 4 || segs_host[i].t_off % 4) return -2;   // caller falls back
-    }
-    if (max_parts < n_segs) return -1;
-    int done = 0;
-    hipStream_t st = (hipStream_t)stream;
+    LseStatArgs a;
+    a.n_segs = n_segs;
+    long work[JLM_MAX_SEGMENTS], total = 0;
+    int ntiles[JLM_MAX_SEGMENTS];
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
-        const float *bias = b2 + sg.v_start;
-        float *pp = part + (size_t)done * ld_part * 2;
-        const int budget = max_parts - done - (n_segs - 1 - i);
         const int nk = (sg.k + BK - 1) / BK;
-        int r;
-        switch (nk) {
-            case 1: r = launch_lse_stat<2, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 2: r = launch_lse_stat<2, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 3: r = launch_lse_stat<3, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 4: r = launch_lse_stat<4, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 5: r = launch_lse_stat<5, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 6: r = launch_lse_stat<6, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            case 7: r = launch_lse_stat<7, 4, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-            default: r = launch_lse_stat<8, 2, 2>(sg, bias, budget, T, ldt, rows, pp, ld_part, n_rows_max, n_dev, st); break;
-        }
-        if (r < 0) return r;
-        done += r;
+        if (nk > 8 || sg.k % 4 || sg.ldb % 4 || sg.t_off % 4) return -2;   // caller falls back to the tile form
+        a.seg[i] = sg;
+        a.bias[i] = b2 + sg.v_start;
+        const int bmv = nk >= 8 ? 64 : 128;
+        ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
+        work[i] = (long)(sg.v_end - sg.v_start) * ((sg.k + 7) / 8);          // MFMA quads actually issued
+        total += work[i];
     }
-    return done;
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("JLM_LSE_ABL"); abl = e ? atoi(e) : 0; }
+    const int n_ptiles = (n_rows_max + 127) / 128;
+    int cap = max_parts < LSES_MAX_PARTS ? max_parts : LSES_MAX_PARTS;
+    if (cap < n_segs) return -1;
+    int np = (2 * 256) / n_ptiles;                 // one resident round: 2 workgroups per CU (register bound)
+    if (np < n_segs) np = n_segs;
+    if (np > cap) np = cap;
+    if (np >= 8) np &= ~7;                         // whole ranges per XCD, the same number on each (see kernel)
+    if (np < n_segs) np = n_segs;
+    // ranges per segment in proportion to its work, at least one, at most one per tile
+    int given = 0, k[JLM_MAX_SEGMENTS];
+    for (int i = 0; i < n_segs; ++i) {
+        k[i] = (int)((work[i] * np + total / 2) / total);
+        if (k[i] < 1) k[i] = 1;
+        if (k[i] > ntiles[i]) k[i] = ntiles[i];
+        given += k[i];
+    }
+    for (int guard = 0; given != np && guard < 4 * LSES_MAX_PARTS; ++guard) {   // settle the rounding on the fattest / leanest ranges
+        int best = -1;
+        for (int i = 0; i < n_segs; ++i) {
+            if (given < np) { if (k[i] < ntiles[i] && (best < 0 || work[i] * k[best] > work[best] * k[i])) best = i; }
+            else { if (k[i] > 1 && (best < 0 || work[i] * k[best] < work[best] * k[i])) best = i; }
+        }
+        if (best < 0) break;
+        if (given < np) { ++k[best]; ++given; } else { --k[best]; --given; }
+    }
+    a.part_first[0] = 0;
+    for (int i = 0; i < n_segs; ++i) a.part_first[i + 1] = (short)(a.part_first[i] + k[i]);
+    a.n_parts = given;
+    const int lds = (2 * 128 * 32 + 3 * 128) * 4;
+    const int grid = given * n_ptiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (abl == 1)
+        hipLaunchKernelGGL(vocab_lse_stationary_kernel<1>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    else if (abl == 2)
+        hipLaunchKernelGGL(vocab_lse_stationary_kernel<2>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    else
+        hipLaunchKernelGGL(vocab_lse_stationary_kernel<0>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e - 100;
+    return given;
 }
 
 // ------------------------------------------------------- word-list LSE on the matrix pipe
