@@ -14,15 +14,11 @@
 // on single-pass bf16/fp16 MFMA (which misses the bar at K~768).
 //
 // Tiling: block = WAVES_M x WAVES_N waves, wave tile = (MT*32) x (NT*32),
-// BK = 32 floats per k-step.  LDS rows are padded to 36 floats: the wave's
-// ds_read_b128 fragment reads (row = lane&31, 16-B slot = 9*row + const) hit 16
-// distinct slots per 16-lane service group, i.e. conflict free, and the
-// 128-B-per-row ds_write_b128 staging writes are conflict free as well.
-// Global -> LDS staging goes through registers (8 lanes read one 128-B row
-// segment: fully coalesced) and is issued one k-step ahead of the MFMAs; two
-// LDS buffers, one barrier per k-step.  f32 MFMA retires 4096 FLOP per 64
-// cycles per SIMD, so a 64x64 wave tile spends 4096 cycles per k-step against
-// 16 ds_read_b128 + 8 global loads: the kernel is MFMA-issue bound by design.
+// BK = 32 floats per k-step, tiles staged global -> LDS by the DMA one k-step
+// ahead of the MFMAs (see "mainloop, LDS-DMA staging" below); two LDS buffers,
+// one barrier per k-step.  f32 MFMA retires 4096 FLOP per 64 cycles per SIMD, so
+// a 64x64 wave tile spends 4096 cycles per k-step against 16 ds_read_b128 and 8
+// DMA issues: the kernel is MFMA-issue bound by design.
 //
 // MFMA operand mapping (32x32x2): lane l supplies A[i = l&31][kk = l>>5] and
 // B[kk = l>>5][j = l&31].  Within a k-step lane-half h owns k = 16h .. 16h+15
@@ -33,7 +29,6 @@
 #include <stdlib.h>
 
 #define BK 32
-#define LDS_LD 36
 
 template <int WM_, int WN_, int MT_, int NT_>
 struct TileCfg {
@@ -41,10 +36,6 @@ struct TileCfg {
     static constexpr int BM = WM_ * MT_ * 32;
     static constexpr int BN = WN_ * NT_ * 32;
     static constexpr int NTHREADS = WM_ * WN_ * 64;
-    static constexpr int A_CHUNKS = BM * 8 / NTHREADS;
-    static constexpr int B_CHUNKS = BN * 8 / NTHREADS;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * LDS_LD * 4;
-    static_assert(BM * 8 % NTHREADS == 0 && BN * 8 % NTHREADS == 0, "tile/threads mismatch");
 };
 
 // ---------------------------------------------------------------- row sources
@@ -244,135 +235,6 @@ struct EpiLse {
     }
 };
 
-// ------------------------------------------------------------------- mainloop
-template <class Cfg, class ARows, class BRows, class Epi, int ABL = 0>
-__global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(ARows A, BRows B, int K, Epi epi, TileMap tmap) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, MT = Cfg::MT, NT = Cfg::NT;
-    int tile_m, tile_n;
-    if (!tmap.get(blockIdx.x, tile_m, tile_n)) return;
-    const int M = A.count(), N = B.count();
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    if (m0 >= M || n0 >= N) return;
-
-    float *As = smem;                         // [2][BM][LDS_LD]
-    float *Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-    const int kc = tid & 7;                   // 16-B chunk inside the 128-B row segment
-
-    typename ARows::St sa[Cfg::A_CHUNKS];
-    typename BRows::St sb[Cfg::B_CHUNKS];
-#pragma unroll
-    for (int j = 0; j < Cfg::A_CHUNKS; ++j) sa[j] = A.init(m0 + (tid >> 3) + j * (Cfg::NTHREADS / 8), M);
-#pragma unroll
-    for (int j = 0; j < Cfg::B_CHUNKS; ++j) sb[j] = B.init(n0 + (tid >> 3) + j * (Cfg::NTHREADS / 8), N);
-
-    f32x4 ra[Cfg::A_CHUNKS], rb[Cfg::B_CHUNKS];
-    unsigned ok_bits = 0;       // validity of the chunks in flight; the zero-select happens at the
-                                // ds_write, so nothing forces a wait on the loads before the MFMAs
-    auto load_tile = [&](int k0) {
-        const int k = k0 + kc * 4;
-        const bool okk = k < K;
-        const int kk = okk ? k : k0;            // k0 < K always: stays inside the row
-        ok_bits = 0;
-#pragma unroll
-        for (int j = 0; j < Cfg::A_CHUNKS; ++j) {
-            ra[j] = *reinterpret_cast<const f32x4 *>(A.ptr(sa[j], k0) + kk);
-            ok_bits |= (okk && A.valid(sa[j], k0)) ? (1u << j) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < Cfg::B_CHUNKS; ++j) {
-            rb[j] = *reinterpret_cast<const f32x4 *>(B.ptr(sb[j], k0) + kk);
-            ok_bits |= (okk && B.valid(sb[j], k0)) ? (1u << (16 + j)) : 0u;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float *as = As + buf * BM * LDS_LD, *bs = Bs + buf * BN * LDS_LD;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < Cfg::A_CHUNKS; ++j)
-            *reinterpret_cast<f32x4 *>(as + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) =
-                (ok_bits >> j) & 1u ? ra[j] : zero;
-#pragma unroll
-        for (int j = 0; j < Cfg::B_CHUNKS; ++j)
-            *reinterpret_cast<f32x4 *>(bs + ((tid >> 3) + j * (Cfg::NTHREADS / 8)) * LDS_LD + kc * 4) =
-                (ok_bits >> (16 + j)) & 1u ? rb[j] : zero;
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-
-    const int nk = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 16;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (ABL != 3) { if (kt + 1 < nk) load_tile((kt + 1) * BK); }
-        // keep the prefetch ABOVE this k-step's MFMAs: hipcc otherwise sinks the loads next to
-        // their ds_write and the whole global latency is exposed once per k-step
-        __builtin_amdgcn_sched_barrier(0);
-        const float *as = As + cur * BM * LDS_LD + (wm * MT * 32) * LDS_LD + frag_off;
-        const float *bs = Bs + cur * BN * LDS_LD + (wn * NT * 32) * LDS_LD + frag_off;
-        // fragment reads run one quad ahead of the MFMAs that consume them
-        f32x4 a[2][MT], b[2][NT];
-        if (ABL == 2) {                        // ablation: no LDS fragment reads (operands from staging registers)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[mt % Cfg::A_CHUNKS][e], rb[nt % Cfg::B_CHUNKS][(e + q) & 3], acc[mt][nt], 0, 0, 0);
-        } else {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[0][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < 3) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    a[(q + 1) & 1][mt] = *reinterpret_cast<const f32x4 *>(as + mt * 32 * LDS_LD + (q + 1) * 4);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[(q + 1) & 1][nt] = *reinterpret_cast<const f32x4 *>(bs + nt * 32 * LDS_LD + (q + 1) * 4);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], b[q & 1][nt][e], acc[mt][nt], 0, 0, 0);
-        }
-        }
-        if (ABL == 1) {                       // ablation: no staging writes, no barrier
-#pragma unroll
-            for (int j = 0; j < Cfg::A_CHUNKS; ++j) asm volatile("" ::"v"(ra[j]));
-#pragma unroll
-            for (int j = 0; j < Cfg::B_CHUNKS; ++j) asm volatile("" ::"v"(rb[j]));
-        } else if (ABL == 4) {                // ablation: staging writes but no barrier
-            if (kt + 1 < nk) store_tile(cur ^ 1);
-        } else {
-            if (kt + 1 < nk) store_tile(cur ^ 1);
-            __syncthreads();
-        }
-    }
-    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
-}
-
 // ------------------------------------------------------ mainloop, LDS-DMA staging
 // Same tiling and MFMA mapping as above, but the tiles go global -> LDS directly
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass, nothing for the wave
@@ -513,33 +375,8 @@ static int launch_gemm2(const ARows &A, const BRows &B, int K, const Epi &epi, i
     return 0;
 }
 
-static int gemm_v2_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("JLM_GEMM_V2"); v = e ? atoi(e) : 1; }
-    return v;
-}
 
 // ------------------------------------------------------------------ launchers
-template <class Cfg, class ARows, class BRows, class Epi, int ABL = 0>
-static int launch_gemm(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st, int lds_extra = 0) {
-    static bool attr_done = false;
-    auto kern = gemm_nt_kernel<Cfg, ARows, BRows, Epi, ABL>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 30000);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    TileMap tm;
-    tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
-    tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
-    tm.xcd = xcd;
-    if (tm.tiles_m == 0 || tm.tiles_n == 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), Cfg::LDS_BYTES + lds_extra, st, A, B, K, epi, tm);
-    JLM_LAUNCH_CHECK();
-    return 0;
-}
-
 typedef TileCfg<2, 2, 2, 2> Cfg128;     // 128 x 128, wave 64 x 64
 typedef TileCfg<2, 2, 1, 1> Cfg64;      //  64 x  64, wave 32 x 32
 
@@ -559,8 +396,7 @@ extern "C" int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state,
     epi.rows = rows; epi.prev = prev; epi.bias = bias;
     // K = H + E: chunks past it are zero filled, the packed weights are zero padded
     const int tiles_n = 4 * H / Cfg64::BN;
-    if (gemm_v2_enabled()) return launch_gemm2<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
-    return launch_gemm<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
+    return launch_gemm2<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
 }
 
 extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const float *Bp, int ldb, const int *b_rows,
@@ -574,28 +410,8 @@ extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const fl
     epi.C = C; epi.c_map = c_rows; epi.ldc = ldc; epi.bias = bias;
     // small problems: 64 x 64 tiles give 4x the workgroups (K4: [R,512]x[512,256] is only 40 tiles of 128^2)
     long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    static int variant = -1;
-    if (variant < 0) { const char *v = getenv("JLM_GEMM_VARIANT"); variant = v ? atoi(v) : 0; }
-    if (variant == 1) return launch_gemm<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream, 30000);       // 1 block / CU
-    if (variant == 2) return launch_gemm<TileCfg<2, 4, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);  // 8 waves 64x32
-    if (variant == 3) return launch_gemm<TileCfg<4, 2, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);  // 8 waves 32x64
-    if (variant == 11) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 1>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
-    if (variant == 12) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 2>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
-    if (variant == 13) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 3>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
-    if (variant == 14) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 4>(A, B, K, epi, 0, (hipStream_t)stream, 30000);
-    if (variant == 21) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 1>(A, B, K, epi, 0, (hipStream_t)stream);
-    if (variant == 22) return launch_gemm<Cfg128, PlainRows, PlainRows, EpiStore, 2>(A, B, K, epi, 0, (hipStream_t)stream);
-    if (variant == 6) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
-    if (variant == 7) return launch_gemm2<TileCfg<2, 2, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);   // 128 x 64
-    if (variant == 8) return launch_gemm2<TileCfg<2, 2, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);   // 64 x 128
-    if (variant == 9) return launch_gemm2<TileCfg<4, 1, 1, 2>>(A, B, K, epi, 0, (hipStream_t)stream);   // 128 x 64, waves stacked on M
-    if (variant == 10) return launch_gemm2<TileCfg<2, 4, 2, 1>>(A, B, K, epi, 0, (hipStream_t)stream);  // 128 x 128, 8 waves
-    if (gemm_v2_enabled() && variant == 0) {
-        if (tiles128 < 512) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
-        return launch_gemm2<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
-    }
-    if (tiles128 < 512) return launch_gemm<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
-    return launch_gemm<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
+    if (tiles128 < 512) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
+    return launch_gemm2<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
 }
 
 extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, int K, const float *T, int ldt,
@@ -607,8 +423,7 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
     B.base = T; B.map = rows; B.ld = ldt; B.nrows = n_rows_max; B.ndev = n_dev;
     EpiLse epi;
     epi.bias = bias; epi.part = part; epi.ld_part = ld_part; epi.tile0 = tile0;
-    int r = gemm_v2_enabled() ? launch_gemm2<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream)
-                              : launch_gemm<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
+    int r = launch_gemm2<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
     if (r != 0) return r > 0 ? -r : r;
     return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
 }
@@ -625,7 +440,7 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
 // (max, sum) pair per (row, vocabulary range) is written at the very end.
 // One kernel instantiation per number of k-steps NK (its own register budget);
 // the grid of a launch is sized to ONE resident round of workgroups.
-template <int NK, int MT, int ABL = 0>
+template <int NK, int MT>
 __device__ __forceinline__ void lse_stat_body(
     const jlm_segment &sg, const float *__restrict__ bias, int p_in_seg, int parts_in_seg, int pt, int n_paths,
     const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row, float *smem) {
@@ -710,7 +525,6 @@ __device__ __forceinline__ void lse_stat_body(
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 a[0][mt] = *reinterpret_cast<const f32x4 *>(bs + mt * 1024 + (last_k ? qoff_last[0] : qoff[0]));
-            if (ABL == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (last_k && q >= nq_last) break;       // short last k-step (uniform)
@@ -727,19 +541,11 @@ __device__ __forceinline__ void lse_stat_body(
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][e], tf[kt][q][e],
                                                                        (kt == 0 && q == 0 && e == 0) ? zero16 : acc[mt], 0, 0, 0);
             }
-            if (ABL == 2) __builtin_amdgcn_s_setprio(0);
             // bias of the next tile: its global load is waited for together with the DMA at the barrier
             // (a wait placed before the MFMAs would also drain the DMA just issued: vmcnt is in-order)
             if (last_k) bias_stage(t + 1);
             __syncthreads();
             buf ^= 1;
-        }
-        if (ABL == 1) {          // ablation: keep every accumulator live with one add each, skip the fold
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[mt][r];
-            continue;
         }
         // 3. fold this tile's 16*MT base-2 logits of the lane's row into (m, s): branch free,
         //    ~4 VALU + 1 v_exp per logit
@@ -769,7 +575,6 @@ __device__ __forceinline__ void lse_stat_body(
         s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
         m = mn;
     }
-    if (ABL == 1) { m = 0.0f; }
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
     {   // merge the two lane halves (base-2 units), then hand out natural-log units
         const float mm = fmaxf(m, m2);
@@ -789,7 +594,6 @@ struct LseStatArgs {
     short part_first[JLM_MAX_SEGMENTS + 1];     // ranges [part_first[i], part_first[i+1]) belong to segment i
 };
 
-template <int ABL>
 __global__ __launch_bounds__(256, 2) void vocab_lse_stationary_kernel(LseStatArgs a, const float *__restrict__ T, int ldt,
                                                                        const int *__restrict__ rows, float2 *__restrict__ part,
                                                                        int ld_part, int n_rows_max, const int *n_dev,
@@ -812,13 +616,13 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_stationary_kernel(LseStatArg
     float2 *prow = part + (size_t)p * ld_part;
     switch ((sg.k + BK - 1) / BK) {
         case 1:
-        case 2: lse_stat_body<2, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        case 3: lse_stat_body<3, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        case 4: lse_stat_body<4, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        case 5: lse_stat_body<5, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        case 6: lse_stat_body<6, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        case 7: lse_stat_body<7, 4, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
-        default: lse_stat_body<8, 2, ABL>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 2: lse_stat_body<2, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 3: lse_stat_body<3, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 4: lse_stat_body<4, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 5: lse_stat_body<5, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 6: lse_stat_body<6, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        case 7: lse_stat_body<7, 4>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
+        default: lse_stat_body<8, 2>(sg, bias, pis, npis, pt, n_paths, T, ldt, rows, prow, smem); break;
     }
 }
 
@@ -842,8 +646,6 @@ extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs
         work[i] = (long)(sg.v_end - sg.v_start) * ((sg.k + 7) / 8);          // MFMA quads actually issued
         total += work[i];
     }
-    static int abl = -1;
-    if (abl < 0) { const char *e = getenv("JLM_LSE_ABL"); abl = e ? atoi(e) : 0; }
     const int n_ptiles = (n_rows_max + 127) / 128;
     int cap = max_parts < LSES_MAX_PARTS ? max_parts : LSES_MAX_PARTS;
     if (cap < n_segs) return -1;
@@ -875,15 +677,8 @@ extern "C" int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs
     const int lds = (2 * 128 * 32 + 3 * 128) * 4;
     const int grid = given * n_ptiles;
     hipStream_t st = (hipStream_t)stream;
-    if (abl == 1)
-        hipLaunchKernelGGL(vocab_lse_stationary_kernel<1>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
-    else if (abl == 2)
-        hipLaunchKernelGGL(vocab_lse_stationary_kernel<2>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
-    else
-        hipLaunchKernelGGL(vocab_lse_stationary_kernel<0>, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipLaunchKernelGGL(vocab_lse_stationary_kernel, dim3(grid), dim3(256), lds, st, a, T, ldt, rows,
+                       reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return given;

@@ -110,13 +110,7 @@ def bench_gemm(M, N, K, tag):
 
 
 if __name__ == "__main__":
-    print(torch.cuda.get_device_name(0), "variant", os.environ.get("JLM_GEMM_VARIANT"))
-    if flt == "variants":
-        flt = ""
-        bench_gemm(4096, 4096, 4096, "square")
-        bench_gemm(2560, 8192, 256, "lse-like")
-        bench_gemm(2560, 2048, 736, "gate-like")
-        sys.exit(0)
+    print(torch.cuda.get_device_name(0))
     for R in (2560,):
         bench_gate(512, 200, R)
         bench_gate(512, 256, R)
