@@ -143,3 +143,38 @@ def test_full_size_properties(fixture, kind, kwargs, n, beam, fx):
     for si in (0, n // 2, n - 1)[: (2 if fixture == "big-tied" else 3)]:
         want = o.decode(sents[si], beam_width=beam, **kwargs)
         _check_nbest(out[si], want, (fixture, si), strict_nbest=False)
+
+
+@pytest.mark.parametrize("case", [c for c in gc.DECODE_CASES if c[0] in (
+    "small-tied/static", "small-vtable/static-vs", "small-tied/dynamic", "small-tied-sn/dynamic", "mid-tied/static",
+    "mid-tied/dynamic", "mid-vtable/static")], ids=lambda c: c[0])
+def test_per_frame_beams_match_reference_traces(case, fx, golden_decode):
+    """Not only the final n-best: every frame's surviving hypotheses (score, last node's start
+    frame and softmax row, path length) equal what the reference's Path objects held."""
+    name, fixture, kind, kwargs, spec = case
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    sents = gc.case_sentences(spec, f["alphabet"])
+    gold = golden_decode[name]
+    n = sum(1 for g in gold if "trace" in g)
+    dec.decode_batch(sents[:n], **kwargs)
+    p = dec._engine.last_state
+    lat = dec.last_lattice
+    B, beam, rmax = lat.n_sent, lat.beam, lat.n_sent * lat.beam
+    score, bp, node, cnt = (getattr(p, k).cpu().numpy() for k in ("score", "bp", "node", "cnt"))
+    for s in range(n):
+        trace = gold[s]["trace"]
+        assert len(trace) == len(sents[s]) + 1
+        for fr, want in enumerate(trace):
+            k = int(cnt[fr * B + s])
+            assert k == len(want), (name, s, fr)
+            g0 = fr * rmax + s * beam
+            for r, (w_score, w_start, w_word, w_len) in enumerate(want):
+                g = g0 + r
+                nd = int(node[g])
+                assert int(lat.node_start[nd]) == w_start and int(lat.node_word[nd]) == w_word, (name, s, fr, r)
+                depth, q = 0, g
+                while q >= 0:
+                    depth, q = depth + 1, int(bp[q])
+                assert depth == w_len
+                assert abs(score[g] - w_score) <= 1e-5 * abs(w_score) + 1e-3, (name, s, fr, r, score[g], w_score)
