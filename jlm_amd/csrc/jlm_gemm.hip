@@ -146,42 +146,48 @@ struct EpiGate {
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
                         int M, int, float *smem) const {
-        static_assert(Cfg::BM == 64 && Cfg::BN == 64 && Cfg::MT == 1 && Cfg::NT == 1 && Cfg::NTHREADS == 256,
-                      "gate epilogue is written for the 64 x 64 tile");
-        float *ct = smem;                      // [64][GATE_CT_LD]
+        static_assert(Cfg::BN == 64 && Cfg::NT == 1 && Cfg::WAVES_N == 2 && Cfg::NTHREADS == 256,
+                      "gate epilogue: 64 columns = 4 gates x 16 units per tile");
+        float *ct = smem;                      // [BM][GATE_CT_LD]
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[0][0][reg];
-        }
+        for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[mt][0][reg];
+            }
         __syncthreads();
         const int tid = threadIdx.x;
-        const int r = tid >> 2, uq = (tid & 3) * 4;
-        const int row = m0 + r;
-        if (row >= M) return;
-        const int g = rows ? rows[row] : row;
-        const int p = prev[g];
+        const int uq = (tid & 3) * 4;
         const int u0 = (n0 >> 2) + uq;
-        const f32x4 zi = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + uq) +
-                         *reinterpret_cast<const f32x4 *>(bias + n0 + uq);
-        const f32x4 zf = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 16 + uq) +
-                         *reinterpret_cast<const f32x4 *>(bias + n0 + 16 + uq);
-        const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 32 + uq) +
-                         *reinterpret_cast<const f32x4 *>(bias + n0 + 32 + uq);
-        const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 48 + uq) +
-                         *reinterpret_cast<const f32x4 *>(bias + n0 + 48 + uq);
-        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-        if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
-        f32x4 cn, hn;
+        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n0 + uq);
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(bias + n0 + 16 + uq);
+        const f32x4 bo = *reinterpret_cast<const f32x4 *>(bias + n0 + 32 + uq);
+        const f32x4 bg = *reinterpret_cast<const f32x4 *>(bias + n0 + 48 + uq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid(zi[e]), gf = jlm_sigmoid(zf[e]), go = jlm_sigmoid(zo[e]);
-            const float gg = tanhf(zg[e]);
-            cn[e] = cp[e] * gf + gg * gi;
-            hn[e] = tanhf(cn[e]) * go;
+        for (int it = 0; it < Cfg::BM / 64; ++it) {
+            const int r = (tid >> 2) + it * 64;
+            const int row = m0 + r;
+            if (row >= M) continue;
+            const int g = rows ? rows[row] : row;
+            const int p = prev[g];
+            const f32x4 zi = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + uq) + bi;
+            const f32x4 zf = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 16 + uq) + bf;
+            const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 32 + uq) + bo;
+            const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 48 + uq) + bg;
+            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+            if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
+            f32x4 cn, hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = jlm_sigmoid(zi[e]), gf = jlm_sigmoid(zf[e]), go = jlm_sigmoid(zo[e]);
+                const float gg = tanhf(zg[e]);
+                cn[e] = cp[e] * gf + gg * gi;
+                hn[e] = tanhf(cn[e]) * go;
+            }
+            *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
+            *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
         }
-        *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
-        *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
     }
 };
 
@@ -396,6 +402,9 @@ extern "C" int jlm_lstm_step(const float *h_in, const float *c_in, int ld_state,
     epi.rows = rows; epi.prev = prev; epi.bias = bias;
     // K = H + E: chunks past it are zero filled, the packed weights are zero padded
     const int tiles_n = 4 * H / Cfg64::BN;
+    // 64 x 64 tiles balance the CUs at a few thousand rows (1 280 workgroups = 5 per CU at R = 2 560);
+    // from ~8 k rows on the balance is given and 128 x 64 tiles (fewer barriers per MFMA) are 4 % faster
+    if (n_rows_max >= 8192) return launch_gemm2<TileCfg<2, 2, 2, 1>>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
     return launch_gemm2<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
 }
 
