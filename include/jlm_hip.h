@@ -117,6 +117,32 @@ int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs, const flo
                              float *part, int ld_part, int max_parts,
                              int n_rows_max, const int *n_dev, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Split-f16 ("f16x3") operands.  The f32 matrix pipe of gfx950 runs at 1/16 of
+ * the f16 rate; these entry points carry every f32 value x as two f16 halves
+ *   x * scale = hi + lo (+ r, |r| <= 2^-22 |x * scale|)
+ * and form a product as hi.hi + hi.lo + lo.hi in three f16 MFMAs with f32
+ * accumulation -- f32-grade results (error pinned in tests/test_gpu_kernels.py)
+ * at 16/3 of the f32 MFMA rate.  "Split rows": a row of k values, k padded with
+ * zeros to a multiple of 16, stored as k/8 blocks of [8 x f16 hi][8 x f16 lo]
+ * (4 bytes per value, row stride ld_dst in 4-byte units, a multiple of 16).
+ * scale must be a power of two (so that dividing it out again is exact) chosen
+ * so that max|x| * scale stays below 65504. */
+int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale,
+                       void *dst, int ld_dst, void *stream);
+
+/* jlm_vocab_lse_stationary on split rows: segs[i].B = split rows of the
+ * segment's output embedding scaled by 2^eB_i, segs[i].ldb their stride in
+ * 4-byte units, segs[i].k the true contraction length (<= 256, multiple of 4).
+ * T is plain f32 (the kernel splits its rows while loading them, after scaling
+ * by t_scale[i] = 2^eT_i); descale[i] = 2^-(eT_i + eB_i).  Same partial-slice
+ * contract and return value as jlm_vocab_lse_stationary. */
+int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale,
+                        int n_segs, const float *b2,
+                        const float *T, int ldt, const int *rows,
+                        float *part, int ld_part, int max_parts,
+                        int n_rows_max, const int *n_dev, void *stream);
+
 /* Word-list groups: one per (sentence, frame).  Group j covers hypothesis rows
  * g0[j] .. g0[j]+cnt[cnt_idx[j]]-1 and the word list number l = wl_base +
  * wl_idx[j], i.e. words wl[wl_off[l] .. wl_off[l+1]). */

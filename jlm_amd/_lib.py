@@ -42,6 +42,9 @@ _SIGS = {
     "jlm_vocab_lse_partials": ([P, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_lse_combine": ([P, c_int, c_int, P, P, c_int, P, P], c_int),
     "jlm_vocab_lse_stationary": ([POINTER(Segment), c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
+    "jlm_pack_split_f16": ([P, c_int, c_int, c_int, c_float, P, c_int, P], c_int),
+    "jlm_vocab_lse_split": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), c_int, P, P, c_int, P, P, c_int, c_int,
+                             c_int, P, P], c_int),
     "jlm_edge_logits": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
     "jlm_wordlist_lse": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
                          c_int),

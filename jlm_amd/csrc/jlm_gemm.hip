@@ -449,6 +449,33 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
 // (max, sum) pair per (row, vocabulary range) is written at the very end.
 // One kernel instantiation per number of k-steps NK (its own register budget);
 // the grid of a launch is sized to ONE resident round of workgroups.
+// Cycle accounting of the kernel below (tools/lse_profile.sh builds a -DJLM_PROFILE copy of the
+// library; the shipped build has none of it): per wave, cycles in the prologue (T fragments), waiting
+// at the k-step barrier (skew + DMA landing), in the fold, and in total.
+#ifdef JLM_PROFILE
+__device__ unsigned long long jlm_prof[8];
+extern "C" int jlm_prof_read(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof), sizeof(jlm_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(jlm_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define JLM_PROF_DECL() unsigned long long p_t0 = clock64(), p_t1 = 0, p_t2 = 0, p_x = 0, p_bar = 0, p_fold = 0
+#define JLM_PROF_MARK(v) v = clock64()
+#define JLM_PROF_ADD(acc_, since) acc_ += clock64() - since
+#define JLM_PROF_FLUSH()                                                                   \
+    if ((threadIdx.x & 63) == 0) {                                                         \
+        const unsigned long long now = clock64();                                          \
+        atomicAdd(&jlm_prof[0], now - p_t0); atomicAdd(&jlm_prof[1], p_t1 - p_t0);         \
+        atomicAdd(&jlm_prof[2], p_t2 - p_t1); atomicAdd(&jlm_prof[3], p_bar);              \
+        atomicAdd(&jlm_prof[4], p_fold); atomicAdd(&jlm_prof[5], 1ull);                    \
+    }
+#else
+#define JLM_PROF_DECL() (void)0
+#define JLM_PROF_MARK(v) (void)0
+#define JLM_PROF_ADD(acc_, since) (void)0
+#define JLM_PROF_FLUSH() (void)0
+#endif
+
 template <int NK, int MT>
 __device__ __forceinline__ void lse_stat_body(
     const jlm_segment &sg, const float *__restrict__ bias, int p_in_seg, int parts_in_seg, int pt, int n_paths,
@@ -456,6 +483,7 @@ __device__ __forceinline__ void lse_stat_body(
     constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
     constexpr int NINST = BMV / 32;                // LDS-DMA instructions per wave per k-step (8 rows each, 4 waves)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    JLM_PROF_DECL();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
@@ -519,9 +547,11 @@ __device__ __forceinline__ void lse_stat_body(
         qoff[q] = li * 32 + (((h * 4 + q) ^ ((li >> 1) & 7)) * 4);
         qoff_last[q] = li * 32 + ((((h * nq_last + q) & 7) ^ ((li >> 1) & 7)) * 4);
     }
+    JLM_PROF_MARK(p_t1);
     issue(vt0, 0, 0);
     bias_stage(vt0);
     __syncthreads();
+    JLM_PROF_MARK(p_t2);
     int buf = 0;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = vt0; t < vt1; ++t) {
@@ -553,9 +583,12 @@ __device__ __forceinline__ void lse_stat_body(
             // bias of the next tile: its global load is waited for together with the DMA at the barrier
             // (a wait placed before the MFMAs would also drain the DMA just issued: vmcnt is in-order)
             if (last_k) bias_stage(t + 1);
+            JLM_PROF_MARK(p_x);
             __syncthreads();
+            JLM_PROF_ADD(p_bar, p_x);
             buf ^= 1;
         }
+        JLM_PROF_MARK(p_x);
         // 3. fold this tile's 16*MT base-2 logits of the lane's row into (m, s): branch free,
         //    ~4 VALU + 1 v_exp per logit
         const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
@@ -583,7 +616,9 @@ __device__ __forceinline__ void lse_stat_body(
             }
         s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
         m = mn;
+        JLM_PROF_ADD(p_fold, p_x);
     }
+    JLM_PROF_FLUSH();
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
     {   // merge the two lane halves (base-2 units), then hand out natural-log units
         const float mm = fmaxf(m, m2);

@@ -1,0 +1,353 @@
+// Split-f16 ("f16x3") matrix kernels for gfx950.
+//
+// The f32 matrix pipe of CDNA4 runs at the f32 VECTOR rate (v_mfma_f32_32x32x2_f32: 64 cycles per
+// instruction and SIMD, 1/16 of the f16 rate) and a kernel that keeps it >90 % busy is clocked down
+// by the power governor (measured: tools/lse_profile.py).  The kernels here get f32-grade products
+// out of the f16 pipe instead: every f32 operand x is carried as two halves
+//     x * 2^e = hi + lo + r,   hi = f16(x 2^e),  lo = f16(x 2^e - hi),  |r| <= 2^-22 |x 2^e|
+// (e = a per-matrix power of two that keeps hi inside the f16 range and lo out of the subnormals)
+// and a product a.b is formed as  hi_a hi_b + hi_a lo_b + lo_a hi_b  in THREE
+// v_mfma_f32_32x32x16_f16 instructions accumulating in f32: 3 x 32 cycles per 32x32x16 block instead of
+// 8 x 64.  Every partial product of two f16 values is exact in f32; what is dropped
+// (lo_a lo_b, hi r, r hi) is <= 3 x 2^-22 |a b| per term, the size of one f32 rounding step of the
+// accumulation itself.  tests/test_gpu_kernels.py pins the error against an f64 evaluation next to
+// that of the plain f32 kernels.
+//
+// Packed operand layout ("split rows"): a row of K values (K padded to a multiple of 16) is stored
+// as K/8 blocks of 32 bytes: [8 x f16 hi][8 x f16 lo] -- the same bytes per element as f32, and one
+// 16-byte granule = one MFMA operand (8 consecutive k of one plane) for the LDS-DMA.
+#include "jlm_common.h"
+#include <stdlib.h>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define GLDS16(gp, lp)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
+                                     (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
+
+// hi/lo of x * scale.  The scaled value is pinned in a register before it is converted: left to
+// itself the compiler folds the multiply into ONE of the two uses of the conversion (v_fma_mix*,
+// single rounding from the exact product) and not into the other, and hi and lo then disagree about
+// what hi is whenever the f32 product sits on an f16 rounding tie -- a 2^-11 error in that element
+// (tools/probes/split_debug2.py finds them).
+__device__ __forceinline__ void split8(const float *x, float scale, f16x8 &hi, f16x8 &lo) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = x[i] * scale;
+        asm volatile("" : "+v"(v));
+        _Float16 h = (_Float16)v;
+        asm volatile("" : "+v"(h));
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 [rows, k] (ld) -> split rows [rows, ld_dst] (ld_dst in 4-byte units, >= k rounded up to 16).
+__global__ void pack_split_kernel(const float *__restrict__ src, int rows, int k, int ld, float scale,
+                                  float *__restrict__ dst, int ld_dst) {
+    const int nblk = ld_dst / 8;                       // 8-value blocks per destination row
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * nblk) return;
+    const int r = (int)(i / nblk), kb = (int)(i % nblk);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (kb * 8 + j < k) ? src[(size_t)r * ld + kb * 8 + j] : 0.0f;
+    f16x8 hi, lo;
+    split8(x, scale, hi, lo);
+    f16x8 *d = reinterpret_cast<f16x8 *>(dst + (size_t)r * ld_dst + kb * 8);
+    d[0] = hi;
+    d[1] = lo;
+}
+
+extern "C" int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale, void *dst, int ld_dst,
+                                  void *stream) {
+    if (rows < 0 || k <= 0 || ld < k || ld_dst % 16 || ld_dst < k) return -1;
+    if (rows == 0) return 0;
+    const long n = (long)rows * (ld_dst / 8);
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k,
+                       ld, scale, reinterpret_cast<float *>(dst), ld_dst);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rows-stationary vocabulary log-sum-exp, split-f16 form.  Same structure as
+// vocab_lse_stationary_kernel (jlm_gemm.hip): a workgroup keeps 128 hypothesis rows' operands in
+// registers (32 rows per wave, both planes, the whole contraction) and streams a range of
+// vocabulary tiles (32*MT rows) past them; per row and range one (max, sum exp) partial.
+//
+// NS = k-steps of 16 the contraction is split into (k <= 16 NS); a tile is consumed in
+// NC = ceil(NS / 4) chunks of <= 4 steps (64 k-values, 256 bytes per vocabulary row), one workgroup
+// barrier per chunk.  LDS tile: [32*MT rows][16 granules of 16 B]; granule g of a chunk =
+// (step g >> 2, lane half (g >> 1) & 1, plane g & 1); stored at g ^ (row & 15) -- the XOR is applied
+// to the SOURCE address of the lane-linear LDS-DMA -- so that the 16 lanes a ds_read_b128 serves
+// together hit 16 distinct granules of the 256-byte bank line.
+template <int NS>
+struct SplitChunks {
+    static constexpr int NC = (NS + 3) / 4;
+    static constexpr int size(int c) { return NS / NC + (c < NS % NC ? 1 : 0); }
+    static constexpr int start(int c) { return c * (NS / NC) + (c < NS % NC ? c : NS % NC); }
+};
+
+struct LseSplitArgs {
+    int n_parts, n_segs;
+    jlm_segment seg[JLM_MAX_SEGMENTS];          // B = split rows, ldb in 4-byte units
+    const float *bias[JLM_MAX_SEGMENTS];
+    float t_scale[JLM_MAX_SEGMENTS];            // log2(e) * 2^eT: applied to T before it is split
+    float descale[JLM_MAX_SEGMENTS];            // 2^-(eT + eB): accumulator -> base-2 logit
+    short part_first[JLM_MAX_SEGMENTS + 1];
+};
+
+template <int NS, int MT>
+__device__ __forceinline__ void lse_split_body(
+    const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int p_in_seg, int parts_in_seg, int pt,
+    int n_paths, const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row,
+    float *smem) {
+    using CH = SplitChunks<NS>;
+    constexpr int NC = CH::NC;
+    constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
+    constexpr int NINST = BMV / 16;                // LDS-DMA instructions per wave per chunk (4 rows each, 4 waves)
+    constexpr int MP = MT / 2;                     // fragment units (pairs of 32-row blocks) per k-step
+    constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
+    const int ns_rt = (K + 15) >> 4;               // steps that hold data (<= NS); the rest are skipped
+    const int ntiles = (n_vocab + BMV - 1) / BMV;
+    const int vt0 = (int)((long)ntiles * p_in_seg / parts_in_seg), vt1 = (int)((long)ntiles * (p_in_seg + 1) / parts_in_seg);
+    const float *__restrict__ Bp = sg.B;
+    // 1. this lane's row operands: for step s the lane half h owns k = 16 s + 8 h .. + 7, both planes
+    const int prow = pt * 128 + wave * 32 + li;
+    const bool row_ok = prow < n_paths;
+    const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
+    f16x8 thi[NS], tlo[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k0 = 16 * s + 8 * h;
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = k0 + 4 * q;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && k < K) ? v[e] : 0.0f;
+        }
+        split8(x, t_scale, thi[s], tlo[s]);
+    }
+    float *Bs = smem;                              // [2][BMV][64]
+    float *bias_s = smem + 2 * BMV * 64;           // [3][BMV], base-2 units
+    // LDS-DMA: one wave instruction fills 4 tile rows x 16 granules, lane-linear.  Source of lane
+    // (row r, slot) = granule g = slot ^ (r & 15) of that row.  Nothing is masked: rows past the
+    // segment re-read its last row (their bias is -3e38), granules past the chunk / the padded row
+    // re-read the row's last granule (no fragment read ever touches them).
+    const int lrow = lane >> 4, pslot = lane & 15;
+    const int dma_r0 = wave * NINST * 4 + lrow;    // instruction i fills rows dma_r0 + 4 i ...
+    const int dma_g0 = pslot ^ lrow;               // ... with granule dma_g0 ^ (4 (i & 3)) in this lane's slot
+    auto issue = [&](int t, int c_start, int buf) {   // chunk = steps [c_start, ...)
+        int r0 = dma_r0, g0 = dma_g0;
+        asm volatile("" : "+v"(r0), "+v"(g0));     // keep per-instruction offsets out of the loop-invariant registers
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) {
+            const int vrow = min(t * BMV + r0 + 4 * i, n_vocab - 1);
+            const int koff = min(c_start * 16 + ((g0 ^ (4 * (i & 3))) << 2), ldb - 4);
+            GLDS16(Bp + ((size_t)vrow * ldb + koff), Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+        }
+    };
+    auto bias_stage = [&](int t) {
+        if (tid < BMV) {
+            const int vrow = t * BMV + tid;
+            bias_s[((t - vt0) % 3) * BMV + tid] = vrow < n_vocab ? bias[vrow] * LOG2E : JLM_NEG_BIG;
+        }
+    };
+    float m = JLM_NEG_BIG, s = 0.0f;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    // fragment offsets (floats) inside a tile for step-in-chunk j, plane p: granule 4 j + 2 h + p of row li (+32 mt)
+    int goff[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) goff[j][p] = li * 64 + (((4 * j + 2 * h + p) ^ (li & 15)) * 4);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    issue(vt0, 0, 0);
+    bias_stage(vt0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = vt0; t < vt1; ++t) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool last_c = (c == NC - 1);
+            if (last_c) issue(t + 1, 0, buf ^ 1);                    // past the range: harmless (next range / last row)
+            else issue(t, CH::start(c + 1 < NC ? c + 1 : 0), buf ^ 1);
+            const float *bs = Bs + buf * BMV * 64;
+            // units u = (step j, block pair mp), fragments read one unit ahead of the MFMAs
+            constexpr int NU = 4 * MP;             // upper bound; units past the chunk's size are compiled out below
+            f16x8 a[2][2][2];                      // [unit parity][block of the pair][plane]
+            const int csz = CH::size(c), cst = CH::start(c);
+            auto load_unit = [&](int u, int par) {
+                const int j = u / MP, mp = u % MP;
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        a[par][b2][p] = *reinterpret_cast<const f16x8 *>(bs + (2 * mp + b2) * 32 * 64 + goff[j][p]);
+            };
+            if (cst < ns_rt) load_unit(0, 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int j = u / MP, mp = u % MP;
+                if (j >= csz) break;               // compile-time bound of this chunk
+                if (cst + j >= ns_rt) break;       // padded steps hold nothing (uniform)
+                if (u + 1 < NU && (u + 1) / MP < csz && cst + (u + 1) / MP < ns_rt) load_unit(u + 1, (u + 1) & 1);
+                const int st = cst + j;            // compile-time after unrolling (register index)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int mt = 2 * mp + b2;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][1], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], tlo[st], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], thi[st], acc[mt], 0, 0, 0);
+                }
+            }
+            if (last_c) bias_stage(t + 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // fold this tile's 16*MT logits of the lane's row into (m, s), base-2 units
+        const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
+        float tmax = JLM_NEG_BIG;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + mt * 32 + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaf(acc[mt][4 * j + e], descale, b4[e]);
+                    acc[mt][4 * j + e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            }
+        const float mn = fmaxf(m, tmax);
+        float add0 = 0.0f, add1 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                add0 += __builtin_amdgcn_exp2f(acc[mt][r] - mn);
+                add1 += __builtin_amdgcn_exp2f(acc[mt][r + 1] - mn);
+            }
+        s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
+        m = mn;
+    }
+    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+    {
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm * LN2;
+    }
+    if (h == 0 && row_ok) part_row[prow] = make_float2(m, s);
+}
+
+#define LSES_MAX_PARTS 96
+
+__global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a, const float *__restrict__ T, int ldt,
+                                                                  const int *__restrict__ rows, float2 *__restrict__ part,
+                                                                  int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    // XCD-aware order, as in vocab_lse_stationary_kernel: with n_parts a multiple of 8 one XCD walks
+    // all row tiles of its vocabulary ranges, which stay in its L2
+    const int b = blockIdx.x;
+    int p, pt;
+    if ((a.n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { p = b / n_ptiles; pt = b % n_ptiles; }
+    if (p >= a.n_parts || pt * 128 >= n_paths) return;
+    int si = 0;
+    while (si + 1 < a.n_segs && p >= a.part_first[si + 1]) ++si;
+    const jlm_segment sg = a.seg[si];
+    const float *bias = a.bias[si];
+    const float ts = a.t_scale[si], ds = a.descale[si];
+    const int pis = p - a.part_first[si], npis = a.part_first[si + 1] - a.part_first[si];
+    float2 *prow = part + (size_t)p * ld_part;
+    const int ns = (sg.k + 15) >> 4;
+    if (ns <= 2) lse_split_body<2, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+    else if (ns <= 4) lse_split_body<4, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+    else if (ns <= 7) lse_split_body<7, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+    else if (ns <= 10) lse_split_body<10, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+    else if (ns <= 13) lse_split_body<13, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+    else lse_split_body<16, 2>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+}
+
+// Host side: ranges per segment in proportion to their cost, one resident round of workgroups.
+// Returns the number of partial slices written (fold them with jlm_lse_combine), or <0.
+extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale, int n_segs,
+                                   const float *b2, const float *T, int ldt, const int *rows, float *part, int ld_part,
+                                   int max_parts, int n_rows_max, const int *n_dev, void *stream) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
+    LseSplitArgs a;
+    a.n_segs = n_segs;
+    long work[JLM_MAX_SEGMENTS], total = 0;
+    int ntiles[JLM_MAX_SEGMENTS];
+    for (int i = 0; i < n_segs; ++i) {
+        const jlm_segment &sg = segs_host[i];
+        const int ns = (sg.k + 15) / 16;
+        if (ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4) return -2;
+        a.seg[i] = sg;
+        a.bias[i] = b2 + sg.v_start;
+        a.t_scale[i] = t_scale[i] * 1.4426950408889634f;
+        a.descale[i] = descale[i];
+        const int bmv = ns > 13 ? 64 : 128;
+        ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
+        // cycles per vocabulary row and SIMD: matrix pipe 2 waves x 3 ns, or the fold's VALU work
+        // (2 waves x ~17) when that is longer, plus the per-chunk barrier
+        const int mf = 6 * ns, fold = 34;
+        work[i] = (long)(sg.v_end - sg.v_start) * ((mf > fold ? mf : fold) + 3 * ((ns + 3) / 4));
+        total += work[i];
+    }
+    const int n_ptiles = (n_rows_max + 127) / 128;
+    int cap = max_parts < LSES_MAX_PARTS ? max_parts : LSES_MAX_PARTS;
+    if (cap < n_segs) return -1;
+    int np = (2 * 256) / n_ptiles;                 // one resident round: 2 workgroups per CU
+    if (np < n_segs) np = n_segs;
+    if (np > cap) np = cap;
+    if (np >= 8) np &= ~7;
+    if (np < n_segs) np = n_segs;
+    int given = 0, k[JLM_MAX_SEGMENTS];
+    for (int i = 0; i < n_segs; ++i) {
+        k[i] = (int)((work[i] * np + total / 2) / total);
+        if (k[i] < 1) k[i] = 1;
+        if (k[i] > ntiles[i]) k[i] = ntiles[i];
+        given += k[i];
+    }
+    for (int guard = 0; given != np && guard < 4 * LSES_MAX_PARTS; ++guard) {
+        int best = -1;
+        for (int i = 0; i < n_segs; ++i) {
+            if (given < np) { if (k[i] < ntiles[i] && (best < 0 || work[i] * k[best] > work[best] * k[i])) best = i; }
+            else { if (k[i] > 1 && (best < 0 || work[i] * k[best] < work[best] * k[i])) best = i; }
+        }
+        if (best < 0) break;
+        if (given < np) { ++k[best]; ++given; } else { --k[best]; --given; }
+    }
+    a.part_first[0] = 0;
+    for (int i = 0; i < n_segs; ++i) a.part_first[i + 1] = (short)(a.part_first[i] + k[i]);
+    a.n_parts = given;
+    const int lds = (2 * 128 * 64 + 3 * 128) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    const int grid = given * n_ptiles;
+    hipLaunchKernelGGL(vocab_lse_split_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, T, ldt, rows,
+                       reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e - 100;
+    return given;
+}

@@ -139,6 +139,47 @@ class FakeLib:
             pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
         return n_segs
 
+    def jlm_pack_split_f16(self, src, rows, k, ld, scale, dst, ld_dst, stream):
+        """split rows: per 8 values [8 x f16 hi][8 x f16 lo] (include/jlm_hip.h)"""
+        if rows < 0 or k <= 0 or ld < k or ld_dst % 16 or ld_dst < k:
+            return -1
+        if rows == 0:
+            return 0
+        x = np.zeros((rows, ld_dst), dtype=np.float32)
+        x[:, :k] = view(src, rows * ld, np.float32).reshape(rows, ld)[:, :k]
+        x *= np.float32(scale)
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        out = view(dst, rows * ld_dst * 2, np.float16).reshape(rows, ld_dst // 8, 2, 8)
+        out[:, :, 0, :] = hi.reshape(rows, ld_dst // 8, 8)
+        out[:, :, 1, :] = lo.reshape(rows, ld_dst // 8, 8)
+        return 0
+
+    def jlm_vocab_lse_split(self, segs, t_scale, descale, n_segs, b2, T, ldt, rows, part, ld_part, max_parts, n_rows_max,
+                            n_dev, stream):
+        """Contract of jlm_vocab_lse_stationary, operands read from split rows."""
+        if n_segs > max_parts:
+            return -1
+        n = _n(n_rows_max, n_dev)
+        pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
+        if n == 0:
+            return n_segs
+        g = _rows(rows, n)
+        for i in range(n_segs):
+            sg = segs[i]
+            if sg.k > 256 or sg.ldb % 16:
+                return -2
+            nv = sg.v_end - sg.v_start
+            Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g]).astype(np.float64)
+            sp = view(sg.B, nv * sg.ldb * 2, np.float16).reshape(nv, sg.ldb // 8, 2, 8).astype(np.float64)
+            Bv = (sp[:, :, 0, :] + sp[:, :, 1, :]).reshape(nv, sg.ldb)[:, :sg.k]
+            y = ((Tv * float(t_scale[i])) @ Bv.T * float(descale[i])).astype(np.float32) \
+                + view(_p(b2) + 4 * sg.v_start, nv, np.float32)
+            mx = y.max(axis=1)
+            pv[i, :n, 0] = mx
+            pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
+        return n_segs
+
     def jlm_lse_combine(self, part, ld_part, n_tiles, rows, lse, n_rows_max, n_dev, stream):
         n = _n(n_rows_max, n_dev)
         if n == 0:

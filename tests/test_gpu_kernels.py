@@ -168,6 +168,74 @@ def test_vocab_lse_stationary(L, V, widths, R):
                                       partg.data_ptr(), R, 0, R, ndg.data_ptr(), _st()) < 0
 
 
+def _split_segments(L, segs_g, keep_g, n, scale_exp):
+    """split-row copies of the gpu segments' matrices -> (Segment array, t_scale, descale, keepalive)"""
+    import ctypes
+    out = (_lib.Segment * n)()
+    ts, ds, keep = (ctypes.c_float * n)(), (ctypes.c_float * n)(), []
+    for i in range(n):
+        sg = segs_g[i]
+        nv, kp = sg.v_end - sg.v_start, (sg.k + 15) // 16 * 16
+        dst = torch.zeros((nv, kp), dtype=torch.float32, device="cuda")
+        assert L.jlm_pack_split_f16(sg.B, nv, sg.k, sg.ldb, float(2.0 ** scale_exp[i]), dst.data_ptr(), kp, _st()) == 0
+        keep.append(dst)
+        out[i] = _lib.Segment(sg.v_start, sg.v_end, sg.k, sg.t_off, dst.data_ptr(), kp)
+        ts[i] = 2.0 ** 3
+        ds[i] = 2.0 ** -(3 + scale_exp[i])
+    return out, ts, ds, keep
+
+
+@pytest.mark.parametrize("V,widths,R", [(2000, [32], 10), (3000, [32, 16, 8], 300), (50000, [200, 100, 52], 2560),
+                                        (50000, [256], 1000), (700, [100], 129), (5000, [8, 256, 40], 64),
+                                        (4000, [160, 112, 64], 200)])
+def test_vocab_lse_split(L, V, widths, R):
+    """split-f16 form of the rows-stationary LSE: same contract; its error against an f64
+    evaluation of the same f32 operands must be of the size of the plain f32 kernel's"""
+    rng = np.random.default_rng(V + R + len(widths))
+    segs_c, segs_g, keep, ldt = _segments(rng, V, widths, ldt_extra=8)
+    G = R + 50
+    T, Tg = _pair(rng.standard_normal((G, ldt)).astype(np.float32))
+    b2, b2g = _pair(rng.standard_normal(V).astype(np.float32))
+    rows, rowsg = _pair(rng.permutation(G)[:R].astype(np.int32))
+    nd, ndg = _pair(np.array([R - 1], dtype=np.int32))
+    maxp = 96
+    partg = torch.zeros((maxp, R, 2), dtype=torch.float32, device="cuda")
+    lse64 = np.zeros(G)
+    n = R - 1
+    ys = []
+    for i in range(len(widths)):                 # f64 reference straight from the f32 operands
+        sg = segs_c[i]
+        nv = sg.v_end - sg.v_start
+        Bv = FK_view(sg.B, nv * sg.ldb).reshape(nv, sg.ldb)[:, :sg.k].astype(np.float64)
+        Tv = T.numpy()[rows.numpy()[:n], sg.t_off:sg.t_off + sg.k].astype(np.float64)
+        ys.append(Tv @ Bv.T + b2.numpy()[sg.v_start:sg.v_end].astype(np.float64))
+    y = np.concatenate(ys, axis=1)
+    mx = y.max(axis=1)
+    ref = mx + np.log(np.exp(y - mx[:, None]).sum(axis=1))
+    errs = {}
+    for name in ("f32", "f16x3"):
+        lseg = torch.zeros(G, dtype=torch.float64, device="cuda")
+        if name == "f32":
+            n1 = L.jlm_vocab_lse_stationary(segs_g, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
+                                            partg.data_ptr(), R, maxp, R, ndg.data_ptr(), _st())
+        else:
+            sp, ts, ds, keep2 = _split_segments(L, segs_g, keep, len(widths), [6] * len(widths))
+            n1 = L.jlm_vocab_lse_split(sp, ts, ds, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
+                                       partg.data_ptr(), R, maxp, R, ndg.data_ptr(), _st())
+        assert len(widths) <= n1 <= maxp, n1
+        assert L.jlm_lse_combine(partg.data_ptr(), R, n1, rowsg.data_ptr(), lseg.data_ptr(), R, ndg.data_ptr(), _st()) == 0
+        torch.cuda.synchronize()
+        errs[name] = np.abs(lseg.cpu().numpy()[rows.numpy()[:n]] - ref).max()
+    print("max |lse - f64|: f32 MFMA %.3g, split f16 %.3g" % (errs["f32"], errs["f16x3"]))
+    assert errs["f16x3"] < 2e-5
+    assert errs["f16x3"] < 4 * errs["f32"] + 2e-6
+
+
+def FK_view(ptr, count):
+    from tests.fake_hip import view
+    return view(ptr, count, np.float32)
+
+
 def _segments(rng, V, widths, ldt_extra=0):
     """random multi-segment output side: returns (cpu Segment array, gpu Segment array, keepalive, ldt)"""
     bounds = np.linspace(0, V, len(widths) + 1).astype(int)

@@ -81,6 +81,37 @@ def bench_lse_stat(V, widths, R, tag):
     report("vocab_lse_stationary %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
 
 
+def bench_lse_split(V, widths, R, tag):
+    if flt and flt not in "lse":
+        return
+    import ctypes
+    bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
+    n = len(widths)
+    segs = (_lib.Segment * n)()
+    ts, ds = (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    keep, off, flops = [], 0, 0.0
+    for i, k in enumerate(widths):
+        kp = (k + 3) // 4 * 4
+        k16 = (k + 15) // 16 * 16
+        nv = bounds[i + 1] - bounds[i]
+        Bm = rnd(nv, kp, scale=0.05)
+        Bs = torch.zeros((nv, k16), device=dev)
+        assert L.jlm_pack_split_f16(Bm.data_ptr(), nv, kp, kp, 1024.0, Bs.data_ptr(), k16, st) == 0
+        keep += [Bm, Bs]
+        segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bs.data_ptr(), k16)
+        ts[i], ds[i] = 16.0, 1.0 / (16.0 * 1024.0)
+        off += kp
+        flops += 2.0 * k * nv * R
+    T, b2 = rnd(R, off), rnd(V, scale=0.05)
+    part = torch.empty((96, R, 2), device=dev)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    rows = torch.arange(R, device=dev, dtype=torch.int32)
+    f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, n, b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
+                                      part.data_ptr(), R, 96, R, nd.data_ptr(), st)
+    print("parts:", f())
+    report("vocab_lse_split      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+
+
 def bench_gate(H, E, R):
     if flt and flt not in "gate":
         return
@@ -115,7 +146,9 @@ if __name__ == "__main__":
         bench_gate(512, 200, R)
         bench_gate(512, 256, R)
         bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
+        bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_stat(50000, [256], R, "tied50k")
+        bench_lse_split(50000, [256], R, "tied50k")
         bench_lse(12000, 200, R, "seg0")
         bench_lse(18000, 100, R, "seg1")
         bench_lse(20000, 50, R, "seg2")
@@ -126,4 +159,5 @@ if __name__ == "__main__":
     bench_gate(512, 256, 20480)
     bench_lse(100000, 256, 20480, "tied100k-b20")
     bench_lse_stat(100000, [256], 20480, "tied100k-b20")
+    bench_lse_split(100000, [256], 20480, "tied100k-b20")
     bench_gemm(4096, 4096, 4096, "square")
