@@ -32,14 +32,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // (tools/probes/split_debug2.py finds them).
 __device__ __forceinline__ void split8(const float *x, float scale, f16x8 &hi, f16x8 &lo) {
 #pragma clang fp contract(off)
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float v = x[i] * scale;
+    for (int i = 0; i < 8; i += 2) {
+        f32x2 v = {x[i] * scale, x[i + 1] * scale};
         asm volatile("" : "+v"(v));
-        _Float16 h = (_Float16)v;
+        f16x2 h = __builtin_convertvector(v, f16x2);          // v_cvt_pk_f16_f32, round to nearest even
         asm volatile("" : "+v"(h));
-        hi[i] = h;
-        lo[i] = (_Float16)(v - (float)h);
+        const f32x2 r = v - __builtin_convertvector(h, f32x2); // exact: h is within half an f16 ulp of v
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
     }
 }
 
@@ -123,18 +127,35 @@ __device__ __forceinline__ void lse_split_body(
     const bool row_ok = prow < n_paths;
     const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
     f16x8 thi[NS], tlo[NS];
+    {   // loads of the next 4 steps in flight while 4 are split: bounded register use, one exposed latency
+        constexpr int NG = (NS + 3) / 4;
+        f32x4 xb[2][4][2];
+        auto load_group = [&](int g, int par) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int k0 = 16 * s + 8 * h;
-        float x[8];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = k0 + 4 * q;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+                for (int q = 0; q < 2; ++q) {
+                    const int k = 16 * (4 * g + j) + 8 * h + 4 * q;
+                    xb[par][j][q] = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+                }
+        };
+        load_group(0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && k < K) ? v[e] : 0.0f;
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int st = 4 * g + j;
+                if (st >= NS) break;
+                float x[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && 16 * st + 8 * h + 4 * q < K) ? xb[g & 1][j][q][e] : 0.0f;
+                split8(x, t_scale, thi[st], tlo[st]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        split8(x, t_scale, thi[s], tlo[s]);
     }
     float *Bs = smem;                              // [2][BMV][64]
     float *bias_s = smem + 2 * BMV * 64;           // [3][BMV], base-2 units
@@ -212,6 +233,7 @@ __device__ __forceinline__ void lse_split_body(
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], tlo[st], acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], thi[st], acc[mt], 0, 0, 0);
                 }
+                if (MT == 2) __builtin_amdgcn_sched_barrier(0);   // keeps the fragment reads one unit ahead, not three
             }
             if (last_c) bias_stage(t + 1);
             __syncthreads();

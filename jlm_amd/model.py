@@ -245,6 +245,49 @@ class DeviceModel:
             arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], sg["k"], sg["t_off"], self.seg_B[i].data_ptr(), sg["ldb"])
         self.seg_array = arr
         self.n_segs = len(self.segments)
+        # --- split-f16 copies of the output embeddings (include/jlm_hip.h "f16x3"): the vocabulary
+        #     reduction then runs on the f16 matrix pipe with f32-grade products.  JLM_PRECISION=f32
+        #     keeps the plain f32-MFMA kernel.
+        self.precision = os.environ.get("JLM_PRECISION", "f16x3")
+        if self.precision not in ("f16x3", "f32"):
+            raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
+        self.split_array = None
+        if self.stationary_ok and self.precision == "f16x3":
+            self._build_split(None if self.pmt is None else np.abs(pmt).sum(axis=1))
+
+    def _build_split(self, t_bound):
+        """Split rows of every segment's matrix.  Scales are powers of two: 2^eB puts max|B| at
+        <= 2^14, 2^eT puts the largest value a T column can take (|h| < 1, so |T_j| <= sum_i |PM_ij|)
+        times log2(e) at <= 2^15 -- both inside the f16 range with their low halves out of the
+        subnormals."""
+        import ctypes
+        torch, L = self.torch, _lib.lib()
+        n = self.n_segs
+        arr = (_lib.Segment * n)()
+        self.split_t_scale, self.split_descale = (ctypes.c_float * n)(), (ctypes.c_float * n)()
+        self.seg_split = []
+
+        def pow2_below(limit, value):
+            if not (value > 0.0) or not np.isfinite(value):
+                return 0
+            return int(np.clip(np.floor(np.log2(limit / value)), -40, 40))
+
+        for i, sg in enumerate(self.segments):
+            nv, k = sg["v_end"] - sg["v_start"], sg["k"]
+            k16 = _pad(k, 16)
+            eB = pow2_below(2.0 ** 14, float(self.seg_B[i].abs().max().item()) if nv else 0.0)
+            tb = 1.0 if t_bound is None else float(t_bound[sg["t_off"]:sg["t_off"] + k].max())
+            eT = pow2_below(2.0 ** 15, tb * 1.4426950408889634)
+            dst = torch.zeros((max(nv, 1), k16), dtype=torch.float32, device=self.device)
+            _lib.check(L.jlm_pack_split_f16(self.seg_B[i].data_ptr(), nv, k, sg["ldb"], float(2.0 ** eB), dst.data_ptr(), k16,
+                                            self.stream() if self.device.type == "cuda" else None), "jlm_pack_split_f16")
+            self.seg_split.append(dst)
+            arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], k, sg["t_off"], dst.data_ptr(), k16)
+            self.split_t_scale[i] = 2.0 ** eT
+            self.split_descale[i] = 2.0 ** -(eT + eB)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.split_array = arr
 
     # -- enqueue helpers (all on torch's current HIP stream) ------------------
     def stream(self):
@@ -278,12 +321,17 @@ class DeviceModel:
         if self.stationary_ok:
             if rec is not None:
                 rec.begin("vocab_lse")
-            r = L.jlm_vocab_lse_stationary(self.seg_array, self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part,
-                                           ld_part, max_parts, n_rows_max, n_dev, stream)
+            if self.split_array is not None:
+                r = L.jlm_vocab_lse_split(self.split_array, self.split_t_scale, self.split_descale, self.n_segs,
+                                          self.b2.data_ptr(), T, self.ldt, rows, part, ld_part, max_parts, n_rows_max,
+                                          n_dev, stream)
+            else:
+                r = L.jlm_vocab_lse_stationary(self.seg_array, self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part,
+                                               ld_part, max_parts, n_rows_max, n_dev, stream)
             if rec is not None:
                 rec.end("vocab_lse")
             if r < 0:
-                raise _lib.JlmHipError("jlm_vocab_lse_stationary failed with code %d" % r)
+                raise _lib.JlmHipError("rows-stationary vocabulary LSE failed with code %d" % r)
             n_parts = r
         else:
             n_parts = 0

@@ -13,7 +13,7 @@ import ctypes
 import numpy as np
 
 NEG = -3.0e38
-_CT = {np.float32: ctypes.c_float, np.float64: ctypes.c_double, np.int32: ctypes.c_int32}
+_CT = {np.float32: ctypes.c_float, np.float64: ctypes.c_double, np.int32: ctypes.c_int32, np.float16: ctypes.c_uint16}
 
 
 def _p(x):
