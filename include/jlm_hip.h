@@ -127,9 +127,29 @@ int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs, const flo
  * zeros to a multiple of 16, stored as k/8 blocks of [8 x f16 hi][8 x f16 lo]
  * (4 bytes per value, row stride ld_dst in 4-byte units, a multiple of 16).
  * scale must be a power of two (so that dividing it out again is exact) chosen
- * so that max|x| * scale stays below 65504. */
+ * so that max|x| * scale stays below 65504.  jlm_pack_split_f16 writes the
+ * blocks that cover k rounded up to 16 values (zero padded) and leaves the rest
+ * of each destination row alone, so a matrix can be packed in column ranges
+ * with different scales (dst / src advanced by a multiple of 16 values). */
 int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale,
                        void *dst, int ld_dst, void *stream);
+
+/* jlm_lstm_step on split rows (K1+K2+K3+K9): h_in / h_out are split rows of the
+ * state scaled by h_scale (a power of two <= 2^14; |h| < 1), emb the split rows
+ * of the input embedding, wt the split rows of the packed gate matrix whose
+ * first H columns are scaled by S / h_scale and the rest by S / (embedding
+ * scale), descale = 1 / S.  c stays f32.  H % 32 == 0, E % 16 == 0, all strides
+ * multiples of 16.  Same row semantics as jlm_lstm_step (decoder/model.py:105-131). */
+int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
+                        const int *rows, const int *prev, const int *word,
+                        const void *emb, int ld_emb, const void *wt, const float *bias,
+                        int kpad, int H, int E, float descale, float h_scale,
+                        int n_rows_max, const int *n_dev, void *stream);
+
+/* jlm_gemm_nt on split rows: C = descale * (A . B^T) + bias, C plain f32. */
+int jlm_gemm_nt_split(const void *A, int lda, const int *a_rows, const void *B, int ldb, const int *b_rows,
+                      float *C, int ldc, const int *c_rows, const float *bias, float descale,
+                      int M, int N, int K, const int *m_dev, void *stream);
 
 /* jlm_vocab_lse_stationary on split rows: segs[i].B = split rows of the
  * segment's output embedding scaled by 2^eB_i, segs[i].ldb their stride in

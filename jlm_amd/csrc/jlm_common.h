@@ -30,3 +30,45 @@ __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2
     s = s * expf(m - mm) + s2 * expf(m2 - mm);
     m = mm;
 }
+
+// ---- split-f16 operands (include/jlm_hip.h "f16x3"): x * scale = hi + lo, both f16.
+// The scaled value and hi are pinned in registers before they are used twice: left to itself the
+// compiler folds the multiply into ONE of the two uses of the f32->f16 conversion (v_fma_mix*,
+// single rounding from the exact product) and not the other, and hi and lo then disagree about
+// what hi is whenever the f32 product sits on an f16 rounding tie -- a 2^-11 error in that element
+// (tools/probes/split_debug2.py finds them).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void jlm_split2(float x0, float x1, float scale, f16x2 &hi, f16x2 &lo) {
+#pragma clang fp contract(off)
+    f32x2 v = {x0 * scale, x1 * scale};
+    asm volatile("" : "+v"(v));
+    f16x2 h = __builtin_convertvector(v, f16x2);              // v_cvt_pk_f16_f32, round to nearest even
+    asm volatile("" : "+v"(h));
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);     // exact: h is within half an f16 ulp of v
+    hi = h;
+    lo = __builtin_convertvector(r, f16x2);
+}
+
+template <class V4>
+__device__ __forceinline__ void jlm_split4(const f32x4 &x, float scale, V4 &hi, V4 &lo) {
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        f16x2 h, l;
+        jlm_split2(x[i], x[i + 1], scale, h, l);
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
+    }
+}
+
+__device__ __forceinline__ void jlm_split8(const float *x, float scale, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        f16x2 h, l;
+        jlm_split2(x[i], x[i + 1], scale, h, l);
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
+    }
+}

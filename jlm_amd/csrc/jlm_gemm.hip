@@ -112,6 +112,7 @@ struct TileMap {
 // ------------------------------------------------------------------ epilogues
 struct EpiStore {
     float *C; const int *c_map; int ldc; const float *bias;
+    float scale = 1.0f;                    // split-f16 mainloop: 2^-(eA + eB); 1 (exact) for the f32 mainloop
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
                         int M, int N, float *) const {
@@ -126,7 +127,7 @@ struct EpiStore {
 #pragma unroll
                 for (int nt = 0; nt < Cfg::NT; ++nt) {
                     int col = n0 + (wn * Cfg::NT + nt) * 32 + (lane & 31);
-                    if (col < N) crow[col] = acc[mt][nt][reg] + (bias ? bias[col] : 0.0f);
+                    if (col < N) crow[col] = acc[mt][nt][reg] * scale + (bias ? bias[col] : 0.0f);
                 }
             }
     }
@@ -143,6 +144,9 @@ struct EpiStore {
 struct EpiGate {
     const float *c_in; float *h_out; float *c_out; int ld;
     const int *rows; const int *prev; const float *bias;
+    float scale = 1.0f;                    // split-f16 mainloop: 2^-S; 1 (exact) for the f32 mainloop
+    float *h_split = nullptr;              // optional: h' also (or only, h_out == NULL) as split rows, stride ld
+    float h_scale = 1.0f;                  //           scaled by this power of two
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
                         int M, int, float *smem) const {
@@ -154,7 +158,7 @@ struct EpiGate {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int r = (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[mt][0][reg];
+                ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[mt][0][reg] * scale;
             }
         __syncthreads();
         const int tid = threadIdx.x;
@@ -186,7 +190,15 @@ struct EpiGate {
                 hn[e] = tanhf(cn[e]) * go;
             }
             *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
-            *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
+            if (h_out) *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
+            if (h_split) {                 // units u0 .. u0+3 = half of an 8-value block [8 x f16 hi][8 x f16 lo]
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 hi4, lo4;
+                jlm_split4(hn, h_scale, hi4, lo4);
+                _Float16 *blk = reinterpret_cast<_Float16 *>(h_split + (size_t)g * ld + (u0 & ~7)) + (u0 & 7);
+                *reinterpret_cast<f16x4 *>(blk) = hi4;
+                *reinterpret_cast<f16x4 *>(blk + 8) = lo4;
+            }
         }
     }
 };
@@ -382,6 +394,128 @@ static int launch_gemm2(const ARows &A, const BRows &B, int K, const Epi &epi, i
 }
 
 
+// ------------------------------------------------------ split-f16 mainloop ("f16x3")
+// Same tiles, same LDS-DMA staging, same row sources and epilogues as gemm2_kernel, but both
+// operands are SPLIT ROWS (include/jlm_hip.h): a 32-value k-step of a row is still 128 bytes =
+// 8 granules, granule (2 kb + p) = plane p (0 hi, 1 lo) of the 8 values kb.  A k-step is two
+// v_mfma_f32_32x32x16_f16 steps; lane half h of step s reads granules 4 s + 2 h + p, and each 32x32
+// block of the wave tile takes 3 MFMAs per step (lo.hi, hi.lo, hi.hi) -- 6 x 32 cycles per k-step and
+// block instead of the 16 x 64 of the f32 pipe.  The epilogue multiplies the accumulators by
+// 2^-(eA + eB) (Epi::scale).
+template <class Cfg, class ARows, class BRows, class Epi>
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRows B, int K, Epi epi, TileMap tmap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, MT = Cfg::MT, NT = Cfg::NT;
+    using L2 = Lds2<Cfg>;
+    int tile_m, tile_n;
+    if (!tmap.get(blockIdx.x, tile_m, tile_n)) return;
+    const int M = A.count(), N = B.count();
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= M || n0 >= N) return;
+    float *As = smem;                         // [2][BM][32]
+    float *Bs = smem + 2 * BM * 32;           // [2][BN][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    typename ARows::St sa[L2::A_INST];
+    typename BRows::St sb[L2::B_INST];
+    int ka[L2::A_INST], kb[L2::B_INST];
+#pragma unroll
+    for (int i = 0; i < L2::A_INST; ++i) {
+        const int r = (wave * L2::A_INST + i) * 8 + lrow;
+        sa[i] = A.init(m0 + r, M);
+        ka[i] = (lslot ^ ((r >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < L2::B_INST; ++i) {
+        const int r = (wave * L2::B_INST + i) * 8 + lrow;
+        sb[i] = B.init(n0 + r, N);
+        kb[i] = (lslot ^ ((r >> 1) & 7)) * 4;
+    }
+    auto issue = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < L2::A_INST; ++i) {
+            const int k = k0 + ka[i];
+            const float *p = (k < K && A.valid(sa[i], k0)) ? A.ptr(sa[i], k0) + k : jlm_zero_page;
+            GLDS16(p, As + (buf * BM + (wave * L2::A_INST + i) * 8) * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < L2::B_INST; ++i) {
+            const int k = k0 + kb[i];
+            const float *p = (k < K && B.valid(sb[i], k0)) ? B.ptr(sb[i], k0) + k : jlm_zero_page;
+            GLDS16(p, Bs + (buf * BN + (wave * L2::B_INST + i) * 8) * 32);
+        }
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    const int nk = (K + BK - 1) / BK;
+    const int li = lane & 31, h = lane >> 5;
+    int goff[2][2];                            // float offset of (step s, plane p) inside the lane's row
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * h + p) ^ ((li >> 1) & 7)) * 4);
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue((kt + 1) * BK, cur ^ 1);
+        const float *as = As + (cur * BM + wm * MT * 32) * 32;
+        const float *bs = Bs + (cur * BN + wn * NT * 32) * 32;
+        f16x8 a[2][MT][2], b[2][NT][2];
+        auto load = [&](int st) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[st][mt][p] = *reinterpret_cast<const f16x8 *>(as + mt * 1024 + goff[st][p]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[st][nt][p] = *reinterpret_cast<const f16x8 *>(bs + nt * 1024 + goff[st][p]);
+            }
+        };
+        load(0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (st == 0) load(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][1], b[st][nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][0], b[st][nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][0], b[st][nt][0], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+}
+
+template <class Cfg, class ARows, class BRows, class Epi>
+static int launch_gemm_split(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_split_kernel<Cfg, ARows, BRows, Epi>;
+    constexpr int lds = Lds2<Cfg>::BYTES;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    TileMap tm;
+    tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
+    tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
+    tm.xcd = xcd;
+    if (tm.tiles_m == 0 || tm.tiles_n == 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(tm.grid()), dim3(Cfg::NTHREADS), lds, st, A, B, K, epi, tm);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ launchers
 typedef TileCfg<2, 2, 2, 2> Cfg128;     // 128 x 128, wave 64 x 64
 typedef TileCfg<2, 2, 1, 1> Cfg64;      //  64 x  64, wave 32 x 32
@@ -421,6 +555,42 @@ extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const fl
     long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles128 < 512) return launch_gemm2<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
     return launch_gemm2<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
+}
+
+// Split-f16 forms of the two entry points above (operands = split rows, strides in 4-byte units).
+extern "C" int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
+                                   const int *rows, const int *prev, const int *word, const void *emb, int ld_emb,
+                                   const void *wt, const float *bias, int kpad, int H, int E, float descale,
+                                   float h_scale, int n_rows_max, const int *n_dev, void *stream) {
+    if (H % 32 != 0 || E % 16 != 0 || kpad % BK != 0 || kpad < H + E || ld_state % 16 || ld_emb % 16) return -1;
+    GateRows A;
+    A.h = reinterpret_cast<const float *>(h_in); A.ldh = ld_state; A.rows = rows; A.prev = prev; A.word = word;
+    A.emb = reinterpret_cast<const float *>(emb); A.lde = ld_emb; A.H = H; A.nrows = n_rows_max; A.ndev = n_dev;
+    PlainRows B;
+    B.base = reinterpret_cast<const float *>(wt); B.map = nullptr; B.ld = kpad; B.nrows = 4 * H; B.ndev = nullptr;
+    EpiGate epi;
+    epi.c_in = c_in; epi.h_out = nullptr; epi.c_out = c_out; epi.ld = ld_state;
+    epi.rows = rows; epi.prev = prev; epi.bias = bias;
+    epi.scale = descale; epi.h_split = reinterpret_cast<float *>(h_out); epi.h_scale = h_scale;
+    const int tiles_n = 4 * H / 64;
+    static int big = -1;
+    if (big < 0) { const char *e = getenv("JLM_GATE_TILE"); big = e ? atoi(e) : 128; }
+    if (big == 128) return launch_gemm_split<TileCfg<2, 2, 2, 1>>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
+    return launch_gemm_split<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
+}
+
+extern "C" int jlm_gemm_nt_split(const void *Ap, int lda, const int *a_rows, const void *Bp, int ldb, const int *b_rows,
+                                 float *C, int ldc, const int *c_rows, const float *bias, float descale, int M, int N,
+                                 int K, const int *m_dev, void *stream) {
+    if (K % 16 != 0 || lda % 16 != 0 || ldb % 16 != 0) return -1;
+    PlainRows A, B;
+    A.base = reinterpret_cast<const float *>(Ap); A.map = a_rows; A.ld = lda; A.nrows = M; A.ndev = m_dev;
+    B.base = reinterpret_cast<const float *>(Bp); B.map = b_rows; B.ld = ldb; B.nrows = N; B.ndev = nullptr;
+    EpiStore epi;
+    epi.C = C; epi.c_map = c_rows; epi.ldc = ldc; epi.bias = bias; epi.scale = descale;
+    long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 < 512) return launch_gemm_split<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
+    return launch_gemm_split<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
 }
 
 extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, int K, const float *T, int ldt,

@@ -19,39 +19,18 @@
 #include "jlm_common.h"
 #include <stdlib.h>
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 #define GLDS16(gp, lp)                                                                          \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
-// hi/lo of x * scale.  The scaled value is pinned in a register before it is converted: left to
-// itself the compiler folds the multiply into ONE of the two uses of the conversion (v_fma_mix*,
-// single rounding from the exact product) and not into the other, and hi and lo then disagree about
-// what hi is whenever the f32 product sits on an f16 rounding tie -- a 2^-11 error in that element
-// (tools/probes/split_debug2.py finds them).
-__device__ __forceinline__ void split8(const float *x, float scale, f16x8 &hi, f16x8 &lo) {
-#pragma clang fp contract(off)
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-        f32x2 v = {x[i] * scale, x[i + 1] * scale};
-        asm volatile("" : "+v"(v));
-        f16x2 h = __builtin_convertvector(v, f16x2);          // v_cvt_pk_f16_f32, round to nearest even
-        asm volatile("" : "+v"(h));
-        const f32x2 r = v - __builtin_convertvector(h, f32x2); // exact: h is within half an f16 ulp of v
-        const f16x2 l = __builtin_convertvector(r, f16x2);
-        hi[i] = h[0]; hi[i + 1] = h[1];
-        lo[i] = l[0]; lo[i + 1] = l[1];
-    }
-}
+#define split8 jlm_split8
 
 // ---------------------------------------------------------------------------------------------
-// f32 [rows, k] (ld) -> split rows [rows, ld_dst] (ld_dst in 4-byte units, >= k rounded up to 16).
+// f32 [rows, k] (ld) -> split rows (stride ld_dst 4-byte units): the blocks covering k rounded up to
+// 16 values are written (zero padded), the rest of a destination row is left alone.
 __global__ void pack_split_kernel(const float *__restrict__ src, int rows, int k, int ld, float scale,
                                   float *__restrict__ dst, int ld_dst) {
-    const int nblk = ld_dst / 8;                       // 8-value blocks per destination row
+    const int nblk = ((k + 15) / 16) * 2;              // 8-value blocks written per row
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * nblk) return;
     const int r = (int)(i / nblk), kb = (int)(i % nblk);
@@ -67,9 +46,9 @@ __global__ void pack_split_kernel(const float *__restrict__ src, int rows, int k
 
 extern "C" int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale, void *dst, int ld_dst,
                                   void *stream) {
-    if (rows < 0 || k <= 0 || ld < k || ld_dst % 16 || ld_dst < k) return -1;
+    if (rows < 0 || k <= 0 || ld < k || ld_dst % 16 || ld_dst < (k + 15) / 16 * 16) return -1;
     if (rows == 0) return 0;
-    const long n = (long)rows * (ld_dst / 8);
+    const long n = (long)rows * (((k + 15) / 16) * 2);
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k,
                        ld, scale, reinterpret_cast<float *>(dst), ld_dst);
     JLM_LAUNCH_CHECK();

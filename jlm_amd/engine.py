@@ -207,10 +207,10 @@ class DecodeEngine:
             if timing:
                 e0, e1, e2 = (_Stamp(torch, self.device) for _ in range(3))
                 e0.record()
-            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st, self.recorder)
+            m.lstm_step(hp, cp, H, hp, cp, rows, bpp, wordp, rmax, ndev, st, self.recorder, split=m.split_lstm)
             if timing:
                 e1.record()
-            m.project_T(hp, H, Tp, rows, rmax, ndev, st)
+            m.project_T(hp, H, Tp, rows, rmax, ndev, st, split=m.split_lstm)
             cell = 4 * f * B
             est = st
             if side is not None:       # edge logits need only T: run them beside the normaliser

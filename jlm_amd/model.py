@@ -168,6 +168,7 @@ class DeviceModel:
             wt[n, H:H + E_in] = np.asarray(weights["IM" + g], dtype=f32).T
             bias[n] = np.asarray(weights["b" + g], dtype=f32)
         self.wt, self.gate_bias = dev(wt), dev(bias)
+        self._wmax = (float(np.abs(wt[:, :H]).max()), float(np.abs(wt[:, H:]).max()), float(np.abs(emb).max()))
         self.b2 = dev(weights["b2"])
 
         # --- output side: segments over T
@@ -252,6 +253,7 @@ class DeviceModel:
         if self.precision not in ("f16x3", "f32"):
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None
+        self.split_lstm = False
         if self.stationary_ok and self.precision == "f16x3":
             self._build_split(None if self.pmt is None else np.abs(pmt).sum(axis=1))
 
@@ -285,33 +287,71 @@ class DeviceModel:
             arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], k, sg["t_off"], dst.data_ptr(), k16)
             self.split_t_scale[i] = 2.0 ** eT
             self.split_descale[i] = 2.0 ** -(eT + eB)
+        self.split_array = arr
+        # --- the LSTM step and the T projection on split rows (tied / D-softmax / V-table models; an
+        #     untied model's T is the state itself and its k = H > 256 reduction stays on the f32 pipe)
+        self.split_lstm = self.pmt is not None
+        if self.split_lstm:
+            H, st = self.H, (self.stream() if self.device.type == "cuda" else None)
+            wh, wx, em = self._wmax
+            self.h_scale = 2.0 ** 14                                   # |h| < 1
+            eE = pow2_below(2.0 ** 14, em)
+            S = min(14 + pow2_below(2.0 ** 14, wh), eE + pow2_below(2.0 ** 14, wx))
+            self.Epad16 = _pad(self.E_in, 16)
+            self.kpad_split = _pad(H + self.Epad16, 32)
+            self.emb_split = torch.zeros((self.emb.shape[0], self.Epad16), dtype=torch.float32, device=self.device)
+            _lib.check(L.jlm_pack_split_f16(self.emb.data_ptr(), self.emb.shape[0], self.Epad, self.Epad, float(2.0 ** eE),
+                                            self.emb_split.data_ptr(), self.Epad16, st), "jlm_pack_split_f16(emb)")
+            self.wt_split = torch.zeros((4 * H, self.kpad_split), dtype=torch.float32, device=self.device)
+            _lib.check(L.jlm_pack_split_f16(self.wt.data_ptr(), 4 * H, H, self.kpad, float(2.0 ** (S - 14)),
+                                            self.wt_split.data_ptr(), self.kpad_split, st), "jlm_pack_split_f16(W_h)")
+            _lib.check(L.jlm_pack_split_f16(self.wt.data_ptr() + 4 * H, 4 * H, self.Epad, self.kpad, float(2.0 ** (S - eE)),
+                                            self.wt_split.data_ptr() + 4 * H, self.kpad_split, st), "jlm_pack_split_f16(W_x)")
+            self.gate_descale = 2.0 ** -S
+            eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
+            self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
+            _lib.check(L.jlm_pack_split_f16(self.pmt.data_ptr(), self.pmt.shape[0], H, H, float(2.0 ** eP),
+                                            self.pmt_split.data_ptr(), H, st), "jlm_pack_split_f16(PM)")
+            self.t_descale = 2.0 ** -(14 + eP)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        self.split_array = arr
 
     # -- enqueue helpers (all on torch's current HIP stream) ------------------
     def stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
-    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream, rec=None):
+    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream, rec=None, split=False):
+        """One fused LSTM step.  split=True: h_in / h_out hold SPLIT ROWS of the state (the decode
+        engine's layout when self.split_lstm); otherwise plain f32 (LSTM_Model.predict)."""
         L = _lib.lib()
         if rec is not None:
             rec.begin("gate_gemm")
-        _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
-                                   self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),
-                                   self.kpad, self.H, self.Epad, n_rows_max, n_dev, stream), "jlm_lstm_step")
+        if split:
+            _lib.check(L.jlm_lstm_step_split(h_in, c_in, ld, h_out, c_out, rows, prev, word,
+                                             self.emb_split.data_ptr(), self.Epad16, self.wt_split.data_ptr(),
+                                             self.gate_bias.data_ptr(), self.kpad_split, self.H, self.Epad16,
+                                             self.gate_descale, self.h_scale, n_rows_max, n_dev, stream),
+                       "jlm_lstm_step_split")
+        else:
+            _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
+                                       self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),
+                                       self.kpad, self.H, self.Epad, n_rows_max, n_dev, stream), "jlm_lstm_step")
         if rec is not None:
             rec.end("gate_gemm")
 
-    def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream):
+    def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream, split=False):
         """T[g] = h[g].[PM | PM.VT_i^T ...]: one GEMM.  No-op for untied models
-        (T aliases h there)."""
+        (T aliases h there).  split=True: h holds split rows."""
         if self.mode == "untied":
             return
         L = _lib.lib()
         n_t = self.pmt.shape[0]
-        _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
-                                 n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
+        if split:
+            _lib.check(L.jlm_gemm_nt_split(h, ldh, rows, self.pmt_split.data_ptr(), self.H, None, T, self.ldt, rows, None,
+                                           self.t_descale, n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt_split(PM)")
+        else:
+            _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
+                                     n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
 
     def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None):
         """lse[g] over the full vocabulary for the listed rows (K5+K6 fused).

@@ -79,6 +79,79 @@ class FakeLib:
         cout[g, :H] = cn
         return 0
 
+    # ---- split rows helpers (include/jlm_hip.h "f16x3")
+    @staticmethod
+    def _split_view(ptr, nrows, ld):
+        """[nrows, ld // 8, 2 planes, 8] float16 view of split rows"""
+        return view(ptr, nrows * ld * 2, np.float16).reshape(nrows, ld // 8, 2, 8)
+
+    @classmethod
+    def _split_read(cls, ptr, nrows, ld):
+        sp = cls._split_view(ptr, nrows, ld).astype(np.float64)
+        with np.errstate(invalid="ignore"):        # rows nobody reads may hold uninitialised storage
+            return (sp[:, :, 0, :] + sp[:, :, 1, :]).reshape(nrows, ld)
+
+    @classmethod
+    def _split_write(cls, ptr, nrows, ld, row_ids, x):
+        """x [len(row_ids), k] float32 (already scaled) -> split rows row_ids; k <= ld, k % 8 == 0"""
+        out = cls._split_view(ptr, nrows, ld)
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        nb = x.shape[1] // 8
+        out[row_ids, :nb, 0, :] = hi.reshape(len(row_ids), nb, 8)
+        out[row_ids, :nb, 1, :] = lo.reshape(len(row_ids), nb, 8)
+
+    def jlm_lstm_step_split(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,
+                            descale, h_scale, n_rows_max, n_dev, stream):
+        if H % 32 or E % 16 or kpad % 32 or kpad < H + E or ld % 16 or ld_emb % 16:
+            return -1
+        n = _n(n_rows_max, n_dev)
+        if n == 0:
+            return 0
+        g = _rows(rows, n)
+        gmax = int(g.max()) + 1
+        p = view(prev, gmax, np.int32)[g].astype(np.int64)
+        w = view(word, gmax, np.int32)[g].astype(np.int64)
+        hmax = max(gmax, int(p.max()) + 1)
+        hin = self._split_read(h_in, hmax, ld)
+        cin = view(c_in, hmax * ld, np.float32).reshape(hmax, ld)
+        embv = self._split_read(emb, int(w.max()) + 1, ld_emb)
+        x = np.zeros((n, kpad), dtype=np.float64)
+        ok = p >= 0
+        x[ok, :H] = hin[p[ok], :H]
+        x[:, H:H + E] = embv[w, :E]
+        cp = np.zeros((n, H), dtype=np.float32)
+        cp[ok] = cin[p[ok], :H]
+        W = self._split_read(wt, 4 * H, kpad)
+        b = view(bias, 4 * H, np.float32)
+        z = ((x @ W.T) * float(descale)).astype(np.float32) + b
+        u = np.arange(H)
+        zi, zf, zo, zg = (z[:, (u // 16) * 64 + k * 16 + (u % 16)] for k in range(4))
+        sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
+        cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
+        hn = (np.tanh(cn) * sig(zo)).astype(np.float32)
+        self._split_write(h_out, gmax, ld, g, hn * np.float32(h_scale))
+        cout = view(c_out, gmax * ld, np.float32).reshape(gmax, ld)
+        cout[g, :H] = cn
+        return 0
+
+    def jlm_gemm_nt_split(self, A, lda, a_rows, B, ldb, b_rows, C, ldc, c_rows, bias, descale, M, N, K, m_dev, stream):
+        if K % 16 or lda % 16 or ldb % 16:
+            return -1
+        m = _n(M, m_dev)
+        if m == 0 or N == 0:
+            return 0
+        ar, br, cr = _rows(a_rows, m), _rows(b_rows, N), _rows(c_rows, m)
+        Av = self._split_read(A, int(ar.max()) + 1, lda)[ar, :K]
+        Bv = self._split_read(B, int(br.max()) + 1, ldb)[br, :K]
+        out = ((Av @ Bv.T) * float(descale)).astype(np.float32)
+        if _p(bias):
+            out = out + view(bias, N, np.float32)
+        base = _p(C)
+        for i, r in enumerate(cr):
+            view(base + 4 * int(r) * ldc, N, np.float32)[:] = out[i]
+        return 0
+
     # --------------------------------------------------------------------- K4
     def jlm_gemm_nt(self, A, lda, a_rows, B, ldb, b_rows, C, ldc, c_rows, bias, M, N, K, m_dev, stream):
         m = _n(M, m_dev)
@@ -140,19 +213,24 @@ class FakeLib:
         return n_segs
 
     def jlm_pack_split_f16(self, src, rows, k, ld, scale, dst, ld_dst, stream):
-        """split rows: per 8 values [8 x f16 hi][8 x f16 lo] (include/jlm_hip.h)"""
-        if rows < 0 or k <= 0 or ld < k or ld_dst % 16 or ld_dst < k:
+        """split rows: per 8 values [8 x f16 hi][8 x f16 lo]; blocks covering pad16(k) are written"""
+        k16 = (k + 15) // 16 * 16
+        if rows < 0 or k <= 0 or ld < k or ld_dst % 16 or ld_dst < k16:
             return -1
         if rows == 0:
             return 0
-        x = np.zeros((rows, ld_dst), dtype=np.float32)
-        x[:, :k] = view(src, rows * ld, np.float32).reshape(rows, ld)[:, :k]
+        as_strided = np.lib.stride_tricks.as_strided
+        # src / dst may be column-offset views of wider matrices: the last row is only k (k16) long
+        flat = view(src, (rows - 1) * ld + k, np.float32)
+        x = np.zeros((rows, k16), dtype=np.float32)
+        x[:, :k] = as_strided(flat, shape=(rows, k), strides=(4 * ld, 4))
         x *= np.float32(scale)
         hi = x.astype(np.float16)
         lo = (x - hi.astype(np.float32)).astype(np.float16)
-        out = view(dst, rows * ld_dst * 2, np.float16).reshape(rows, ld_dst // 8, 2, 8)
-        out[:, :, 0, :] = hi.reshape(rows, ld_dst // 8, 8)
-        out[:, :, 1, :] = lo.reshape(rows, ld_dst // 8, 8)
+        dflat = view(dst, ((rows - 1) * ld_dst + k16) * 2, np.float16)
+        out = as_strided(dflat, shape=(rows, k16 // 8, 2, 8), strides=(4 * ld_dst, 32, 16, 2))
+        out[:, :, 0, :] = hi.reshape(rows, k16 // 8, 8)
+        out[:, :, 1, :] = lo.reshape(rows, k16 // 8, 8)
         return 0
 
     def jlm_vocab_lse_split(self, segs, t_scale, descale, n_segs, b2, T, ldt, rows, part, ld_part, max_parts, n_rows_max,
