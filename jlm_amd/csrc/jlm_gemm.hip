@@ -619,32 +619,7 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
 // (max, sum) pair per (row, vocabulary range) is written at the very end.
 // One kernel instantiation per number of k-steps NK (its own register budget);
 // the grid of a launch is sized to ONE resident round of workgroups.
-// Cycle accounting of the kernel below (tools/lse_profile.sh builds a -DJLM_PROFILE copy of the
-// library; the shipped build has none of it): per wave, cycles in the prologue (T fragments), waiting
-// at the k-step barrier (skew + DMA landing), in the fold, and in total.
-#ifdef JLM_PROFILE
-__device__ unsigned long long jlm_prof[8];
-extern "C" int jlm_prof_read(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof), sizeof(jlm_prof)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(jlm_prof), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#define JLM_PROF_DECL() unsigned long long p_t0 = clock64(), p_t1 = 0, p_t2 = 0, p_x = 0, p_bar = 0, p_fold = 0
-#define JLM_PROF_MARK(v) v = clock64()
-#define JLM_PROF_ADD(acc_, since) acc_ += clock64() - since
-#define JLM_PROF_FLUSH()                                                                   \
-    if ((threadIdx.x & 63) == 0) {                                                         \
-        const unsigned long long now = clock64();                                          \
-        atomicAdd(&jlm_prof[0], now - p_t0); atomicAdd(&jlm_prof[1], p_t1 - p_t0);         \
-        atomicAdd(&jlm_prof[2], p_t2 - p_t1); atomicAdd(&jlm_prof[3], p_bar);              \
-        atomicAdd(&jlm_prof[4], p_fold); atomicAdd(&jlm_prof[5], 1ull);                    \
-    }
-#else
-#define JLM_PROF_DECL() (void)0
-#define JLM_PROF_MARK(v) (void)0
-#define JLM_PROF_ADD(acc_, since) (void)0
-#define JLM_PROF_FLUSH() (void)0
-#endif
+JLM_PROF_READER(jlm_prof_read)
 
 template <int NK, int MT>
 __device__ __forceinline__ void lse_stat_body(

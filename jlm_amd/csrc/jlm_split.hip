@@ -83,6 +83,8 @@ struct LseSplitArgs {
     short part_first[JLM_MAX_SEGMENTS + 1];
 };
 
+JLM_PROF_READER(jlm_prof_read_split)
+
 template <int NS, int MT>
 __device__ __forceinline__ void lse_split_body(
     const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int p_in_seg, int parts_in_seg, int pt,
@@ -94,6 +96,7 @@ __device__ __forceinline__ void lse_split_body(
     constexpr int NINST = BMV / 16;                // LDS-DMA instructions per wave per chunk (4 rows each, 4 waves)
     constexpr int MP = MT / 2;                     // fragment units (pairs of 32-row blocks) per k-step
     constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
+    JLM_PROF_DECL();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
@@ -174,9 +177,11 @@ __device__ __forceinline__ void lse_split_body(
 #pragma unroll
         for (int p = 0; p < 2; ++p) goff[j][p] = li * 64 + (((4 * j + 2 * h + p) ^ (li & 15)) * 4);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    JLM_PROF_MARK(p_t1);
     issue(vt0, 0, 0);
     bias_stage(vt0);
     __syncthreads();
+    JLM_PROF_MARK(p_t2);
     int buf = 0;
     for (int t = vt0; t < vt1; ++t) {
 #pragma unroll
@@ -215,9 +220,12 @@ __device__ __forceinline__ void lse_split_body(
                 if (MT == 2) __builtin_amdgcn_sched_barrier(0);   // keeps the fragment reads one unit ahead, not three
             }
             if (last_c) bias_stage(t + 1);
+            JLM_PROF_MARK(p_x);
             __syncthreads();
+            JLM_PROF_ADD(p_bar, p_x);
             buf ^= 1;
         }
+        JLM_PROF_MARK(p_x);
         // fold this tile's 16*MT logits of the lane's row into (m, s), base-2 units
         const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
         float tmax = JLM_NEG_BIG;
@@ -244,7 +252,9 @@ __device__ __forceinline__ void lse_split_body(
             }
         s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
         m = mn;
+        JLM_PROF_ADD(p_fold, p_x);
     }
+    JLM_PROF_FLUSH();
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
     {
         const float mm = fmaxf(m, m2);

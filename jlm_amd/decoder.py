@@ -20,6 +20,7 @@ Deliberate differences (DESIGN.md "Reference quirks"):
   * the LSTM step of the last frame is skipped (its result is never read,
     decoder.py:233-237).
 """
+import gc
 import os
 import pickle
 
@@ -68,6 +69,11 @@ class Decoder():
         self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
+        # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
+        # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20
+        # batches (tools/probes/stall_probe.py).  Park them in the permanent generation.
+        gc.collect()
+        gc.freeze()
 
     def _load_vocab(self):
         self.vocab = Vocab(self.config['vocab_size'])

@@ -1,0 +1,40 @@
+"""A/B of engine options in ONE process, interleaved (the chip's clocks drift between runs, so
+separate bench runs cannot resolve a few per cent): configs[1] batch, pipelined submit/collect."""
+import os, sys, time, tempfile
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import torch
+from jlm_amd import config as jconfig, synth
+from jlm_amd.decoder import Decoder
+from jlm_amd.lattice import BatchLattice
+root = os.path.join(tempfile.gettempdir(), "jlm_dbg")
+cfg, _l, _r, al = synth.build_fixture(root, sys.argv[1] if len(sys.argv) > 1 else "mid-vtable")
+jconfig.set_root(root)
+dec = Decoder(1); dec.perf_timing = False
+eng = dec._engine
+sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
+lat = BatchLattice(dec._builder, sents, 10)
+
+def run_pipe(n=12):
+    prev = None
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        tk = eng.submit(lat, "static", topN=10)
+        if prev is not None: eng.collect(prev)
+        prev = tk
+    eng.collect(prev)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+variants = {"eager+side": (False, True), "graph+side": (True, True), "eager": (False, False), "graph": (True, False)}
+for _ in range(3):
+    for g, sd in variants.values():
+        eng.use_graph, eng.use_side = g, sd
+        run_pipe(14)
+res = {k: [] for k in variants}
+for rep in range(8):
+    for k, (g, sd) in variants.items():
+        eng.use_graph, eng.use_side = g, sd
+        res[k].append(run_pipe(12))
+for k, v in res.items():
+    print("%-12s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
