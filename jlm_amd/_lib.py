@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjlm_hip.so")
+# JLM_HIP_LIB: developer override used by tools/ab_lib.sh to A/B two builds of the same ABI
+LIB_PATH = os.environ.get("JLM_HIP_LIB") or os.path.join(_HERE, "csrc", "libjlm_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "csrc", "libjlm_host.so")
 
 JLM_MAX_SEGMENTS = 8

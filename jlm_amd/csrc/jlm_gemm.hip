@@ -482,14 +482,15 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRow
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             if (st == 0) load(1);
+            // products outer, blocks inner: consecutive MFMAs never share an accumulator (MT * NT > 1)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][1], b[st][nt][0], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][0], b[st][nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][0], b[st][nt][0], acc[mt][nt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[st][mt][pr == 0 ? 1 : 0], b[st][nt][pr == 1 ? 1 : 0],
+                                                                             acc[mt][nt], 0, 0, 0);
         }
         __syncthreads();
     }

@@ -84,6 +84,13 @@ struct LseSplitArgs {
 };
 
 JLM_PROF_READER(jlm_prof_read_split)
+#ifdef JLM_PROFILE
+// per-workgroup timeline (constant 100 MHz clock): start, end, segment, row tile
+static __device__ unsigned long long jlm_prof_wg[1024][4];
+extern "C" int jlm_prof_read_wg(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof_wg), sizeof(jlm_prof_wg)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <int NS, int MT>
 __device__ __forceinline__ void lse_split_body(
@@ -94,13 +101,12 @@ __device__ __forceinline__ void lse_split_body(
     constexpr int NC = CH::NC;
     constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
     constexpr int NINST = BMV / 16;                // LDS-DMA instructions per wave per chunk (4 rows each, 4 waves)
-    constexpr int MP = MT / 2;                     // fragment units (pairs of 32-row blocks) per k-step
     constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
     JLM_PROF_DECL();
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // an SGPR: LDS-DMA destinations (M0) stay scalar
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
-    const int ns_rt = (K + 15) >> 4;               // steps that hold data (<= NS); the rest are skipped
     const int ntiles = (n_vocab + BMV - 1) / BMV;
     const int vt0 = (int)((long)ntiles * p_in_seg / parts_in_seg), vt1 = (int)((long)ntiles * (p_in_seg + 1) / parts_in_seg);
     const float *__restrict__ Bp = sg.B;
@@ -145,17 +151,35 @@ __device__ __forceinline__ void lse_split_body(
     // (row r, slot) = granule g = slot ^ (r & 15) of that row.  Nothing is masked: rows past the
     // segment re-read its last row (their bias is -3e38), granules past the chunk / the padded row
     // re-read the row's last granule (no fragment read ever touches them).
+    // The address of a DMA piece is a SCALAR part (segment base + tile + 4 i rows, all wave-uniform:
+    // SALU work) plus a small per-lane offset (the lane's row inside the instruction's 4 rows and its
+    // granule): one VALU add per piece instead of ten -- VALU issue slots are what this kernel runs
+    // out of beside the MFMAs (tools/probes/mfma_valu_overlap.hip).  Only a segment's last, partial
+    // tile takes the slow path that clamps the row index.
     const int lrow = lane >> 4, pslot = lane & 15;
-    const int dma_r0 = wave * NINST * 4 + lrow;    // instruction i fills rows dma_r0 + 4 i ...
-    const int dma_g0 = pslot ^ lrow;               // ... with granule dma_g0 ^ (4 (i & 3)) in this lane's slot
-    auto issue = [&](int t, int c_start, int buf) {   // chunk = steps [c_start, ...)
-        int r0 = dma_r0, g0 = dma_g0;
-        asm volatile("" : "+v"(r0), "+v"(g0));     // keep per-instruction offsets out of the loop-invariant registers
+    const int dma_g0 = pslot ^ ((wave * NINST * 4 + lrow) & 15);   // granule of piece i: dma_g0 ^ (4 (i & 3))
+    const unsigned lane_row_b = (unsigned)lrow * (unsigned)ldb * 4u;
+    const unsigned row4_b = 16u * (unsigned)ldb;                   // bytes between the rows of consecutive pieces
+    auto issue = [&](int t, int c_start, int buf) {                // chunk = steps [c_start, ...)
+        int g0 = dma_g0;
+        asm volatile("" : "+v"(g0));               // keep the per-chunk offsets out of the loop-invariant registers
+        unsigned voff[4];
 #pragma unroll
-        for (int i = 0; i < NINST; ++i) {
-            const int vrow = min(t * BMV + r0 + 4 * i, n_vocab - 1);
-            const int koff = min(c_start * 16 + ((g0 ^ (4 * (i & 3))) << 2), ldb - 4);
-            GLDS16(Bp + ((size_t)vrow * ldb + koff), Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+        for (int q = 0; q < 4 && q < NINST; ++q)
+            voff[q] = lane_row_b + 4u * (unsigned)min(c_start * 16 + ((g0 ^ (4 * q)) << 2), ldb - 4);
+        const int row0 = t * BMV + wave * NINST * 4;               // scalar: first row of this wave's pieces
+        if (row0 + NINST * 4 <= n_vocab) {
+            const char *sbase = reinterpret_cast<const char *>(Bp) + (size_t)row0 * ldb * 4;
+#pragma unroll
+            for (int i = 0; i < NINST; ++i)
+                GLDS16(sbase + (size_t)i * row4_b + voff[i & 3], Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) {
+                const int vrow = min(row0 + 4 * i + lrow, n_vocab - 1);
+                const unsigned off = (unsigned)vrow * (unsigned)ldb * 4u + (voff[i & 3] - lane_row_b);
+                GLDS16(reinterpret_cast<const char *>(Bp) + off, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+            }
         }
     };
     auto bias_stage = [&](int t) {
@@ -190,34 +214,35 @@ __device__ __forceinline__ void lse_split_body(
             if (last_c) issue(t + 1, 0, buf ^ 1);                    // past the range: harmless (next range / last row)
             else issue(t, CH::start(c + 1 < NC ? c + 1 : 0), buf ^ 1);
             const float *bs = Bs + buf * BMV * 64;
-            // units u = (step j, block pair mp), fragments read one unit ahead of the MFMAs
-            constexpr int NU = 4 * MP;             // upper bound; units past the chunk's size are compiled out below
-            f16x8 a[2][2][2];                      // [unit parity][block of the pair][plane]
+            // One k-step = 3 groups of MT MFMAs (lo.hi, hi.lo, hi.hi over all MT blocks): consecutive
+            // MFMAs never share an accumulator and a dependent one is MT instructions away.  The
+            // fragment registers are refilled in place: the lo planes of the next step right after
+            // the first group has issued, the hi planes after the last.
+            f16x8 ah[MT], al[MT];
             const int csz = CH::size(c), cst = CH::start(c);
-            auto load_unit = [&](int u, int par) {
-                const int j = u / MP, mp = u % MP;
+            auto load_plane = [&](f16x8 (&dst)[MT], int j, int p) {
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        a[par][b2][p] = *reinterpret_cast<const f16x8 *>(bs + (2 * mp + b2) * 32 * 64 + goff[j][p]);
+                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const f16x8 *>(bs + mt * 32 * 64 + goff[j][p]);
             };
-            if (cst < ns_rt) load_unit(0, 0);
+            // (steps past the segment's own k, when NS is rounded up, multiply zero T operands: no
+            //  run-time guards in here, they would split the chunk into basic blocks and force
+            //  s_waitcnt lgkmcnt(0) -- the full LDS latency -- in front of every MFMA group)
+            load_plane(al, 0, 1);
+            load_plane(ah, 0, 0);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int j = u / MP, mp = u % MP;
+            for (int j = 0; j < 4; ++j) {
                 if (j >= csz) break;               // compile-time bound of this chunk
-                if (cst + j >= ns_rt) break;       // padded steps hold nothing (uniform)
-                if (u + 1 < NU && (u + 1) / MP < csz && cst + (u + 1) / MP < ns_rt) load_unit(u + 1, (u + 1) & 1);
                 const int st = cst + j;            // compile-time after unrolling (register index)
+                const bool more = (j + 1 < csz);
 #pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    const int mt = 2 * mp + b2;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][1], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], tlo[st], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 1][b2][0], thi[st], acc[mt], 0, 0, 0);
-                }
-                if (MT == 2) __builtin_amdgcn_sched_barrier(0);   // keeps the fragment reads one unit ahead, not three
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
+                if (j + 1 < 4 && more) load_plane(al, j + 1 < 4 ? j + 1 : 0, 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], tlo[st], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], thi[st], acc[mt], 0, 0, 0);
+                if (j + 1 < 4 && more) load_plane(ah, j + 1 < 4 ? j + 1 : 0, 0);
             }
             if (last_c) bias_stage(t + 1);
             JLM_PROF_MARK(p_x);
@@ -286,12 +311,20 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
     const int pis = p - a.part_first[si], npis = a.part_first[si + 1] - a.part_first[si];
     float2 *prow = part + (size_t)p * ld_part;
     const int ns = (sg.k + 15) >> 4;
+#ifdef JLM_PROFILE
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     if (ns <= 2) lse_split_body<2, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
     else if (ns <= 4) lse_split_body<4, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
     else if (ns <= 7) lse_split_body<7, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
     else if (ns <= 10) lse_split_body<10, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
     else if (ns <= 13) lse_split_body<13, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
     else lse_split_body<16, 2>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+#ifdef JLM_PROFILE
+    if (threadIdx.x == 0 && b < 1024) {
+        jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si; jlm_prof_wg[b][3] = pt;
+    }
+#endif
 }
 
 // Host side: ranges per segment in proportion to their cost, one resident round of workgroups.
@@ -302,6 +335,8 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
     LseSplitArgs a;
     a.n_segs = n_segs;
+    static int c0 = -1;
+    if (c0 < 0) { const char *e = getenv("JLM_LSE_C0"); c0 = e ? atoi(e) : 4; }
     long work[JLM_MAX_SEGMENTS], total = 0;
     int ntiles[JLM_MAX_SEGMENTS];
     for (int i = 0; i < n_segs; ++i) {
@@ -314,10 +349,13 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         a.descale[i] = descale[i];
         const int bmv = ns > 13 ? 64 : 128;
         ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
-        // cycles per vocabulary row and SIMD: matrix pipe 2 waves x 3 ns, or the fold's VALU work
-        // (2 waves x ~17) when that is longer, plus the per-chunk barrier
-        const int mf = 6 * ns, fold = 34;
-        work[i] = (long)(sg.v_end - sg.v_start) * ((mf > fold ? mf : fold) + 3 * ((ns + 3) / 4));
+        // Cost of a vocabulary row ~ (k-steps + c0): the MFMAs plus a per-row constant (fold, staging).
+        // Single-segment timings (tools/probes/lse_cost_calib.py) give c0 = 1.6; in the mixed launch the
+        // fold-heavy workgroups (short k) share SIMDs with MFMA-heavy ones and finish later
+        // (tools/probes/lse_wg_timeline.py), which argues for more.  The launch time itself is flat
+        // (+-2 %) for c0 in 2..24 on the (200, 100, 50) model: the SIMDs, not one workgroup's critical
+        // path, are what is full.
+        work[i] = (long)(sg.v_end - sg.v_start) * (ns + c0);
         total += work[i];
     }
     const int n_ptiles = (n_rows_max + 127) / 128;

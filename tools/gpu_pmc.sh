@@ -1,10 +1,25 @@
 #!/bin/bash
+# SQ counters of the LSE kernels (kbench "lse" workloads), one rocprofv3 --pmc pass per counter set
 mkdir -p gpurun_out/pmc2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python $R/tools/kbench.py lse 2>&1 | grep stationary
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE"; do
+export KBENCH_ONLY=${KBENCH_ONLY:-split dsoftmax*}
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc2/$tag -o p -- python $R/tools/kbench.py lse > $R/gpurun_out/pmc2/$tag.log 2>&1
   echo "$tag rc=$?"
 done
+python - <<'PY'
+import csv, glob, os, collections
+R = os.environ["GRAFT_REPO_ROOT"]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(R + "/gpurun_out/pmc2/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:28] + " grid=" + r.get("Grid_Size", "?")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(agg):
+    if "lse" not in k: continue
+    print(k)
+    for c, v in sorted(agg[k].items()):
+        print("   %-28s %14.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY

@@ -60,6 +60,8 @@ def bench_lse(V, K, R, tag):
 def bench_lse_stat(V, widths, R, tag):
     if flt and flt not in "lse":
         return
+    if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "stat " + tag:
+        return
     bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
     segs = (_lib.Segment * len(widths))()
     keep, off, flops = [], 0, 0.0
@@ -83,6 +85,8 @@ def bench_lse_stat(V, widths, R, tag):
 
 def bench_lse_split(V, widths, R, tag):
     if flt and flt not in "lse":
+        return
+    if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "split " + tag:
         return
     import ctypes
     bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
