@@ -139,11 +139,18 @@ int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale,
  * of the input embedding, wt the split rows of the packed gate matrix whose
  * first H columns are scaled by S / h_scale and the rest by S / (embedding
  * scale), descale = 1 / S.  c stays f32.  H % 32 == 0, E % 16 == 0, all strides
- * multiples of 16.  Same row semantics as jlm_lstm_step (decoder/model.py:105-131). */
+ * multiples of 16.  Same row semantics as jlm_lstm_step (decoder/model.py:105-131).
+ *
+ * xgate != NULL: the input side is a table lookup instead of a contraction.
+ * xgate[w][n] = sum_e emb[w][e] * W_x[n][e] + bias[n]  (f32 [V, 4H], packed column
+ * order) is added in the epilogue for w = word[g]; the GEMM then runs over the
+ * state only (emb / bias / E are ignored, wt needs its first H columns only).
+ * model.py:125-131 computes x.IM_g + h.HM_g + b_g; the table is x.IM_g + b_g for
+ * every vocabulary word, formed once at load time. */
 int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
                         const int *rows, const int *prev, const int *word,
                         const void *emb, int ld_emb, const void *wt, const float *bias,
-                        int kpad, int H, int E, float descale, float h_scale,
+                        int kpad, int H, int E, float descale, float h_scale, const float *xgate,
                         int n_rows_max, const int *n_dev, void *stream);
 
 /* jlm_gemm_nt on split rows: C = descale * (A . B^T) + bias, C plain f32. */

@@ -20,9 +20,16 @@ struct SegTable {
     jlm_segment s[JLM_MAX_SEGMENTS];
 };
 
-// sigma(x) = 1/(exp(-x)+1), the reference's formula (decoder/model.py:12-13);
-// exp overflow gives 1/inf = 0, as in numpy.
-__device__ __forceinline__ float jlm_sigmoid(float x) { return 1.0f / (expf(-x) + 1.0f); }
+// sigma(x) = 1/(exp(-x)+1), the reference's formula (decoder/model.py:12-13); exp overflow gives
+// 1/inf = 0, as in numpy.  Hardware exp2 / rcp (1 ulp each): two transcendental issues instead of the
+// ~40-instruction libm expansions, which made the gate epilogue as long as the gate GEMM's mainloop.
+__device__ __forceinline__ float jlm_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -1.4426950408889634f) + 1.0f);
+}
+// tanh(x) = 2 sigma(2x) - 1 (np.tanh in model.py:129-130): exact limits +-1, absolute error ~1e-7
+__device__ __forceinline__ float jlm_tanh(float x) {
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -2.8853900817779268f) + 1.0f), -1.0f);
+}
 
 // online log-sum-exp pair merge: (m, s) <- (m, s) (+) (m2, s2); empty = (NEG_BIG, 0)
 __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {

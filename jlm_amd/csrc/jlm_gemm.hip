@@ -140,64 +140,90 @@ struct EpiStore {
 // then 4-wide, and c_prev / c' / h' move as 16-byte accesses.  Small tiles on
 // purpose: at R = 2560 rows the gate GEMM is 40 x 32 = 1280 workgroups = exactly
 // 5 per CU; 128 x 128 tiles (320 workgroups on 256 CUs) cap MFMA use at 62.5 %.
-#define GATE_CT_LD 68
 struct EpiGate {
     const float *c_in; float *h_out; float *c_out; int ld;
     const int *rows; const int *prev; const float *bias;
     float scale = 1.0f;                    // split-f16 mainloop: 2^-S; 1 (exact) for the f32 mainloop
     float *h_split = nullptr;              // optional: h' also (or only, h_out == NULL) as split rows, stride ld
     float h_scale = 1.0f;                  //           scaled by this power of two
+    const float *xgate = nullptr;          // optional [V, 4H] table  emb . W_x^T + bias  (packed column order):
+    const int *word = nullptr;             //   the GEMM then contracts over the state only and bias is unused
+    int ld_gate = 0;                       //   = H (a table row has 4 H floats)
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
                         int M, int, float *smem) const {
-        static_assert(Cfg::BN == 64 && Cfg::NT == 1 && Cfg::WAVES_N == 2 && Cfg::NTHREADS == 256,
-                      "gate epilogue: 64 columns = 4 gates x 16 units per tile");
-        float *ct = smem;                      // [BM][GATE_CT_LD]
-#pragma unroll
-        for (int mt = 0; mt < Cfg::MT; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                ct[r * GATE_CT_LD + wn * 32 + (lane & 31)] = acc[mt][0][reg] * scale;
-            }
-        __syncthreads();
+        constexpr int BN = Cfg::BN, NT = Cfg::NT;
+        static_assert((BN == 64 || BN == 128) && Cfg::WAVES_N == 2 && Cfg::NTHREADS == 256 && Cfg::BM % 64 == 0,
+                      "gate epilogue: tiles of 64-column groups (4 gates x 16 units), 64 rows at a time");
+        constexpr int CT_LD = BN + 4;          // transposition buffer [64][CT_LD]: 64 rows of the tile at a time
+        constexpr int TPR = BN / 16;           // threads per row, 4 units (x 4 gates) each
+        constexpr int RPP = 256 / TPR;         // rows per pass
+        float *ct = smem;
         const int tid = threadIdx.x;
-        const int uq = (tid & 3) * 4;
-        const int u0 = (n0 >> 2) + uq;
-        const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + n0 + uq);
-        const f32x4 bf = *reinterpret_cast<const f32x4 *>(bias + n0 + 16 + uq);
-        const f32x4 bo = *reinterpret_cast<const f32x4 *>(bias + n0 + 32 + uq);
-        const f32x4 bg = *reinterpret_cast<const f32x4 *>(bias + n0 + 48 + uq);
+        const int q = tid % TPR;
+        const int cb = (q >> 2) * 64 + (q & 3) * 4;          // column of the thread's i-gate quad inside the tile
+        const int u0 = (n0 >> 2) + (q >> 2) * 16 + (q & 3) * 4;
+        f32x4 bi = {0.f, 0.f, 0.f, 0.f}, bf = bi, bo = bi, bg = bi;
+        if (!xgate) {
+            bi = *reinterpret_cast<const f32x4 *>(bias + n0 + cb);
+            bf = *reinterpret_cast<const f32x4 *>(bias + n0 + cb + 16);
+            bo = *reinterpret_cast<const f32x4 *>(bias + n0 + cb + 32);
+            bg = *reinterpret_cast<const f32x4 *>(bias + n0 + cb + 48);
+        }
 #pragma unroll
-        for (int it = 0; it < Cfg::BM / 64; ++it) {
-            const int r = (tid >> 2) + it * 64;
-            const int row = m0 + r;
-            if (row >= M) continue;
-            const int g = rows ? rows[row] : row;
-            const int p = prev[g];
-            const f32x4 zi = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + uq) + bi;
-            const f32x4 zf = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 16 + uq) + bf;
-            const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 32 + uq) + bo;
-            const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * GATE_CT_LD + 48 + uq) + bg;
-            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-            if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
-            f32x4 cn, hn;
+        for (int rh = 0; rh < Cfg::BM / 64; ++rh) {
+            if (rh > 0) __syncthreads();       // the previous 64 rows have been consumed
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gi = jlm_sigmoid(zi[e]), gf = jlm_sigmoid(zf[e]), go = jlm_sigmoid(zo[e]);
-                const float gg = tanhf(zg[e]);
-                cn[e] = cp[e] * gf + gg * gi;
-                hn[e] = tanhf(cn[e]) * go;
+            for (int mt = 0; mt < Cfg::MT; ++mt) {
+                const int blk = wm * Cfg::MT + mt;           // 32-row block of the tile held by this wave
+                if ((blk >> 1) != rh) continue;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int r = (blk & 1) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                        ct[r * CT_LD + (wn * NT + nt) * 32 + (lane & 31)] = acc[mt][nt][reg] * scale;
+                    }
             }
-            *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
-            if (h_out) *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
-            if (h_split) {                 // units u0 .. u0+3 = half of an 8-value block [8 x f16 hi][8 x f16 lo]
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 hi4, lo4;
-                jlm_split4(hn, h_scale, hi4, lo4);
-                _Float16 *blk = reinterpret_cast<_Float16 *>(h_split + (size_t)g * ld + (u0 & ~7)) + (u0 & 7);
-                *reinterpret_cast<f16x4 *>(blk) = hi4;
-                *reinterpret_cast<f16x4 *>(blk + 8) = lo4;
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 64 / RPP; ++it) {
+                const int r = tid / TPR + it * RPP;
+                const int row = m0 + rh * 64 + r;
+                if (row >= M) continue;
+                const int g = rows ? rows[row] : row;
+                const int p = prev[g];
+                if (xgate) {               // 4 x 16 B of the word's precomputed input-side pre-activations
+                    const float *xr = xgate + (size_t)word[g] * (size_t)(4 * ld_gate) + n0 + cb;
+                    bi = *reinterpret_cast<const f32x4 *>(xr);
+                    bf = *reinterpret_cast<const f32x4 *>(xr + 16);
+                    bo = *reinterpret_cast<const f32x4 *>(xr + 32);
+                    bg = *reinterpret_cast<const f32x4 *>(xr + 48);
+                }
+                const f32x4 zi = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb) + bi;
+                const f32x4 zf = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb + 16) + bf;
+                const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb + 32) + bo;
+                const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb + 48) + bg;
+                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+                if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
+                f32x4 cn, hn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = jlm_sigmoid(zi[e]), gf = jlm_sigmoid(zf[e]), go = jlm_sigmoid(zo[e]);
+                    const float gg = jlm_tanh(zg[e]);
+                    cn[e] = cp[e] * gf + gg * gi;
+                    hn[e] = jlm_tanh(cn[e]) * go;
+                }
+                *reinterpret_cast<f32x4 *>(c_out + (size_t)g * ld + u0) = cn;
+                if (h_out) *reinterpret_cast<f32x4 *>(h_out + (size_t)g * ld + u0) = hn;
+                if (h_split) {             // units u0 .. u0+3 = half of an 8-value block [8 x f16 hi][8 x f16 lo]
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    f16x4 hi4, lo4;
+                    jlm_split4(hn, h_scale, hi4, lo4);
+                    _Float16 *blk = reinterpret_cast<_Float16 *>(h_split + (size_t)g * ld + (u0 & ~7)) + (u0 & 7);
+                    *reinterpret_cast<f16x4 *>(blk) = hi4;
+                    *reinterpret_cast<f16x4 *>(blk + 8) = lo4;
+                }
             }
         }
     }
@@ -479,9 +505,12 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRow
             }
         };
         load(0);
+        load(1);
+        // all fragment reads of the k-step in flight before the first MFMA: left alone the scheduler
+        // sinks each read next to its use to save registers and every MFMA then waits an LDS round trip
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            if (st == 0) load(1);
             // products outer, blocks inner: consecutive MFMAs never share an accumulator (MT * NT > 1)
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr)
@@ -562,7 +591,7 @@ extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const fl
 extern "C" int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
                                    const int *rows, const int *prev, const int *word, const void *emb, int ld_emb,
                                    const void *wt, const float *bias, int kpad, int H, int E, float descale,
-                                   float h_scale, int n_rows_max, const int *n_dev, void *stream) {
+                                   float h_scale, const float *xgate, int n_rows_max, const int *n_dev, void *stream) {
     if (H % 32 != 0 || E % 16 != 0 || kpad % BK != 0 || kpad < H + E || ld_state % 16 || ld_emb % 16) return -1;
     GateRows A;
     A.h = reinterpret_cast<const float *>(h_in); A.ldh = ld_state; A.rows = rows; A.prev = prev; A.word = word;
@@ -573,11 +602,15 @@ extern "C" int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_s
     epi.c_in = c_in; epi.h_out = nullptr; epi.c_out = c_out; epi.ld = ld_state;
     epi.rows = rows; epi.prev = prev; epi.bias = bias;
     epi.scale = descale; epi.h_split = reinterpret_cast<float *>(h_out); epi.h_scale = h_scale;
-    const int tiles_n = 4 * H / 64;
-    static int big = -1;
-    if (big < 0) { const char *e = getenv("JLM_GATE_TILE"); big = e ? atoi(e) : 128; }
-    if (big == 128) return launch_gemm_split<TileCfg<2, 2, 2, 1>>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
-    return launch_gemm_split<Cfg64>(A, B, H + E, epi, (tiles_n % 8 == 0) ? 2 : 0, (hipStream_t)stream);
+    if (xgate) { epi.xgate = xgate; epi.word = word; epi.ld_gate = H; }
+    const int Kc = xgate ? H : H + E;      // with the table the contraction is over the state only
+    static int tile = -1;
+    if (tile < 0) { const char *e = getenv("JLM_GATE_TILE"); tile = e ? atoi(e) : 128; }
+    const int tiles_n = 4 * H / (tile == 256 ? 128 : 64);
+    const int xcd = (tiles_n % 8 == 0) ? 2 : 0;
+    if (tile == 256 && (4 * H) % 128 == 0) return launch_gemm_split<Cfg128>(A, B, Kc, epi, xcd, (hipStream_t)stream);
+    if (tile == 128) return launch_gemm_split<TileCfg<2, 2, 2, 1>>(A, B, Kc, epi, xcd, (hipStream_t)stream);
+    return launch_gemm_split<Cfg64>(A, B, Kc, epi, xcd, (hipStream_t)stream);
 }
 
 extern "C" int jlm_gemm_nt_split(const void *Ap, int lda, const int *a_rows, const void *Bp, int ldb, const int *b_rows,

@@ -102,8 +102,9 @@ class FakeLib:
         out[row_ids, :nb, 1, :] = lo.reshape(len(row_ids), nb, 8)
 
     def jlm_lstm_step_split(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,
-                            descale, h_scale, n_rows_max, n_dev, stream):
-        if H % 32 or E % 16 or kpad % 32 or kpad < H + E or ld % 16 or ld_emb % 16:
+                            descale, h_scale, xgate, n_rows_max, n_dev, stream):
+        table = _p(xgate) != 0
+        if H % 32 or kpad % 32 or ld % 16 or (not table and (E % 16 or kpad < H + E or ld_emb % 16)):
             return -1
         n = _n(n_rows_max, n_dev)
         if n == 0:
@@ -115,16 +116,21 @@ class FakeLib:
         hmax = max(gmax, int(p.max()) + 1)
         hin = self._split_read(h_in, hmax, ld)
         cin = view(c_in, hmax * ld, np.float32).reshape(hmax, ld)
-        embv = self._split_read(emb, int(w.max()) + 1, ld_emb)
         x = np.zeros((n, kpad), dtype=np.float64)
         ok = p >= 0
         x[ok, :H] = hin[p[ok], :H]
-        x[:, H:H + E] = embv[w, :E]
+        if not table:
+            x[:, H:H + E] = self._split_read(emb, int(w.max()) + 1, ld_emb)[w, :E]
         cp = np.zeros((n, H), dtype=np.float32)
         cp[ok] = cin[p[ok], :H]
         W = self._split_read(wt, 4 * H, kpad)
-        b = view(bias, 4 * H, np.float32)
-        z = ((x @ W.T) * float(descale)).astype(np.float32) + b
+        if table:
+            W = W.copy()
+            W[:, H:] = 0.0
+            add = view(xgate, (int(w.max()) + 1) * 4 * H, np.float32).reshape(-1, 4 * H)[w]
+        else:
+            add = view(bias, 4 * H, np.float32)
+        z = ((x @ W.T) * float(descale)).astype(np.float32) + add
         u = np.arange(H)
         zi, zf, zo, zg = (z[:, (u // 16) * 64 + k * 16 + (u % 16)] for k in range(4))
         sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)

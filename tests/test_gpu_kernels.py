@@ -169,8 +169,9 @@ def test_lstm_step_split(L, H, E, R, use_rows):
     torch.cuda.synchronize()
     hs_c, es_c, ws_c = hs.cpu(), es.cpu(), ws.cpu()
     hos_c = hs_c if use_rows else torch.zeros_like(hs_c)
-    cc, _ = _pair(c.numpy().copy() if not use_rows else cg.cpu().numpy().copy())
-    args = (kps, H, E16, 2.0 ** -20, 2.0 ** 14, R)
+    c_orig = cg.cpu().numpy().copy()
+    cc, _ = _pair(c_orig.copy())
+    args = (kps, H, E16, 2.0 ** -20, 2.0 ** 14, None, R)
     cog_in = cg
     assert L.jlm_lstm_step_split(hs.data_ptr(), cog_in.data_ptr(), H, hos.data_ptr(), cog.data_ptr(), rpg, prevg.data_ptr(),
                                  wordg.data_ptr(), es.data_ptr(), E16, ws.data_ptr(), biasg.data_ptr(), *args, ndpg,
@@ -186,6 +187,19 @@ def test_lstm_step_split(L, H, E, R, use_rows):
                                   word.data_ptr(), es_c.data_ptr(), E16, ws_c.data_ptr(), bias.data_ptr(), *args, ndp, 0) == 0
     np.testing.assert_allclose(h_gpu[sel], (_unsplit(hos_c) / 2.0 ** 14)[sel], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(cog.cpu().numpy()[sel], co2.numpy()[sel], rtol=2e-5, atol=2e-6)
+    # input side as a table lookup: xgate[w] = emb[w] . W_x^T + bias, contraction over the state only
+    xg = (emb.numpy().astype(np.float64) @ wt_np[:, H:H + E].astype(np.float64).T + bias.numpy()).astype(np.float32)
+    xgg = torch.as_tensor(xg).cuda()
+    hs2 = _pack(L, hg, H, 2.0 ** 14)
+    hos2 = hs2 if use_rows else torch.zeros_like(hs2)
+    cg2 = torch.as_tensor(c_orig.copy()).cuda()
+    cog2 = cg2 if use_rows else torch.zeros_like(cg2)
+    assert L.jlm_lstm_step_split(hs2.data_ptr(), cg2.data_ptr(), H, hos2.data_ptr(), cog2.data_ptr(), rpg, prevg.data_ptr(),
+                                 wordg.data_ptr(), None, 0, ws.data_ptr(), None, kps, H, 0, 2.0 ** -20, 2.0 ** 14,
+                                 xgg.data_ptr(), R, ndpg, _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose((_unsplit(hos2) / 2.0 ** 14)[sel], ho.numpy()[sel], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(cog2.cpu().numpy()[sel], co.numpy()[sel], rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("M,N,K,maps", [(70, 40, 32, False), (300, 352, 512, True), (2560, 352, 512, True), (1, 8, 16, False)])

@@ -156,10 +156,16 @@ def bench_gate_split(H, E, R):
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     f = lambda: L.jlm_lstm_step_split(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(),
                                       prev.data_ptr(), word.data_ptr(), emb.data_ptr(), E16, wt.data_ptr(), bias.data_ptr(),
-                                      kps, H, E16, 2.0 ** -20, 2.0 ** 14, R, nd.data_ptr(), st)
+                                      kps, H, E16, 2.0 ** -20, 2.0 ** 14, None, R, nd.data_ptr(), st)
     assert f() == 0
     report("lstm_step_split H=%d E=%d R=%d tile=%s" % (H, E, R, os.environ.get("JLM_GATE_TILE", "128")),
            2.0 * (H + E) * 4 * H * R, timeit(f))
+    xg = rnd(V, 4 * H)
+    f2 = lambda: L.jlm_lstm_step_split(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(),
+                                       prev.data_ptr(), word.data_ptr(), None, 0, wt.data_ptr(), None,
+                                       kps, H, 0, 2.0 ** -20, 2.0 ** 14, xg.data_ptr(), R, nd.data_ptr(), st)
+    assert f2() == 0
+    report("lstm_step_split+xgate-table H=%d E=%d R=%d" % (H, E, R), 2.0 * (H + E) * 4 * H * R, timeit(f2))
 
 
 def bench_gemm_split(M, N, K, tag):
