@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 1
+#define JLM_ABI_VERSION 2
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
 int jlm_device_arch(int dev, char *buf, int buflen);
@@ -223,6 +223,14 @@ typedef struct {
     int *live;                    /* [n_frames*rmax] compact list of rows to step per frame */
     int *n_live;                  /* [n_frames] */
     const float *edge;            /* [n_nodes*beam] edge logits */
+    /* -- ABI 2: fused K6 tail.  live_base[(frame, sentence)] = position of the sentence's first row
+     * in live[frame] (written by jlm_beam_step when it lists the rows; may be NULL).  lse_part != NULL
+     * (mode 0 only): the n_parts partial slices [n_parts][ld_part] of (max, sum exp) pairs that
+     * jlm_vocab_lse_* left for the rows of frame - 1, indexed by live position, are folded into
+     * lse[] by jlm_beam_step(frame) itself -- no jlm_lse_combine launch in between. */
+    int *live_base;               /* [n_frames*n_sent] */
+    const float *lse_part;
+    int ld_part, n_parts;
 } jlm_beam_state;
 
 /* K7+K8: candidate scoring and stable per-sentence top-k for frame `frame`.

@@ -31,7 +31,8 @@ class BeamState(Structure):
     _fields_ = [("score", c_void_p), ("lse", c_void_p), ("ysum", c_void_p),
                 ("bp", c_void_p), ("node", c_void_p), ("word", c_void_p),
                 ("cnt", c_void_p), ("live", c_void_p), ("n_live", c_void_p),
-                ("edge", c_void_p)]
+                ("edge", c_void_p),
+                ("live_base", c_void_p), ("lse_part", c_void_p), ("ld_part", c_int), ("n_parts", c_int)]
 
 
 P = c_void_p
@@ -82,7 +83,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 1:
+        if l.jlm_abi_version() != 2:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

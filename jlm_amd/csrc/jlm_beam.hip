@@ -209,8 +209,21 @@ extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const 
 // + slot enumerates (node, previous hypothesis) pairs in the reference's
 // generation order (outer loop nodes, inner loop previous paths:
 // decoder/decoder.py:172-182), so a lexicographic (score, c) minimum reproduces
-// Python's stable sort.  Selection: `beam` rounds of a wave-wide arg-min over
-// keys kept in LDS; the winner is struck out by writing +inf.
+// Python's stable sort.
+//
+// Lane l owns the candidates c = l, l + 64, ...: it writes their keys (and their
+// predecessor rows) to LDS and is the only lane that ever reads them back, so the
+// selection needs no workgroup synchronisation: every lane carries the minimum of
+// its own candidates in registers, one round = a wave-wide arg-min over those 64
+// pairs, after which only the winner's owner strikes its key and rescans its
+// <= ceil(C / 64) entries.  Lane r remembers the r-th winner and all K rows are
+// written together at the end (one round of global latency instead of K).
+//
+// Fused K6 tail (st.lse_part != NULL, mode 0): the (max, sum exp) partial slices that
+// the vocabulary kernel left for this sentence's rows of frame - 1 are folded here --
+// 8 lanes per row, slices strided over them, 3 xor-shuffle steps -- instead of in a
+// separate jlm_lse_combine launch; the rows' positions in the slices are
+// live_base[(frame - 1, sentence)] + slot, recorded when the rows were listed.
 __device__ __forceinline__ void wave_argmin(double &v, int &i) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -221,8 +234,8 @@ __device__ __forceinline__ void wave_argmin(double &v, int &i) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam_state st, int frame) {
-    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] (+ [n_frames*beam] for MODE 2)
+__global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam_state st, int frame, int max_cands) {
+    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] | MODE 2: [n_frames*beam] | int [max_cands] | [beam]
     const int s = blockIdx.x, lane = threadIdx.x;
     const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
     const int len = lat.sent_len[s];
@@ -231,19 +244,51 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
     const int nb = lat.end_off[fs], ne = lat.end_off[fs + 1];
     const int gout = frame * rmax + s * beam;
     const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    double *Sarr = keys + max_cands;                                       // MODE 2 only
+    int *gp_of = reinterpret_cast<int *>(Sarr + (MODE == 2 ? lat.n_frames * beam : 0));
+    double *lse_new = reinterpret_cast<double *>(gp_of + ((max_cands + 1) & ~1));   // [beam]
     int K;
+    double win_v = 0.0;
+    int win_i = 0;
     if (frame == 0) {
         K = 1;
-        if (lane == 0) {
-            st.score[gout] = 0.0;
-            if (st.ysum) st.ysum[gout] = 0.0;
-            st.bp[gout] = -1;
-            st.node[gout] = nb;
-            st.word[gout] = lat.node_word[nb];
-        }
+        if (lane == 0) { win_v = 0.0; win_i = -1; }
     } else {
+        // ---- fused fold of the previous frame's vocabulary partials (this sentence's rows)
+        const bool fused = MODE == 0 && st.lse_part != nullptr;
+        const int fprev = (frame - 1) * B + s;
+        const int kprev = st.cnt[fprev];
+        if (fused && kprev > 0) {
+            const int base = st.live_base[fprev];
+            const float2 *part = reinterpret_cast<const float2 *>(st.lse_part);
+            const int sub = lane & 7;
+            for (int r0 = 0; r0 < kprev; r0 += 8) {
+                const int r = r0 + (lane >> 3);
+                float m = JLM_NEG_BIG;
+                double sm = 0.0;
+                if (r < kprev)
+                    for (int p = sub; p < st.n_parts; p += 8) {
+                        const float2 v = part[(size_t)p * st.ld_part + base + r];
+                        const float mm = fmaxf(m, v.x);
+                        sm = sm * (double)expf(m - mm) + (double)v.y * (double)expf(v.x - mm);
+                        m = mm;
+                    }
+#pragma unroll
+                for (int off = 4; off >= 1; off >>= 1) {
+                    const float m2 = __shfl_xor(m, off);
+                    const double s2 = __shfl_xor(sm, off);
+                    const float mm = fmaxf(m, m2);
+                    sm = sm * (double)expf(m - mm) + s2 * (double)expf(m2 - mm);
+                    m = mm;
+                }
+                if (sub == 0 && r < kprev) {
+                    const double l = (double)m + log(sm);
+                    lse_new[r] = l;
+                    st.lse[(size_t)(frame - 1) * rmax + s * beam + r] = l;
+                }
+            }
+        }
         const int C = (ne - nb) * beam;
-        double *Sarr = keys + C;                       // MODE 2 only
         if (MODE == 2) {
             // S(g) = sum of the CURRENT log-normalisers of g's ancestors: every path is
             // re-scored from the head (decoder_dynamic.py:150-175), frame by frame.
@@ -262,53 +307,78 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
                 __syncthreads();
             }
         }
+        __syncthreads();                                   // lse_new (and Sarr) visible to every lane
+        // ---- keys of this lane's candidates, its running minimum
         int nvalid = 0;
+        double bv = INF;
+        int bi = 0x7fffffff;
         for (int c = lane; c < C; c += 64) {
             const int n = nb + c / beam, k = c % beam;
             const int sf = lat.node_start[n];
             double sc = INF;
+            int gp = -1;
             if (k < st.cnt[sf * B + s]) {
-                const int gp = sf * rmax + s * beam + k;
+                gp = sf * rmax + s * beam + k;
                 const double e = (double)st.edge[(size_t)n * beam + k];
-                if (MODE == 0) sc = st.score[gp] + (st.lse[gp] - e);
+                if (MODE == 0) sc = st.score[gp] + (((fused && sf == frame - 1) ? lse_new[k] : st.lse[gp]) - e);
                 else if (MODE == 1) sc = st.score[gp] - e;
                 else sc = (Sarr[sf * beam + k] + st.lse[gp]) - (st.ysum[gp] + e);
                 ++nvalid;
             }
             keys[c] = sc;
+            gp_of[c] = gp;
+            if (sc < bv) { bv = sc; bi = c; }              // ascending c: ties keep the lower index
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nvalid += __shfl_xor(nvalid, off);
-        __syncthreads();
         K = min(beam, nvalid);
+        // ---- K rounds of selection, registers + the owner's private LDS entries only
         for (int r = 0; r < K; ++r) {
-            double bv = INF;
-            int bi = 0x7fffffff;
-            for (int c = lane; c < C; c += 64) {
-                const double v = keys[c];
-                if (v < bv || (v == bv && c < bi)) { bv = v; bi = c; }
+            double v = bv;
+            int i = bi;
+            wave_argmin(v, i);
+            if (lane == r) { win_v = v; win_i = i; }
+            if ((i & 63) == lane) {
+                keys[i] = INF;
+                bv = INF;
+                bi = 0x7fffffff;
+                for (int c = lane; c < C; c += 64) {
+                    const double kv = keys[c];
+                    if (kv < bv) { bv = kv; bi = c; }
+                }
             }
-            wave_argmin(bv, bi);
-            if (lane == 0) {
-                const int n = nb + bi / beam, k = bi % beam;
-                const int gp = lat.node_start[n] * rmax + s * beam + k;
-                st.score[gout + r] = bv;
-                if (MODE == 2) st.ysum[gout + r] = st.ysum[gp] + (double)st.edge[(size_t)n * beam + k];
-                st.bp[gout + r] = gp;
-                st.node[gout + r] = n;
-                st.word[gout + r] = lat.node_word[n];
-                keys[bi] = INF;
-            }
-            __syncthreads();
+        }
+        __syncthreads();                                   // gp_of of other lanes' candidates
+    }
+    // ---- the K surviving hypotheses, one lane each
+    if (lane < K) {
+        const int g = gout + lane;
+        if (frame == 0) {
+            st.score[g] = 0.0;
+            if (st.ysum) st.ysum[g] = 0.0;
+            st.bp[g] = -1;
+            st.node[g] = nb;
+            st.word[g] = lat.node_word[nb];
+        } else {
+            const int n = nb + win_i / beam, k = win_i % beam;
+            const int gp = gp_of[win_i];
+            st.score[g] = win_v;
+            if (MODE == 2) st.ysum[g] = st.ysum[gp] + (double)st.edge[(size_t)n * beam + k];
+            st.bp[g] = gp;
+            st.node[g] = n;
+            st.word[g] = lat.node_word[n];
         }
     }
+    int base = 0;
     if (lane == 0) {
         st.cnt[fs] = K;
         if (frame < len) {      // the last frame's LSTM step is never consumed (decoder.py:233-237)
-            const int base = atomicAdd(&st.n_live[frame], K);
-            for (int r = 0; r < K; ++r) st.live[(size_t)frame * rmax + base + r] = gout + r;
+            base = atomicAdd(&st.n_live[frame], K);
+            if (st.live_base) st.live_base[fs] = base;
         }
     }
+    base = __shfl(base, 0);
+    if (frame < len && lane < K) st.live[(size_t)frame * rmax + base + lane] = gout + lane;
 }
 
 extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int frame, int mode,
@@ -317,9 +387,12 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     const jlm_beam_state st = *st_host;
     if (lat.n_sent <= 0) return 0;
     if (mode == 2 && !st.ysum) return -1;
-    size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0);
-    if (lds > 160 * 1024) return -1;
     if (mode < 0 || mode > 2) return -1;
+    if (st.lse_part && (!st.live_base || st.n_parts < 1 || mode != 0)) return -1;
+    if (max_cands < 1) max_cands = 1;
+    size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0) +
+                 (size_t)((max_cands + 1) & ~1) * sizeof(int) + (size_t)lat.beam * sizeof(double);
+    if (lds > 160 * 1024) return -1;
     const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
                    : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;
     static size_t attr[3] = {0, 0, 0};
@@ -328,9 +401,9 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
         if (e != hipSuccess) return (int)e;
         attr[mode] = lds;
     }
-    if (mode == 0) hipLaunchKernelGGL(beam_step_kernel<0>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
-    else if (mode == 1) hipLaunchKernelGGL(beam_step_kernel<1>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
-    else hipLaunchKernelGGL(beam_step_kernel<2>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame);
+    if (mode == 0) hipLaunchKernelGGL(beam_step_kernel<0>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);
+    else if (mode == 1) hipLaunchKernelGGL(beam_step_kernel<1>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);
+    else hipLaunchKernelGGL(beam_step_kernel<2>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);
     JLM_LAUNCH_CHECK();
     return 0;
 }

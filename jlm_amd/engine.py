@@ -85,6 +85,7 @@ class _Plan:
         self.bp, self.node, self.word = e(G, i32), e(G, i32), e(G, i32)
         self.cnt = torch.zeros(ncell, device=dev, dtype=i32)
         self.live = e(G, i32)
+        self.live_base = torch.zeros(ncell, device=dev, dtype=i32)
         self.n_live = torch.zeros(F, device=dev, dtype=i32)
         self.edge = e(max(caps["nodes"], 1) * beam, f32)
         H, ldt = m.H, m.ldt
@@ -113,7 +114,7 @@ class _Plan:
         self.stS = _lib.BeamState(self.score.data_ptr(), self.lse.data_ptr(),
                                   self.ysum.data_ptr() if dynamic else None, self.bp.data_ptr(), self.node.data_ptr(),
                                   self.word.data_ptr(), self.cnt.data_ptr(), self.live.data_ptr(), self.n_live.data_ptr(),
-                                  self.edge.data_ptr())
+                                  self.edge.data_ptr(), self.live_base.data_ptr(), None, 0, 0)
         self.graph = None
         self.warm = False
 
@@ -189,6 +190,7 @@ class DecodeEngine:
         p.n_live.zero_()
         ev = []
         join = None
+        pending_parts = 0
         for f in range(F):
             if join is not None:
                 main.wait_event(join)
@@ -199,7 +201,11 @@ class DecodeEngine:
                                               ip["dd_words"], ip["dd_off"], ip["sidx"], f * B,
                                               p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 1, beam, (f - 1) * B, st),
                            "jlm_wordlist_lse(merge)")
+            # the full-vocabulary normaliser of frame f-1 left partial slices: beam_step folds them itself
+            p.stS.lse_part = p.part.data_ptr() if pending_parts else None
+            p.stS.ld_part, p.stS.n_parts = rmax, pending_parts
             _lib.check(L.jlm_beam_step(p.latS, p.stS, f, mode, cands, st), "jlm_beam_step")
+            pending_parts = 0
             if f == F - 1:
                 break
             rows = livep + 4 * f * rmax
@@ -236,7 +242,8 @@ class DecodeEngine:
                                                   p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 0, beam, B, st),
                                "jlm_wordlist_lse(vocab_select)")
                 else:
-                    m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, rmax, ndev, st, self.recorder)
+                    pending_parts = m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, rmax, ndev, st,
+                                                      self.recorder, combine=False)
             if timing:
                 e2.record()
                 ev.append((e0, e1, e2))

@@ -352,10 +352,11 @@ class DeviceModel:
             _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
                                      n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
 
-    def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None):
+    def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None, combine=True):
         """lse[g] over the full vocabulary for the listed rows (K5+K6 fused).
         Rows-stationary kernel when every segment's k <= 256, else one tile GEMM
-        per segment."""
+        per segment.  combine=False leaves the partial slices for jlm_beam_step to
+        fold (jlm_beam_state.lse_part); returns the number of slices."""
         L = _lib.lib()
         if self.stationary_ok:
             if rec is not None:
@@ -386,7 +387,9 @@ class DeviceModel:
                 if r < 0:
                     raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
                 n_parts += r
-        _lib.check(L.jlm_lse_combine(part, ld_part, n_parts, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
+        if combine:
+            _lib.check(L.jlm_lse_combine(part, ld_part, n_parts, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
+        return n_parts
 
 
 class LSTM_Model():

@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 1
+        return 2
 
     # ------------------------------------------------------------------ K1-K3
     def jlm_lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,
@@ -361,11 +361,23 @@ class FakeLib:
         live = view(st.live, G, np.int32)
         n_live = view(st.n_live, F, np.int32)
         edge = view(st.edge, max(n_nodes, 1) * beam, np.float32)
+        live_base = view(st.live_base, F * B, np.int32) if _p(st.live_base) else None
+        fused = _p(st.lse_part) != 0
+        if fused:
+            if live_base is None or st.n_parts < 1 or mode != 0:
+                return -1
+            pv = view(st.lse_part, st.n_parts * st.ld_part * 2, np.float32).reshape(st.n_parts, st.ld_part, 2).astype(np.float64)
         for s in range(B):
             fs = frame * B + s
             if frame > slen[s]:
                 cnt[fs] = 0
                 continue
+            if fused and frame >= 1:           # fold the vocabulary partials of this sentence's rows of frame - 1
+                fp = (frame - 1) * B + s
+                for r in range(int(cnt[fp])):
+                    q = pv[:, int(live_base[fp]) + r]
+                    mx = q[:, 0].max()
+                    lse[(frame - 1) * rmax + s * beam + r] = mx + np.log((q[:, 1] * np.exp(q[:, 0] - mx)).sum())
             nb, ne = int(end_off[fs]), int(end_off[fs + 1])
             gout = frame * rmax + s * beam
             if frame == 0:
@@ -407,6 +419,8 @@ class FakeLib:
             cnt[fs] = K
             if frame < slen[s]:
                 base = int(n_live[frame])
+                if live_base is not None:
+                    live_base[fs] = base
                 n_live[frame] = base + K
                 live[frame * rmax + base: frame * rmax + base + K] = np.arange(gout, gout + K)
         return 0

@@ -536,6 +536,64 @@ def test_beam_step_and_backtrace(L, mode, B, beam, F, max_nodes):
         np.testing.assert_array_equal(got["on"][i, :want["ol"][i]], want["on"][i, :want["ol"][i]])
 
 
+def _run_beam_fused(lib, P, cuda, n_parts):
+    """mode 0 with the log-normalisers arriving as partial (max, sum exp) slices indexed by live
+    position, folded inside jlm_beam_step (jlm_beam_state.lse_part)"""
+    dev = "cuda" if cuda else "cpu"
+    t = lambda a: torch.as_tensor(a).contiguous().to(dev)
+    G, F, B, beam, rmax = P["G"], P["F"], P["B"], P["beam"], P["rmax"]
+    rng = np.random.default_rng(11)
+    ints = {k: t(P[k]) for k in ("slen", "end_off", "nstart", "nword")}
+    score, lse = t(np.zeros(G)), t(np.full(G, 1e30))                    # lse must come from the slices
+    edge = t((np.round(rng.standard_normal(max(P["N"], 1) * beam) * 2.0) / 2.0).astype(np.float32))
+    bp, node, word = (t(np.full(G, -7, dtype=np.int32)) for _ in range(3))
+    cnt, live, n_live = t(np.zeros(F * B, dtype=np.int32)), t(np.full(G, -1, dtype=np.int32)), t(np.zeros(F, dtype=np.int32))
+    live_base = t(np.zeros(F * B, dtype=np.int32))
+    part = t(np.zeros((n_parts, rmax, 2), dtype=np.float32))
+    lat = _lib.Lattice(B, beam, F, ints["slen"].data_ptr(), ints["end_off"].data_ptr(), ints["nstart"].data_ptr(),
+                       ints["nword"].data_ptr())
+    st = _lib.BeamState(score.data_ptr(), lse.data_ptr(), None, bp.data_ptr(), node.data_ptr(), word.data_ptr(),
+                        cnt.data_ptr(), live.data_ptr(), n_live.data_ptr(), edge.data_ptr(), live_base.data_ptr(), None, 0, 0)
+    stream = _st() if cuda else 0
+    for f in range(F):
+        if f >= 1:
+            if cuda:
+                torch.cuda.synchronize()
+            nl = int(n_live[f - 1].item())
+            lv = live[(f - 1) * rmax:(f - 1) * rmax + nl].cpu().numpy().astype(np.int64)
+            pn = np.zeros((n_parts, rmax, 2), dtype=np.float32)
+            for q in range(n_parts):
+                # slice maxima either equal or 200 below (exp underflows identically in f32 and f64): exact fold
+                pn[q, :nl, 0] = 3.0 + (lv % 5) - 200.0 * ((lv + q) % 3 == 0)
+                pn[q, :nl, 1] = 1.0 + ((lv + 3 * q) % 7) * 0.5
+            pn[0, :nl, 0] = 3.0 + (lv % 5)
+            part.copy_(t(pn))
+            st.lse_part, st.ld_part, st.n_parts = part.data_ptr(), rmax, n_parts
+        assert lib.jlm_beam_step(lat, st, f, 0, P["max_cands"], stream) == 0
+    if cuda:
+        torch.cuda.synchronize()
+    out = dict(score=score, bp=bp, node=node, word=word, cnt=cnt, n_live=n_live, lse=lse)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("B,beam,F,max_nodes,n_parts", [(7, 10, 9, 12, 24), (64, 3, 6, 40, 5), (3, 20, 22, 70, 96)])
+def test_beam_step_fused_combine(L, B, beam, F, max_nodes, n_parts):
+    P = _beam_problem(np.random.default_rng(B * 100 + beam + F), B, beam, F, max_nodes)
+    want = _run_beam_fused(FK, P, False, n_parts)
+    got = _run_beam_fused(L, P, True, n_parts)
+    np.testing.assert_array_equal(got["cnt"], want["cnt"])
+    rmax = P["rmax"]
+    for f in range(F):
+        for s in range(B):
+            k = int(want["cnt"][f * B + s])
+            sl = slice(f * rmax + s * beam, f * rmax + s * beam + k)
+            for name in ("bp", "node", "word"):
+                np.testing.assert_array_equal(got[name][sl], want[name][sl], err_msg="%s f=%d s=%d" % (name, f, s))
+            np.testing.assert_allclose(got["score"][sl], want["score"][sl], rtol=0, atol=1e-9)
+            if f < F - 1 and f < int(P["slen"][s]):
+                np.testing.assert_allclose(got["lse"][sl], want["lse"][sl], rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("R,C,sn", [(3, 2000, 0), (10, 50000, 0), (4, 301, 1)])
 def test_softmax_rows(L, R, C, sn):
     rng = np.random.default_rng(R + C)
