@@ -4,6 +4,7 @@
 // bound integer + scalar work: one 64-lane wave (or one workgroup) per sentence,
 // wavefront shuffles for the reductions, no MFMA.
 #include "jlm_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 // ------------------------------------------------------------ word-list logits
@@ -224,18 +225,36 @@ extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const 
 // 8 lanes per row, slices strided over them, 3 xor-shuffle steps -- instead of in a
 // separate jlm_lse_combine launch; the rows' positions in the slices are
 // live_base[(frame - 1, sentence)] + slot, recorded when the rows were listed.
+// Wave-wide lexicographic minimum of (v, i), result in every lane.  DPP cross-lane moves (a few
+// cycles each) instead of __shfl_xor, which is ds_bpermute on this ISA: three dependent LDS-crossbar
+// round trips per step made one selection round 0.9 us (8.8 of the kernel's 19 us for beam = 10).
+// Mirror steps leave every lane of a 16-lane row with the row's minimum; row_bcast15 / 31 carry it to
+// the last row; lane 63 holds the wave's and is read back through SGPRs.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_dpp_step(double &v, int &i) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int i2 = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    const double v2 = __hiloint2double(hi2, lo2);
+    if (v2 < v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
 __device__ __forceinline__ void wave_argmin(double &v, int &i) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double v2 = __shfl_xor(v, off);
-        int i2 = __shfl_xor(i, off);
-        if (v2 < v || (v2 == v && i2 < i)) { v = v2; i = i2; }
-    }
+    argmin_dpp_step<0xB1, 0xf>(v, i);      // quad_perm(1,0,3,2)
+    argmin_dpp_step<0x4E, 0xf>(v, i);      // quad_perm(2,3,0,1)
+    argmin_dpp_step<0x141, 0xf>(v, i);     // row_half_mirror
+    argmin_dpp_step<0x140, 0xf>(v, i);     // row_mirror
+    argmin_dpp_step<0x142, 0xa>(v, i);     // row_bcast15 into rows 1 and 3
+    argmin_dpp_step<0x143, 0xc>(v, i);     // row_bcast31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    i = __builtin_amdgcn_readlane(i, 63);
+    v = __hiloint2double(hi, lo);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam_state st, int frame, int max_cands) {
-    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] | MODE 2: [n_frames*beam] | int [max_cands] | [beam]
+    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] | MODE 2: [n_frames*beam] | int [max_cands] | [beam] | int [n_frames]
     const int s = blockIdx.x, lane = threadIdx.x;
     const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
     const int len = lat.sent_len[s];
@@ -247,6 +266,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
     double *Sarr = keys + max_cands;                                       // MODE 2 only
     int *gp_of = reinterpret_cast<int *>(Sarr + (MODE == 2 ? lat.n_frames * beam : 0));
     double *lse_new = reinterpret_cast<double *>(gp_of + ((max_cands + 1) & ~1));   // [beam]
+    int *cnt_s = reinterpret_cast<int *>(lse_new + beam);                           // [n_frames] this sentence's counts
     int K;
     double win_v = 0.0;
     int win_i = 0;
@@ -257,6 +277,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
         // ---- fused fold of the previous frame's vocabulary partials (this sentence's rows)
         const bool fused = MODE == 0 && st.lse_part != nullptr;
         const int fprev = (frame - 1) * B + s;
+        for (int f = lane; f < frame; f += 64) cnt_s[f] = st.cnt[f * B + s];
         const int kprev = st.cnt[fprev];
         if (fused && kprev > 0) {
             const int base = st.live_base[fprev];
@@ -308,27 +329,61 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
             }
         }
         __syncthreads();                                   // lse_new (and Sarr) visible to every lane
-        // ---- keys of this lane's candidates, its running minimum
+        // ---- keys of this lane's candidates, its running minimum.  Four candidates at a time with the
+        //      loads of each dependency level issued together (start frame; then score / lse / edge of
+        //      the predecessor): a round trip per level and group instead of three per candidate --
+        //      these chains, not the selection, were 18 of the kernel's 22 us.
         int nvalid = 0;
         double bv = INF;
         int bi = 0x7fffffff;
-        for (int c = lane; c < C; c += 64) {
-            const int n = nb + c / beam, k = c % beam;
-            const int sf = lat.node_start[n];
-            double sc = INF;
-            int gp = -1;
-            if (k < st.cnt[sf * B + s]) {
-                gp = sf * rmax + s * beam + k;
-                const double e = (double)st.edge[(size_t)n * beam + k];
-                if (MODE == 0) sc = st.score[gp] + (((fused && sf == frame - 1) ? lse_new[k] : st.lse[gp]) - e);
-                else if (MODE == 1) sc = st.score[gp] - e;
-                else sc = (Sarr[sf * beam + k] + st.lse[gp]) - (st.ysum[gp] + e);
-                ++nvalid;
+        constexpr int U = 4, NREG = 8;                     // the lane's first NREG candidates live in registers
+        double kreg[NREG];
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) kreg[j] = INF;
+        auto group = [&](int it, auto REG0) {              // candidates lane + 64 (U it + u), u < U
+            constexpr int reg0 = decltype(REG0)::value;    // first register slot of the group, or -1: keys[] in LDS
+            const int c0 = lane + 64 * U * it;
+            int n[U], k[U], sf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = min(c0 + 64 * u, C - 1);     // past the end: a duplicate, discarded below
+                n[u] = nb + c / beam;
+                k[u] = c % beam;
+                sf[u] = lat.node_start[n[u]];
             }
-            keys[c] = sc;
-            gp_of[c] = gp;
-            if (sc < bv) { bv = sc; bi = c; }              // ascending c: ties keep the lower index
-        }
+            bool ok[U];
+            int gp[U];
+            double scv[U], lsv[U], ysv[U];
+            float ev[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = (c0 + 64 * u < C) && k[u] < cnt_s[sf[u]];
+                gp[u] = sf[u] * rmax + s * beam + (ok[u] ? k[u] : 0);
+                ev[u] = st.edge[(size_t)n[u] * beam + k[u]];
+                scv[u] = (MODE == 2) ? 0.0 : st.score[gp[u]];
+                lsv[u] = (MODE == 1) ? 0.0 : st.lse[gp[u]];
+                ysv[u] = (MODE == 2) ? st.ysum[gp[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + 64 * u;
+                if (c >= C) break;
+                double sc = INF;
+                if (ok[u]) {
+                    const double e = (double)ev[u];
+                    if (MODE == 0) sc = scv[u] + (((fused && sf[u] == frame - 1) ? lse_new[k[u]] : lsv[u]) - e);
+                    else if (MODE == 1) sc = scv[u] - e;
+                    else sc = (Sarr[sf[u] * beam + k[u]] + lsv[u]) - (ysv[u] + e);
+                    ++nvalid;
+                }
+                if constexpr (reg0 >= 0) kreg[reg0 + u] = sc; else keys[c] = sc;
+                gp_of[c] = ok[u] ? gp[u] : -1;
+                if (sc < bv) { bv = sc; bi = c; }          // ascending c: ties keep the lower index
+            }
+        };
+        group(0, std::integral_constant<int, 0>{});
+        if (C > 64 * U) group(1, std::integral_constant<int, U>{});
+        for (int it = 2; 64 * U * it < C; ++it) group(it, std::integral_constant<int, -1>{});
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nvalid += __shfl_xor(nvalid, off);
         K = min(beam, nvalid);
@@ -338,11 +393,17 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
             int i = bi;
             wave_argmin(v, i);
             if (lane == r) { win_v = v; win_i = i; }
-            if ((i & 63) == lane) {
-                keys[i] = INF;
+            if ((i & 63) == lane) {                        // the owner strikes the winner and rescans its own entries
+                const int jw = i >> 6;
+                if (jw >= NREG) keys[i] = INF;
                 bv = INF;
                 bi = 0x7fffffff;
-                for (int c = lane; c < C; c += 64) {
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) {
+                    if (j == jw) kreg[j] = INF;
+                    if (kreg[j] < bv) { bv = kreg[j]; bi = lane + 64 * j; }
+                }
+                for (int c = lane + 64 * NREG; c < C; c += 64) {
                     const double kv = keys[c];
                     if (kv < bv) { bv = kv; bi = c; }
                 }
@@ -391,7 +452,8 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     if (st.lse_part && (!st.live_base || st.n_parts < 1 || mode != 0)) return -1;
     if (max_cands < 1) max_cands = 1;
     size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0) +
-                 (size_t)((max_cands + 1) & ~1) * sizeof(int) + (size_t)lat.beam * sizeof(double);
+                 (size_t)((max_cands + 1) & ~1) * sizeof(int) + (size_t)lat.beam * sizeof(double) +
+                 (size_t)lat.n_frames * sizeof(int);
     if (lds > 160 * 1024) return -1;
     const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
                    : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;
