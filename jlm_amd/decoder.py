@@ -23,6 +23,7 @@ Deliberate differences (DESIGN.md "Reference quirks"):
 import gc
 import os
 import pickle
+from collections import deque
 
 from . import config as _config
 from .data import Vocab
@@ -61,6 +62,7 @@ class Decoder():
         self.model = LSTM_Model(experiment_id, comp, device=device)
         self._builder = LatticeBuilder(self.full_lexicon, self.full_reading_dict, self.w2i)
         self._engine = DecodeEngine(self.model.dev)
+        self.pipeline_depth = self._engine.n_streams      # chunks in flight in decode_batch
         self.lattice_vocab = None
         self.backward_lookup = None
         self.perf_sen = 0
@@ -107,7 +109,7 @@ class Decoder():
             raise ValueError("empty input string")
         if not inputs:
             return []
-        out, prev = [], None
+        out, inflight = [], deque()
         for i in range(0, len(inputs), self.max_batch):
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
             self.last_lattice = lat
@@ -116,13 +118,15 @@ class Decoder():
                 words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
                 vocab = (words, off)
                 self.lattice_vocab = lists[-1]
-            ticket = self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
-            if prev is not None:             # strings of chunk i-1 are built while the GPU decodes chunk i
-                out.extend(self._engine.collect(prev))
+            inflight.append(self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing))
+            # two chunks stay in flight (the engine alternates streams); the strings of chunk i-2 are
+            # built while the GPU decodes chunks i-1 and i
+            if len(inflight) > self.pipeline_depth:
+                out.extend(self._engine.collect(inflight.popleft()))
                 self._log_perf()
-            prev = ticket
-        out.extend(self._engine.collect(prev))
-        self._log_perf()
+        while inflight:
+            out.extend(self._engine.collect(inflight.popleft()))
+            self._log_perf()
         self.perf_sen += len(inputs)
         return out
 

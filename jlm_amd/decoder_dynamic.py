@@ -13,6 +13,8 @@ D-softmax* models the reference mis-assigns softmax columns in this decoder
 (SURVEY.md 8 a16); this implementation computes the self-consistent result
 instead and parity is pinned on tied-softmax models.
 """
+from collections import deque
+
 from .decoder import Decoder
 from .lattice import BatchLattice
 
@@ -37,7 +39,7 @@ class DynamicDecoder(Decoder):
             raise ValueError("empty input string")
         if not inputs:
             return []
-        out, prev = [], None
+        out, inflight = [], deque()
 
         def finish(ticket):
             out.extend(self._engine.collect(ticket))
@@ -53,10 +55,11 @@ class DynamicDecoder(Decoder):
             self.last_lattice = lat
             iw, io, dw, do, lv_final = lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i))
             self.lattice_vocab = lv_final[-1]
-            ticket = self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN, timing=self.perf_timing)
-            if prev is not None:
-                finish(prev)
-            prev = ticket
-        finish(prev)
+            inflight.append(self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN,
+                                                timing=self.perf_timing))
+            if len(inflight) > self.pipeline_depth:
+                finish(inflight.popleft())
+        while inflight:
+            finish(inflight.popleft())
         self.perf_sen += len(inputs)
         return out

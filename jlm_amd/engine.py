@@ -142,7 +142,13 @@ class DecodeEngine:
         self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "0") == "1"
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"
         self.plans = []
-        self._side = None
+        self._side = {}            # side stream of each launch stream (edge logits beside the normaliser)
+        # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
+        # (beam step, LSTM step, T projection: two thirds of the launches, a third of the time, most CUs
+        # idle) fill in beside the vocabulary kernel of batch i.  JLM_STREAMS=1 keeps one stream.
+        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "2")))
+        self._streams = []
+        self._rr = 0
 
     # ------------------------------------------------------------------ plans
     def _plan_for(self, kind, vmode, lat, need):
@@ -175,9 +181,9 @@ class DecodeEngine:
         st = main.cuda_stream if cuda else 0
         side = None
         if cuda and self.use_side and self.recorder is None and not timing:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            side = self._side
+            side = self._side.get(st)
+            if side is None:
+                side = self._side[st] = torch.cuda.Stream()
         ip = p.ip
         H, ldt = m.H, m.ldt
         hp, cp, Tp = p.h.data_ptr(), p.c.data_ptr(), p.T.data_ptr()
@@ -256,7 +262,20 @@ class DecodeEngine:
     # ----------------------------------------------------------------- decode
     def submit(self, lat, kind="static", vocab=None, dyn_lists=None, topN=10, timing=False):
         """Enqueue one batch (upload, launch sequence, asynchronous read-back) and return a
-        ticket for :meth:`collect`.  Nothing here waits for the GPU."""
+        ticket for :meth:`collect`.  Nothing here waits for the GPU.  Successive calls use
+        alternating streams (see __init__); every ticket owns its plan's buffers until collected."""
+        torch = self.torch
+        if self.device.type != "cuda" or self.n_streams < 2 or timing or self.recorder is not None:
+            return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
+        if not self._streams:
+            self._streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
+        strm = self._streams[self._rr]
+        self._rr = (self._rr + 1) % self.n_streams
+        strm.wait_stream(torch.cuda.current_stream())      # after whatever the caller queued (weight uploads, ...)
+        with torch.cuda.stream(strm):
+            return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
+
+    def _submit(self, lat, kind, vocab, dyn_lists, topN, timing):
         torch = self.torch
         dynamic = kind == "dynamic"
         vmode = "dynamic" if dynamic else ("select" if vocab is not None else "full")

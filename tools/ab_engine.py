@@ -26,15 +26,31 @@ def run_pipe(n=12):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-variants = {"eager+side": (False, True), "graph+side": (True, True), "eager": (False, False), "graph": (True, False)}
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+def run_pipe2(n=12, depth=2):
+    """consecutive steps on alternating streams: the device work of step i+1 may overlap step i's"""
+    from collections import deque
+    q = deque()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for it in range(n):
+        with torch.cuda.stream(streams[it % 2]):
+            q.append(eng.submit(lat, "static", topN=10))
+        if len(q) > depth: eng.collect(q.popleft())
+    while q: eng.collect(q.popleft())
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+variants = {"eager+side": (False, True), "2 streams d2": (False, True, 2), "2 streams d3": (False, True, 3), "eager": (False, False)}
+def run(v):
+    eng.use_graph, eng.use_side = v[0], v[1]
+    return run_pipe2(12, v[2]) if len(v) > 2 else run_pipe(12)
 for _ in range(3):
-    for g, sd in variants.values():
-        eng.use_graph, eng.use_side = g, sd
-        run_pipe(14)
+    for v in variants.values():
+        run(v)
 res = {k: [] for k in variants}
 for rep in range(8):
-    for k, (g, sd) in variants.items():
-        eng.use_graph, eng.use_side = g, sd
-        res[k].append(run_pipe(12))
+    for k, v in variants.items():
+        res[k].append(run(v))
 for k, v in res.items():
     print("%-12s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
