@@ -158,14 +158,22 @@ int jlm_gemm_nt_split(const void *A, int lda, const int *a_rows, const void *B, 
                       float *C, int ldc, const int *c_rows, const float *bias, float descale,
                       int M, int N, int K, const int *m_dev, void *stream);
 
+/* One column of split rows from a vector: dst[r][col] = split(v[r] * scale). */
+int jlm_pack_split_f16_col(const float *v, int rows, float scale, void *dst, int ld_dst, int col, void *stream);
+
 /* jlm_vocab_lse_stationary on split rows: segs[i].B = split rows of the
  * segment's output embedding scaled by 2^eB_i, segs[i].ldb their stride in
  * 4-byte units, segs[i].k the true contraction length (<= 256, multiple of 4).
  * T is plain f32 (the kernel splits its rows while loading them, after scaling
- * by t_scale[i] = 2^eT_i); descale[i] = 2^-(eT_i + eB_i).  Same partial-slice
- * contract and return value as jlm_vocab_lse_stationary. */
+ * by t_scale[i] = 2^eT_i); descale[i] = 2^-(eT_i + eB_i).
+ * bias_col (may be NULL): bias_col[i] = segs[i].k says that column k of the
+ * segment's split rows (the first padded one; needs k % 16 != 0) holds
+ * b2[word] * 2^eB_i -- the kernel then feeds 1.0 at that position of every T
+ * row and the bias costs nothing in the fold; bias_col[i] = -1: b2 is added in
+ * the fold.  Same partial-slice contract and return value as
+ * jlm_vocab_lse_stationary. */
 int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale,
-                        int n_segs, const float *b2,
+                        const int *bias_col, int n_segs, const float *b2,
                         const float *T, int ldt, const int *rows,
                         float *part, int ld_part, int max_parts,
                         int n_rows_max, const int *n_dev, void *stream);

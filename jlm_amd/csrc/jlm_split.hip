@@ -55,6 +55,27 @@ extern "C" int jlm_pack_split_f16(const float *src, int rows, int k, int ld, flo
     return 0;
 }
 
+// One column (index col) of split rows from a vector: dst[r][col] = split(v[r] * scale).
+__global__ void pack_split_col_kernel(const float *__restrict__ v, int rows, float scale, float *__restrict__ dst, int ld_dst,
+                                      int col) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    f16x2 h, l;
+    jlm_split2(v[r], 0.0f, scale, h, l);
+    _Float16 *blk = reinterpret_cast<_Float16 *>(dst + (size_t)r * ld_dst + (col & ~7)) + (col & 7);
+    blk[0] = h[0];
+    blk[8] = l[0];
+}
+
+extern "C" int jlm_pack_split_f16_col(const float *v, int rows, float scale, void *dst, int ld_dst, int col, void *stream) {
+    if (rows < 0 || ld_dst % 16 || col < 0 || col >= ld_dst) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(pack_split_col_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, rows, scale,
+                       reinterpret_cast<float *>(dst), ld_dst, col);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rows-stationary vocabulary log-sum-exp, split-f16 form.  Same structure as
 // vocab_lse_stationary_kernel (jlm_gemm.hip): a workgroup keeps 128 hypothesis rows' operands in
@@ -81,6 +102,7 @@ struct LseSplitArgs {
     float t_scale[JLM_MAX_SEGMENTS];            // log2(e) * 2^eT: applied to T before it is split
     float descale[JLM_MAX_SEGMENTS];            // 2^-(eT + eB): accumulator -> base-2 logit
     short part_first[JLM_MAX_SEGMENTS + 1];
+    short bias_col[JLM_MAX_SEGMENTS];           // >= 0: the segment's bias is column bias_col of its split rows
 };
 
 JLM_PROF_READER(jlm_prof_read_split)
@@ -92,7 +114,10 @@ extern "C" int jlm_prof_read_wg(unsigned long long *out) {
 }
 #endif
 
-template <int NS, int MT>
+// BG: the bias rides in the GEMM -- column sg.k of the split rows holds bias * 2^eB and the row operand
+// gets 1.0 there -- so the fold is max3 / fma / exp / add per logit (the fma forms acc * 2^-(eT+eB) - max
+// in one go) and stages no bias through LDS.  Needs a spare column (k % 16 != 0).
+template <int NS, int MT, bool BG>
 __device__ __forceinline__ void lse_split_body(
     const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int p_in_seg, int parts_in_seg, int pt,
     int n_paths, const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row,
@@ -139,7 +164,10 @@ __device__ __forceinline__ void lse_split_body(
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && 16 * st + 8 * h + 4 * q < K) ? xb[g & 1][j][q][e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * st + 8 * h + 4 * q + e;
+                        x[4 * q + e] = (row_ok && k < K) ? xb[g & 1][j][q][e] : (BG && row_ok && k == K) ? 1.0f : 0.0f;
+                    }
                 split8(x, t_scale, thi[st], tlo[st]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -203,7 +231,7 @@ __device__ __forceinline__ void lse_split_body(
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     JLM_PROF_MARK(p_t1);
     issue(vt0, 0, 0);
-    bias_stage(vt0);
+    if (!BG) bias_stage(vt0);
     __syncthreads();
     JLM_PROF_MARK(p_t2);
     int buf = 0;
@@ -244,7 +272,7 @@ __device__ __forceinline__ void lse_split_body(
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], thi[st], acc[mt], 0, 0, 0);
                 if (j + 1 < 4 && more) load_plane(ah, j + 1 < 4 ? j + 1 : 0, 0);
             }
-            if (last_c) bias_stage(t + 1);
+            if (!BG && last_c) bias_stage(t + 1);
             JLM_PROF_MARK(p_x);
             __syncthreads();
             JLM_PROF_ADD(p_bar, p_x);
@@ -252,31 +280,58 @@ __device__ __forceinline__ void lse_split_body(
         }
         JLM_PROF_MARK(p_x);
         // fold this tile's 16*MT logits of the lane's row into (m, s), base-2 units
-        const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
-        float tmax = JLM_NEG_BIG;
+        if (BG) {
+            if ((t + 1) * BMV > n_vocab) {         // the segment's last, partial tile: rows past it re-read its last row
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + mt * 32 + 8 * j);
+                    for (int r = 0; r < 16; ++r)
+                        if (t * BMV + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= n_vocab) acc[mt][r] = JLM_NEG_BIG;
+            }
+            float tmax = JLM_NEG_BIG;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaf(acc[mt][4 * j + e], descale, b4[e]);
-                    acc[mt][4 * j + e] = v;
-                    tmax = fmaxf(tmax, v);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, acc[mt][r]), acc[mt][r + 1]);
+            const float mn = fmaxf(m, tmax * descale);         // descale > 0
+            const float nmn = -mn;
+            float add0 = 0.0f, add1 = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    add0 += __builtin_amdgcn_exp2f(fmaf(acc[mt][r], descale, nmn));
+                    add1 += __builtin_amdgcn_exp2f(fmaf(acc[mt][r + 1], descale, nmn));
                 }
-            }
-        const float mn = fmaxf(m, tmax);
-        float add0 = 0.0f, add1 = 0.0f;
+            s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
+            m = mn;
+        } else {
+            const float *bt = bias_s + ((t - vt0) % 3) * BMV + 4 * h;
+            float tmax = JLM_NEG_BIG;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                add0 += __builtin_amdgcn_exp2f(acc[mt][r] - mn);
-                add1 += __builtin_amdgcn_exp2f(acc[mt][r + 1] - mn);
-            }
-        s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
-        m = mn;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + mt * 32 + 8 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaf(acc[mt][4 * j + e], descale, b4[e]);
+                        acc[mt][4 * j + e] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                }
+            const float mn = fmaxf(m, tmax);
+            float add0 = 0.0f, add1 = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    add0 += __builtin_amdgcn_exp2f(acc[mt][r] - mn);
+                    add1 += __builtin_amdgcn_exp2f(acc[mt][r + 1] - mn);
+                }
+            s = s * __builtin_amdgcn_exp2f(m - mn) + (add0 + add1);
+            m = mn;
+        }
         JLM_PROF_ADD(p_fold, p_x);
     }
     JLM_PROF_FLUSH();
@@ -314,12 +369,19 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
 #ifdef JLM_PROFILE
     const unsigned long long wg_t0 = wall_clock64();
 #endif
-    if (ns <= 2) lse_split_body<2, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
-    else if (ns <= 4) lse_split_body<4, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
-    else if (ns <= 7) lse_split_body<7, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
-    else if (ns <= 10) lse_split_body<10, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
-    else if (ns <= 13) lse_split_body<13, 4>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
-    else lse_split_body<16, 2>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);
+#define JLM_LSE_CASE(NS_, MT_)                                                                                   \
+    do {                                                                                                         \
+        if (bg) lse_split_body<NS_, MT_, true>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);  \
+        else lse_split_body<NS_, MT_, false>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);    \
+    } while (0)
+    const bool bg = a.bias_col[si] >= 0;
+    if (ns <= 2) JLM_LSE_CASE(2, 4);
+    else if (ns <= 4) JLM_LSE_CASE(4, 4);
+    else if (ns <= 7) JLM_LSE_CASE(7, 4);
+    else if (ns <= 10) JLM_LSE_CASE(10, 4);
+    else if (ns <= 13) JLM_LSE_CASE(13, 4);
+    else JLM_LSE_CASE(16, 2);
+#undef JLM_LSE_CASE
 #ifdef JLM_PROFILE
     if (threadIdx.x == 0 && b < 1024) {
         jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si; jlm_prof_wg[b][3] = pt;
@@ -329,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
 
 // Host side: ranges per segment in proportion to their cost, one resident round of workgroups.
 // Returns the number of partial slices written (fold them with jlm_lse_combine), or <0.
-extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale, int n_segs,
-                                   const float *b2, const float *T, int ldt, const int *rows, float *part, int ld_part,
-                                   int max_parts, int n_rows_max, const int *n_dev, void *stream) {
+extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale,
+                                   const int *bias_col, int n_segs, const float *b2, const float *T, int ldt, const int *rows,
+                                   float *part, int ld_part, int max_parts, int n_rows_max, const int *n_dev, void *stream) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
     LseSplitArgs a;
     a.n_segs = n_segs;
@@ -343,6 +405,9 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         const jlm_segment &sg = segs_host[i];
         const int ns = (sg.k + 15) / 16;
         if (ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4) return -2;
+        const int bc = bias_col ? bias_col[i] : -1;
+        if (bc >= 0 && (bc != sg.k || sg.k % 16 == 0)) return -2;          // the bias column is the first padded one
+        a.bias_col[i] = (short)bc;
         a.seg[i] = sg;
         a.bias[i] = b2 + sg.v_start;
         a.t_scale[i] = t_scale[i] * 1.4426950408889634f;

@@ -274,15 +274,30 @@ class DeviceModel:
                 return 0
             return int(np.clip(np.floor(np.log2(limit / value)), -40, 40))
 
+        self.split_bias_col = (ctypes.c_int * n)()
         for i, sg in enumerate(self.segments):
             nv, k = sg["v_end"] - sg["v_start"], sg["k"]
             k16 = _pad(k, 16)
-            eB = pow2_below(2.0 ** 14, float(self.seg_B[i].abs().max().item()) if nv else 0.0)
+            # a segment with a spare (padded) column carries its bias there: b2 * 2^eB against a constant
+            # 1.0 on the T side, so the kernel's fold has no bias add
+            bias_col = k if (k % 16 != 0 and nv > 0) else -1
+            b2seg = self.b2[sg["v_start"]:sg["v_end"]]
+            bmax = float(self.seg_B[i].abs().max().item()) if nv else 0.0
+            if bias_col >= 0:
+                bmax = max(bmax, float(b2seg.abs().max().item()))
+            eB = pow2_below(2.0 ** 14, bmax)
             tb = 1.0 if t_bound is None else float(t_bound[sg["t_off"]:sg["t_off"] + k].max())
+            if bias_col >= 0:
+                tb = max(tb, 1.0)
             eT = pow2_below(2.0 ** 15, tb * 1.4426950408889634)
             dst = torch.zeros((max(nv, 1), k16), dtype=torch.float32, device=self.device)
+            strm = self.stream() if self.device.type == "cuda" else None
             _lib.check(L.jlm_pack_split_f16(self.seg_B[i].data_ptr(), nv, k, sg["ldb"], float(2.0 ** eB), dst.data_ptr(), k16,
-                                            self.stream() if self.device.type == "cuda" else None), "jlm_pack_split_f16")
+                                            strm), "jlm_pack_split_f16")
+            if bias_col >= 0:
+                _lib.check(L.jlm_pack_split_f16_col(b2seg.data_ptr(), nv, float(2.0 ** eB), dst.data_ptr(), k16, bias_col,
+                                                    strm), "jlm_pack_split_f16_col")
+            self.split_bias_col[i] = bias_col
             self.seg_split.append(dst)
             arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], k, sg["t_off"], dst.data_ptr(), k16)
             self.split_t_scale[i] = 2.0 ** eT
@@ -362,9 +377,9 @@ class DeviceModel:
             if rec is not None:
                 rec.begin("vocab_lse")
             if self.split_array is not None:
-                r = L.jlm_vocab_lse_split(self.split_array, self.split_t_scale, self.split_descale, self.n_segs,
-                                          self.b2.data_ptr(), T, self.ldt, rows, part, ld_part, max_parts, n_rows_max,
-                                          n_dev, stream)
+                r = L.jlm_vocab_lse_split(self.split_array, self.split_t_scale, self.split_descale, self.split_bias_col,
+                                          self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part, ld_part, max_parts,
+                                          n_rows_max, n_dev, stream)
             else:
                 r = L.jlm_vocab_lse_stationary(self.seg_array, self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part,
                                                ld_part, max_parts, n_rows_max, n_dev, stream)

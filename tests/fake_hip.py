@@ -239,8 +239,21 @@ class FakeLib:
         out[:, :, 1, :] = lo.reshape(rows, k16 // 8, 8)
         return 0
 
-    def jlm_vocab_lse_split(self, segs, t_scale, descale, n_segs, b2, T, ldt, rows, part, ld_part, max_parts, n_rows_max,
-                            n_dev, stream):
+    def jlm_pack_split_f16_col(self, v, rows, scale, dst, ld_dst, col, stream):
+        if rows < 0 or ld_dst % 16 or col < 0 or col >= ld_dst:
+            return -1
+        if rows == 0:
+            return 0
+        x = view(v, rows, np.float32) * np.float32(scale)
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        out = self._split_view(dst, rows, ld_dst)
+        out[:, col // 8, 0, col % 8] = hi
+        out[:, col // 8, 1, col % 8] = lo
+        return 0
+
+    def jlm_vocab_lse_split(self, segs, t_scale, descale, bias_col, n_segs, b2, T, ldt, rows, part, ld_part, max_parts,
+                            n_rows_max, n_dev, stream):
         """Contract of jlm_vocab_lse_stationary, operands read from split rows."""
         if n_segs > max_parts:
             return -1
@@ -251,14 +264,18 @@ class FakeLib:
         g = _rows(rows, n)
         for i in range(n_segs):
             sg = segs[i]
-            if sg.k > 256 or sg.ldb % 16:
+            bc = bias_col[i] if bias_col is not None and bias_col else -1
+            if sg.k > 256 or sg.ldb % 16 or (bc >= 0 and (bc != sg.k or sg.k % 16 == 0)):
                 return -2
             nv = sg.v_end - sg.v_start
             Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g]).astype(np.float64)
             sp = view(sg.B, nv * sg.ldb * 2, np.float16).reshape(nv, sg.ldb // 8, 2, 8).astype(np.float64)
-            Bv = (sp[:, :, 0, :] + sp[:, :, 1, :]).reshape(nv, sg.ldb)[:, :sg.k]
-            y = ((Tv * float(t_scale[i])) @ Bv.T * float(descale[i])).astype(np.float32) \
-                + view(_p(b2) + 4 * sg.v_start, nv, np.float32)
+            Bfull = (sp[:, :, 0, :] + sp[:, :, 1, :]).reshape(nv, sg.ldb)
+            y = (Tv * float(t_scale[i])) @ Bfull[:, :sg.k].T * float(descale[i])
+            if bc >= 0:          # the bias column times the 1.0 the kernel feeds (scaled by t_scale like every T value)
+                y = (y + float(t_scale[i]) * Bfull[:, bc][None, :] * float(descale[i])).astype(np.float32)
+            else:
+                y = y.astype(np.float32) + view(_p(b2) + 4 * sg.v_start, nv, np.float32)
             mx = y.max(axis=1)
             pv[i, :n, 0] = mx
             pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)

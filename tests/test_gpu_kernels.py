@@ -293,21 +293,27 @@ def test_vocab_lse_stationary(L, V, widths, R):
                                       partg.data_ptr(), R, 0, R, ndg.data_ptr(), _st()) < 0
 
 
-def _split_segments(L, segs_g, keep_g, n, scale_exp):
-    """split-row copies of the gpu segments' matrices -> (Segment array, t_scale, descale, keepalive)"""
+def _split_segments(L, segs_g, keep_g, n, scale_exp, b2g=None):
+    """split-row copies of the gpu segments' matrices -> (Segment array, t_scale, descale, bias_col, keepalive);
+    with b2g the bias goes into the first padded column wherever a segment has one"""
     import ctypes
     out = (_lib.Segment * n)()
-    ts, ds, keep = (ctypes.c_float * n)(), (ctypes.c_float * n)(), []
+    ts, ds, bc, keep = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)(), []
     for i in range(n):
         sg = segs_g[i]
         nv, kp = sg.v_end - sg.v_start, (sg.k + 15) // 16 * 16
         dst = torch.zeros((nv, kp), dtype=torch.float32, device="cuda")
         assert L.jlm_pack_split_f16(sg.B, nv, sg.k, sg.ldb, float(2.0 ** scale_exp[i]), dst.data_ptr(), kp, _st()) == 0
+        bc[i] = -1
+        if b2g is not None and sg.k % 16:
+            assert L.jlm_pack_split_f16_col(b2g.data_ptr() + 4 * sg.v_start, nv, float(2.0 ** scale_exp[i]), dst.data_ptr(), kp,
+                                            sg.k, _st()) == 0
+            bc[i] = sg.k
         keep.append(dst)
         out[i] = _lib.Segment(sg.v_start, sg.v_end, sg.k, sg.t_off, dst.data_ptr(), kp)
         ts[i] = 2.0 ** 3
         ds[i] = 2.0 ** -(3 + scale_exp[i])
-    return out, ts, ds, keep
+    return out, ts, ds, bc, keep
 
 
 @pytest.mark.parametrize("V,widths,R", [(2000, [32], 10), (3000, [32, 16, 8], 300), (50000, [200, 100, 52], 2560),
@@ -338,22 +344,25 @@ def test_vocab_lse_split(L, V, widths, R):
     mx = y.max(axis=1)
     ref = mx + np.log(np.exp(y - mx[:, None]).sum(axis=1))
     errs = {}
-    for name in ("f32", "f16x3"):
+    for name in ("f32", "f16x3", "f16x3-bias-col"):
         lseg = torch.zeros(G, dtype=torch.float64, device="cuda")
         if name == "f32":
             n1 = L.jlm_vocab_lse_stationary(segs_g, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
                                             partg.data_ptr(), R, maxp, R, ndg.data_ptr(), _st())
         else:
-            sp, ts, ds, keep2 = _split_segments(L, segs_g, keep, len(widths), [6] * len(widths))
-            n1 = L.jlm_vocab_lse_split(sp, ts, ds, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
+            sp, ts, ds, bc, keep2 = _split_segments(L, segs_g, keep, len(widths), [6] * len(widths),
+                                                    b2g if name.endswith("col") else None)
+            n1 = L.jlm_vocab_lse_split(sp, ts, ds, bc, len(widths), b2g.data_ptr(), Tg.data_ptr(), ldt, rowsg.data_ptr(),
                                        partg.data_ptr(), R, maxp, R, ndg.data_ptr(), _st())
         assert len(widths) <= n1 <= maxp, n1
         assert L.jlm_lse_combine(partg.data_ptr(), R, n1, rowsg.data_ptr(), lseg.data_ptr(), R, ndg.data_ptr(), _st()) == 0
         torch.cuda.synchronize()
         errs[name] = np.abs(lseg.cpu().numpy()[rows.numpy()[:n]] - ref).max()
-    print("max |lse - f64|: f32 MFMA %.3g, split f16 %.3g" % (errs["f32"], errs["f16x3"]))
-    assert errs["f16x3"] < 2e-5
-    assert errs["f16x3"] < 4 * errs["f32"] + 2e-6
+    print("max |lse - f64|: f32 MFMA %.3g, split f16 %.3g, with the bias as a GEMM column %.3g" % (
+        errs["f32"], errs["f16x3"], errs["f16x3-bias-col"]))
+    for name in ("f16x3", "f16x3-bias-col"):
+        assert errs[name] < 2e-5
+        assert errs[name] < 4 * errs["f32"] + 2e-6
 
 
 def FK_view(ptr, count):

@@ -83,7 +83,7 @@ def bench_lse_stat(V, widths, R, tag):
     report("vocab_lse_stationary %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
 
 
-def bench_lse_split(V, widths, R, tag):
+def bench_lse_split(V, widths, R, tag, bias_col=False):
     if flt and flt not in "lse":
         return
     if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "split " + tag:
@@ -92,7 +92,7 @@ def bench_lse_split(V, widths, R, tag):
     bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
     n = len(widths)
     segs = (_lib.Segment * n)()
-    ts, ds = (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    ts, ds, bcol = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)()
     keep, off, flops = [], 0, 0.0
     for i, k in enumerate(widths):
         kp = (k + 3) // 4 * 4
@@ -103,6 +103,7 @@ def bench_lse_split(V, widths, R, tag):
         assert L.jlm_pack_split_f16(Bm.data_ptr(), nv, kp, kp, 1024.0, Bs.data_ptr(), k16, st) == 0
         keep += [Bm, Bs]
         segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bs.data_ptr(), k16)
+        bcol[i] = kp if (bias_col and kp % 16) else -1
         ts[i], ds[i] = 16.0, 1.0 / (16.0 * 1024.0)
         off += kp
         flops += 2.0 * k * nv * R
@@ -110,10 +111,15 @@ def bench_lse_split(V, widths, R, tag):
     part = torch.empty((96, R, 2), device=dev)
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     rows = torch.arange(R, device=dev, dtype=torch.int32)
-    f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, n, b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
+    if bias_col:
+        for i in range(n):
+            if bcol[i] >= 0:
+                assert L.jlm_pack_split_f16_col(b2.data_ptr() + 4 * bounds[i], bounds[i + 1] - bounds[i], 1024.0,
+                                                segs[i].B, segs[i].ldb, bcol[i], st) == 0
+    f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, bcol, n, b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
                                       part.data_ptr(), R, 96, R, nd.data_ptr(), st)
     print("parts:", f())
-    report("vocab_lse_split      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+    report("vocab_lse_split%s %s V=%d k=%s R=%d" % ("+bcol " if bias_col else "      ", tag, V, widths, R), flops, timeit(f))
 
 
 def bench_gate(H, E, R):
@@ -198,6 +204,7 @@ if __name__ == "__main__":
         bench_gate_split(512, 256, R)
         bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*")
+        bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*", bias_col=True)
         bench_lse_stat(50000, [256], R, "tied50k")
         bench_lse_split(50000, [256], R, "tied50k")
         bench_lse(12000, 200, R, "seg0")

@@ -23,7 +23,7 @@ L.jlm_vocab_lse_stationary.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.
 L.jlm_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.jlm_prof_read_split.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.jlm_vocab_lse_split.restype = ctypes.c_int
-L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [
+L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [
     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
     ctypes.c_void_p, ctypes.c_void_p]
 L.jlm_pack_split_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
@@ -56,7 +56,7 @@ def run(bounds, widths, R, tag, iters=20, split=False):
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     rows = torch.arange(R, device=dev, dtype=torch.int32)
     if split:
-        f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, len(widths), b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
+        f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, None, len(widths), b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),
                                           part.data_ptr(), R, 96, R, nd.data_ptr(), None)
     else:
         f = lambda: L.jlm_vocab_lse_stationary(segs, len(widths), b2.data_ptr(), T.data_ptr(), off, rows.data_ptr(),

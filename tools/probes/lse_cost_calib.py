@@ -15,7 +15,7 @@ def t_us(V, K, iters=30):
     ts, ds = (ctypes.c_float * 1)(16.0), (ctypes.c_float * 1)(1.0 / 16384)
     T, b2 = torch.randn(R, K, device=dev), torch.randn(V, device=dev) * 0.05
     part = torch.empty((96, R, 2), device=dev)
-    f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, 1, b2.data_ptr(), T.data_ptr(), K, None, part.data_ptr(), R, 96, R, None, None)
+    f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, None, 1, b2.data_ptr(), T.data_ptr(), K, None, part.data_ptr(), R, 96, R, None, None)
     for _ in range(5): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

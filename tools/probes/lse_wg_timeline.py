@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from jlm_amd import _lib
 L = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "..", "build_prof", "libjlm_hip_prof.so"))
 L.jlm_vocab_lse_split.restype = ctypes.c_int
-L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [
+L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [
     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
     ctypes.c_void_p, ctypes.c_void_p]
 L.jlm_pack_split_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
@@ -23,7 +23,7 @@ for i, k in enumerate(widths):
     keep += [Bm, Bs]; segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bs.data_ptr(), k16); off += kp
 T, b2 = torch.randn(R, off, device=dev), torch.randn(50000, device=dev) * 0.05
 part = torch.empty((96, R, 2), device=dev)
-f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, n, b2.data_ptr(), T.data_ptr(), off, None, part.data_ptr(), R, 96, R, None, None)
+f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, None, n, b2.data_ptr(), T.data_ptr(), off, None, part.data_ptr(), R, 96, R, None, None)
 for _ in range(5): npart = f()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()

@@ -20,7 +20,7 @@ for K in (160, 256):
         segs = (_lib.Segment * 1)(); segs[0] = _lib.Segment(0, V, K, 0, Bs.data_ptr(), k16)
         ts, ds = (ctypes.c_float * 1)(8.0), (ctypes.c_float * 1)(1.0 / 512)
         part = torch.zeros((96, R, 2), device=dev); lse = torch.zeros(R, dtype=torch.float64, device=dev)
-        n = L.jlm_vocab_lse_split(segs, ts, ds, 1, b2.data_ptr(), Tg.data_ptr(), K, None, part.data_ptr(), R, 96, R, None, st)
+        n = L.jlm_vocab_lse_split(segs, ts, ds, None, 1, b2.data_ptr(), Tg.data_ptr(), K, None, part.data_ptr(), R, 96, R, None, st)
         assert n > 0 and L.jlm_lse_combine(part.data_ptr(), R, n, None, lse.data_ptr(), R, None, st) == 0
         torch.cuda.synchronize()
         ref = T[:, kk].astype(np.float64) * float(B[0, kk])
