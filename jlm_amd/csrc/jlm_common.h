@@ -95,7 +95,7 @@ static __device__ unsigned long long jlm_prof[8];
         }                                                                                                       \
         return 0;                                                                                               \
     }
-#define JLM_PROF_DECL() unsigned long long p_t0 = clock64(), p_t1 = 0, p_t2 = 0, p_x = 0, p_bar = 0, p_fold = 0
+#define JLM_PROF_DECL() unsigned long long p_t0 = clock64(), p_w0 = wall_clock64(), p_t1 = 0, p_t2 = 0, p_x = 0, p_bar = 0, p_fold = 0
 #define JLM_PROF_MARK(v) v = clock64()
 #define JLM_PROF_ADD(acc_, since) acc_ += clock64() - since
 #define JLM_PROF_FLUSH()                                                                   \
@@ -104,6 +104,7 @@ static __device__ unsigned long long jlm_prof[8];
         atomicAdd(&jlm_prof[0], now - p_t0); atomicAdd(&jlm_prof[1], p_t1 - p_t0);         \
         atomicAdd(&jlm_prof[2], p_t2 - p_t1); atomicAdd(&jlm_prof[3], p_bar);              \
         atomicAdd(&jlm_prof[4], p_fold); atomicAdd(&jlm_prof[5], 1ull);                    \
+        atomicAdd(&jlm_prof[6], wall_clock64() - p_w0);                                    \
     }
 #else
 #define JLM_PROF_READER(name)

@@ -117,7 +117,7 @@ extern "C" int jlm_prof_read_wg(unsigned long long *out) {
 // BG: the bias rides in the GEMM -- column sg.k of the split rows holds bias * 2^eB and the row operand
 // gets 1.0 there -- so the fold is max3 / fma / exp / add per logit (the fma forms acc * 2^-(eT+eB) - max
 // in one go) and stages no bias through LDS.  Needs a spare column (k % 16 != 0).
-template <int NS, int MT, bool BG>
+template <int NS, int MT, bool BG, int NW>
 __device__ __forceinline__ void lse_split_body(
     const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int p_in_seg, int parts_in_seg, int pt,
     int n_paths, const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row,
@@ -125,7 +125,7 @@ __device__ __forceinline__ void lse_split_body(
     using CH = SplitChunks<NS>;
     constexpr int NC = CH::NC;
     constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
-    constexpr int NINST = BMV / 16;                // LDS-DMA instructions per wave per chunk (4 rows each, 4 waves)
+    constexpr int NINST = BMV / (4 * NW);          // LDS-DMA instructions per wave per chunk (4 rows each, NW waves)
     constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
     JLM_PROF_DECL();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void lse_split_body(
     const int vt0 = (int)((long)ntiles * p_in_seg / parts_in_seg), vt1 = (int)((long)ntiles * (p_in_seg + 1) / parts_in_seg);
     const float *__restrict__ Bp = sg.B;
     // 1. this lane's row operands: for step s the lane half h owns k = 16 s + 8 h .. + 7, both planes
-    const int prow = pt * 128 + wave * 32 + li;
+    const int prow = pt * (32 * NW) + wave * 32 + li;
     const bool row_ok = prow < n_paths;
     const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
     f16x8 thi[NS], tlo[NS];
@@ -243,34 +243,44 @@ __device__ __forceinline__ void lse_split_body(
             else issue(t, CH::start(c + 1 < NC ? c + 1 : 0), buf ^ 1);
             const float *bs = Bs + buf * BMV * 64;
             // One k-step = 3 groups of MT MFMAs (lo.hi, hi.lo, hi.hi over all MT blocks): consecutive
-            // MFMAs never share an accumulator and a dependent one is MT instructions away.  The
-            // fragment registers are refilled in place: the lo planes of the next step right after
-            // the first group has issued, the hi planes after the last.
-            f16x8 ah[MT], al[MT];
+            // MFMAs never share an accumulator and a dependent one is MT instructions away.  Fragment
+            // reads run ahead of their use: both planes of step j+1 (lo refilled in place, hi double-
+            // buffered) are requested right after step j's first group, 8 MFMAs before they are needed.
+            // The sched_barriers pin that order: left alone hipcc shares one register set between the
+            // planes and moves every read directly in front of its MFMAs (s_waitcnt lgkmcnt(0) before
+            // each group: three exposed LDS round trips per k-step, half the kernel's MFMA time).
+            f16x8 ah[2][MT], al[MT];
             const int csz = CH::size(c), cst = CH::start(c);
             auto load_plane = [&](f16x8 (&dst)[MT], int j, int p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const f16x8 *>(bs + mt * 32 * 64 + goff[j][p]);
             };
             // (steps past the segment's own k, when NS is rounded up, multiply zero T operands: no
-            //  run-time guards in here, they would split the chunk into basic blocks and force
-            //  s_waitcnt lgkmcnt(0) -- the full LDS latency -- in front of every MFMA group)
+            //  run-time guards in here, they would split the chunk into basic blocks)
             load_plane(al, 0, 1);
-            load_plane(ah, 0, 0);
+            load_plane(ah[0], 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j >= csz) break;               // compile-time bound of this chunk
                 const int st = cst + j;            // compile-time after unrolling (register index)
                 const bool more = (j + 1 < csz);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
-                if (j + 1 < 4 && more) load_plane(al, j + 1 < 4 ? j + 1 : 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < 4 && more) {           // both planes of step j+1: 8 MFMAs until the first use
+                    load_plane(al, j + 1 < 4 ? j + 1 : 0, 1);
+                    load_plane(ah[(j + 1) & 1], j + 1 < 4 ? j + 1 : 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], tlo[st], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], tlo[st], acc[mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], thi[st], acc[mt], 0, 0, 0);
-                if (j + 1 < 4 && more) load_plane(ah, j + 1 < 4 ? j + 1 : 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], thi[st], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (!BG && last_c) bias_stage(t + 1);
             JLM_PROF_MARK(p_x);
@@ -346,9 +356,10 @@ __device__ __forceinline__ void lse_split_body(
 
 #define LSES_MAX_PARTS 96
 
-__global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a, const float *__restrict__ T, int ldt,
-                                                                  const int *__restrict__ rows, float2 *__restrict__ part,
-                                                                  int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+template <int NW>
+__device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, const float *__restrict__ T, int ldt,
+                                                     const int *__restrict__ rows, float2 *__restrict__ part, int ld_part,
+                                                     int n_rows_max, const int *n_dev, int n_ptiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
     // XCD-aware order, as in vocab_lse_stationary_kernel: with n_parts a multiple of 8 one XCD walks
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
     int p, pt;
     if ((a.n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
     else { p = b / n_ptiles; pt = b % n_ptiles; }
-    if (p >= a.n_parts || pt * 128 >= n_paths) return;
+    if (p >= a.n_parts || pt * (32 * NW) >= n_paths) return;
     int si = 0;
     while (si + 1 < a.n_segs && p >= a.part_first[si + 1]) ++si;
     const jlm_segment sg = a.seg[si];
@@ -369,10 +380,10 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
 #ifdef JLM_PROFILE
     const unsigned long long wg_t0 = wall_clock64();
 #endif
-#define JLM_LSE_CASE(NS_, MT_)                                                                                   \
-    do {                                                                                                         \
-        if (bg) lse_split_body<NS_, MT_, true>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);  \
-        else lse_split_body<NS_, MT_, false>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);    \
+#define JLM_LSE_CASE(NS_, MT_)                                                                                           \
+    do {                                                                                                                 \
+        if (bg) lse_split_body<NS_, MT_, true, NW>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);  \
+        else lse_split_body<NS_, MT_, false, NW>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);    \
     } while (0)
     const bool bg = a.bias_col[si] >= 0;
     if (ns <= 2) JLM_LSE_CASE(2, 4);
@@ -387,6 +398,20 @@ __global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a,
         jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si; jlm_prof_wg[b][3] = pt;
     }
 #endif
+}
+
+// 4 waves x 32 rows, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void vocab_lse_split_kernel(LseSplitArgs a, const float *__restrict__ T, int ldt,
+                                                                  const int *__restrict__ rows, float2 *__restrict__ part,
+                                                                  int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+    vocab_lse_split_main<4>(a, T, ldt, rows, part, ld_part, n_rows_max, n_dev, n_ptiles);
+}
+// 8 waves x 32 rows, one workgroup per CU: a staged vocabulary chunk serves 256 rows (half the L2 -> LDS
+// traffic and half the DMA issues per MFMA)
+__global__ __launch_bounds__(512, 1) void vocab_lse_split8_kernel(LseSplitArgs a, const float *__restrict__ T, int ldt,
+                                                                   const int *__restrict__ rows, float2 *__restrict__ part,
+                                                                   int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+    vocab_lse_split_main<8>(a, T, ldt, rows, part, ld_part, n_rows_max, n_dev, n_ptiles);
 }
 
 // Host side: ranges per segment in proportion to their cost, one resident round of workgroups.
@@ -423,10 +448,12 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         work[i] = (long)(sg.v_end - sg.v_start) * (ns + c0);
         total += work[i];
     }
-    const int n_ptiles = (n_rows_max + 127) / 128;
+    static int nw = -1;
+    if (nw < 0) { const char *e = getenv("JLM_LSE_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }
+    const int n_ptiles = (n_rows_max + 32 * nw - 1) / (32 * nw);
     int cap = max_parts < LSES_MAX_PARTS ? max_parts : LSES_MAX_PARTS;
     if (cap < n_segs) return -1;
-    int np = (2 * 256) / n_ptiles;                 // one resident round: 2 workgroups per CU
+    int np = ((nw == 8 ? 1 : 2) * 256) / n_ptiles; // one resident round: 2 four-wave / 1 eight-wave workgroup per CU
     if (np < n_segs) np = n_segs;
     if (np > cap) np = cap;
     if (np >= 8) np &= ~7;
@@ -454,13 +481,19 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
     const int grid = given * n_ptiles;
-    hipLaunchKernelGGL(vocab_lse_split_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, T, ldt, rows,
-                       reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    if (nw == 8)
+        hipLaunchKernelGGL(vocab_lse_split8_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    else
+        hipLaunchKernelGGL(vocab_lse_split_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return given;

@@ -74,8 +74,10 @@ def run(bounds, widths, R, tag, iters=20, split=False):
     us = (time.perf_counter() - t0) / iters * 1e6
     read(out, 1)
     tot, pro, first, bar, fold, nw = [float(out[i]) for i in range(6)]
+    wall = float(out[6])
     mf = tot - pro - first - bar - fold
     tag = ("split " if split else "f32   ") + tag
+    print("   shader clock while the waves ran: %.2f GHz" % (tot / max(wall, 1.0) * 0.1))
     print("%-40s parts=%d  %.0f us (%.1f TF)  wave life %.0f cyc: T-frags %.1f%%  first chunk %.1f%%  barrier %.1f%%  fold %.1f%%  mfma+frag %.1f%%"
           % (tag, n, us, flops / us / 1e6, tot / nw, 100 * pro / tot, 100 * first / tot, 100 * bar / tot, 100 * fold / tot,
              100 * mf / tot))
