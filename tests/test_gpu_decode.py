@@ -92,6 +92,26 @@ def test_decode_matches_reference_golden(case, fx, golden_decode):
     assert n_same >= 0.9 * len(outs), (name, n_same, len(outs))
 
 
+@pytest.mark.parametrize("fixture", ["small-vtable", "small-tied"])
+def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
+    """JLM_PRECISION=f32 keeps the whole decode on the f32 matrix pipe (the round's first
+    kernels); it must give the same n-best as the default split-f16 decode."""
+    f = fx(fixture)
+    jconfig.set_root(f["root"])
+    from jlm_amd.decoder import Decoder
+    sents = synth.make_ragged_sentences(12, 2, 16, seed=77, alphabet=f["alphabet"])
+    split = _decoder(f, "static")
+    assert split.model.dev.split_array is not None and split.model.dev.split_lstm
+    monkeypatch.setenv("JLM_PRECISION", "f32")
+    plain = Decoder(1)
+    assert plain.model.dev.split_array is None and not plain.model.dev.split_lstm
+    a = split.decode_batch(sents, beam_width=7)
+    b = plain.decode_batch(sents, beam_width=7)
+    for x, y in zip(a, b):
+        assert [w for _, w in x] == [w for _, w in y]
+        np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=0, atol=2e-5)
+
+
 def test_single_sentence_equals_batch(fx):
     f = fx("small-vtable")
     dec = _decoder(f, "static")
