@@ -208,6 +208,17 @@ int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const float *b2,
                      float *run_max, double *run_sum, double *lse,
                      int merge, int beam, int n_groups, void *stream);
 
+/* jlm_wordlist_lse on split rows, single-segment models (seg->B = split rows scaled by 2^eB,
+ * t_scale = 2^eT, descale = 2^-(eT+eB) as for jlm_vocab_lse_split; b2 is added in the fold).
+ * max_words = longest word list among the groups (<= 4064).  Returns -2 when the shape is outside
+ * the kernel (k > 256, beam > 32, longer lists): use jlm_wordlist_lse then. */
+int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale, float descale, const float *b2,
+                           const float *T, int ldt,
+                           const int *g0, const int *cnt, const int *cnt_idx,
+                           const int *wl, const int *wl_off, const int *wl_idx, int wl_base, int max_words,
+                           float *run_max, double *run_sum, double *lse,
+                           int merge, int beam, int n_groups, void *stream);
+
 /* ------------------------------------------------------------------------
  * Lattice of a batch (CSR, built on the host by jlm_amd/lattice.py following
  * Decoder._build_lattice, decoder.py:79-135), resident in HBM for the decode.

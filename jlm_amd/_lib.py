@@ -54,6 +54,8 @@ _SIGS = {
     "jlm_edge_logits": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
     "jlm_wordlist_lse": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
                          c_int),
+    "jlm_wordlist_lse_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, P, P, P, P, P, c_int, c_int, P, P, P,
+                               c_int, c_int, c_int, P], c_int),
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),

@@ -498,3 +498,205 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (e != hipSuccess) return -(int)e - 100;
     return given;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Word-list log-sum-exp on split rows (selected / incremental vocabulary, single-segment models):
+// the split-f16 form of wordlist_lse_mfma_kernel (jlm_gemm.hip).  One workgroup per (sentence, frame)
+// group, its <= 32 hypothesis rows stationary in registers; the group's word list is walked in
+// 32-word tiles, wave w taking tiles w, w+4, ...; a tile's split rows are GATHERED row by row into
+// the wave's private LDS ring by the DMA (per-lane source = the word's row).  Per group that is
+// ~600 words x 1 KB = 0.6 MB of scattered rows -- the kernel is bound by how many of those requests
+// are in flight, not by arithmetic (f32 form: 44 us, 3.5 TB/s with one 4 KB chunk per wave in flight),
+// hence the deep ring: WLS_RING chunks of 32 words x 64 k-values (8 KB) per wave, no workgroup
+// barrier in the loop, only the wave's own s_waitcnt vmcnt(chunks still allowed in flight).
+// The list's word ids and biases are staged in LDS once (the DMA addresses and the fold need them).
+#define WLS_RING 3
+#define WLS_MAX_WORDS 4096
+
+template <int NS>
+__global__ __launch_bounds__(256) void wordlist_lse_split_kernel(
+    jlm_segment sg, float t_scale, float descale, const float *__restrict__ b2, const float *__restrict__ T, int ldt,
+    const int *__restrict__ g0v, const int *__restrict__ cnt, const int *__restrict__ cnt_idx,
+    const int *__restrict__ wl, const int *__restrict__ wl_off, const int *__restrict__ wl_idx, int wl_base,
+    float *__restrict__ run_max, double *__restrict__ run_sum, double *__restrict__ lse, int merge, int beam) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using CH = SplitChunks<NS>;
+    constexpr int NC = CH::NC;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const int j = blockIdx.x;
+    const int nrows = min(cnt[cnt_idx[j]], min(beam, 32));
+    if (nrows <= 0) return;
+    const int gbase = g0v[j];
+    const int lid = wl_base + wl_idx[j];
+    const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, ldb = sg.ldb;
+    const float *__restrict__ Bp = sg.B;
+    const int ntiles = (nw + 31) >> 5;
+    // LDS: [4 waves][WLS_RING][32][64] rings | word ids (padded to whole tiles) | biases (base-2 units)
+    float *ring = smem + wave * (WLS_RING * 32 * 64);
+    int *wid_s = reinterpret_cast<int *>(smem + 4 * WLS_RING * 32 * 64);
+    float *bias_l = reinterpret_cast<float *>(wid_s + WLS_MAX_WORDS);
+    for (int i = tid; i < ntiles * 32; i += 256) {
+        const int w = i < nw ? wl[w0 + i] : -1;
+        wid_s[i] = w < 0 ? 0 : w - sg.v_start;                         // padded entries re-read row 0 ...
+        bias_l[i] = w < 0 ? JLM_NEG_BIG : b2[w] * LOG2E;               // ... and are switched off by their bias
+    }
+    __syncthreads();
+    float m = JLM_NEG_BIG, s = 0.0f;
+    const int my_tiles = wave < ntiles ? (ntiles - wave + 3) / 4 : 0;  // tiles wave, wave + 4, ...
+    if (my_tiles > 0) {
+        const bool row_ok = li < nrows;
+        const float *trow = T + (size_t)(gbase + (row_ok ? li : 0)) * ldt + sg.t_off;
+        f16x8 thi[NS], tlo[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 16 * st + 8 * h + 4 * q;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && k < K) ? v[e] : 0.0f;
+            }
+            jlm_split8(x, t_scale * LOG2E, thi[st], tlo[st]);
+        }
+        // DMA piece i of a chunk fills ring rows 4 i .. 4 i + 3 (lane: row 4 i + (lane >> 4), slot lane & 15)
+        const int lrow = lane >> 4, pslot = lane & 15;
+        const int total = my_tiles * NC;                               // this wave's chunks, in order
+        auto issue = [&](int t, int c_start, int slot) {               // chunk (tile t, steps c_start ..) -> ring slot
+            float *dst = ring + slot * 32 * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 4 * i + lrow;
+                const int g = pslot ^ (r & 15);
+                const int word = wid_s[t * 32 + r];
+                const unsigned off = ((unsigned)word * (unsigned)ldb + (unsigned)min(c_start * 16 + g * 4, ldb - 4)) * 4u;
+                GLDS16(reinterpret_cast<const char *>(Bp) + off, dst + (4 * i) * 64);
+            }
+        };
+        int goff[4][2];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) goff[jj][p] = li * 64 + (((4 * jj + 2 * h + p) ^ (li & 15)) * 4);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < WLS_RING - 1; ++q)
+            if (q < total) issue(wave + 4 * (q / NC), CH::start(q % NC), q);
+        int q = 0, slot = 0;
+        for (int ti = 0; ti < my_tiles; ++ti) {
+            const int t = wave + 4 * ti;
+            f32x16 acc0 = zero16, acc1 = zero16;                       // two chains: consecutive MFMAs never share one
+#pragma unroll
+            for (int c = 0; c < NC; ++c, ++q) {
+                // the chunk WLS_RING - 1 ahead goes into the slot consumed one iteration ago (this wave's own:
+                // no barrier); then everything but the WLS_RING - 1 youngest chunks has landed
+                if (q + WLS_RING - 1 < total) {
+                    const int cn = (c + WLS_RING - 1) % NC, dti = (c + WLS_RING - 1) / NC;
+                    issue(wave + 4 * (ti + dti), CH::start(cn), slot == 0 ? WLS_RING - 1 : slot - 1);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WLS_RING - 1) * 8) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const float *bs = ring + slot * 32 * 64;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (jj >= CH::size(c)) break;
+                    const int st = CH::start(c) + jj;
+                    const f16x8 al = *reinterpret_cast<const f16x8 *>(bs + goff[jj][1]);
+                    const f16x8 ah = *reinterpret_cast<const f16x8 *>(bs + goff[jj][0]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, thi[st], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, tlo[st], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, thi[st], acc0, 0, 0, 0);
+                }
+                slot = (slot + 1 == WLS_RING) ? 0 : slot + 1;
+            }
+            // fold the tile's 16 base-2 logits of this lane's row
+            const float *bt = bias_l + t * 32 + 4 * h;
+            float v[16], tmax = JLM_NEG_BIG;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + 8 * jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[4 * jj + e] = fmaf(acc0[4 * jj + e] + acc1[4 * jj + e], descale, b4[e]);
+                    tmax = fmaxf(tmax, v[4 * jj + e]);
+                }
+            }
+            const float mn = fmaxf(m, tmax);
+            float add = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(v[r] - mn);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+            m = mn;
+        }
+        const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm;
+    }
+    // the four waves' partial (max, sum) per row meet in LDS (base-2 units)
+    __syncthreads();
+    float *red = smem;                     // [4][32][2], reuses wave 0's ring
+    if (h == 0) { red[(wave * 32 + li) * 2] = m; red[(wave * 32 + li) * 2 + 1] = s; }
+    __syncthreads();
+    if (tid < nrows) {
+        float M = red[tid * 2], S = red[tid * 2 + 1];
+        for (int w = 1; w < 4; ++w) {
+            const float m2 = red[(w * 32 + tid) * 2], s2 = red[(w * 32 + tid) * 2 + 1];
+            const float mm = fmaxf(M, m2);
+            S = S * __builtin_amdgcn_exp2f(M - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+            M = mm;
+        }
+        const int g = gbase + tid;
+        float Mn = M * LN2;                // natural-log units from here on
+        double Sd = (double)S;
+        if (merge) {
+            const float pm = run_max[g];
+            const double ps = run_sum[g];
+            const float mm = fmaxf(pm, Mn);
+            Sd = ps * exp((double)pm - (double)mm) + Sd * exp((double)Mn - (double)mm);
+            Mn = mm;
+        }
+        run_max[g] = Mn;
+        run_sum[g] = Sd;
+        lse[g] = (double)Mn + log(Sd);
+    }
+}
+
+// Returns 0, a HIP error, or -2 when the shape is outside this kernel (caller uses jlm_wordlist_lse).
+extern "C" int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale, float descale, const float *b2, const float *T,
+                                      int ldt, const int *g0, const int *cnt, const int *cnt_idx, const int *wl,
+                                      const int *wl_off, const int *wl_idx, int wl_base, int max_words, float *run_max,
+                                      double *run_sum, double *lse, int merge, int beam, int n_groups, void *stream) {
+    const jlm_segment sg = *seg_host;
+    const int ns = (sg.k + 15) / 16;
+    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (max_words > WLS_MAX_WORDS - 32) return -2;
+    if (n_groups <= 0) return 0;
+    const int lds = (4 * WLS_RING * 32 * 64 + 2 * WLS_MAX_WORDS) * 4;
+    hipStream_t st = (hipStream_t)stream;
+#define JLM_WLS_LAUNCH(N)                                                                                                  \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_lse_split_kernel<N>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
+                return -3;                                                                                                 \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(wordlist_lse_split_kernel<N>, dim3(n_groups), dim3(256), lds, st, sg, t_scale, descale, b2, T, ldt, \
+                           g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum, lse, merge, beam);             \
+    } while (0)
+    if (ns <= 2) JLM_WLS_LAUNCH(2);
+    else if (ns <= 4) JLM_WLS_LAUNCH(4);
+    else if (ns <= 8) JLM_WLS_LAUNCH(8);
+    else if (ns <= 12) JLM_WLS_LAUNCH(12);
+    else JLM_WLS_LAUNCH(16);
+#undef JLM_WLS_LAUNCH
+    JLM_LAUNCH_CHECK();
+    return 0;
+}

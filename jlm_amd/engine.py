@@ -197,16 +197,31 @@ class DecodeEngine:
         ev = []
         join = None
         pending_parts = 0
+        wl_split = getattr(m, "split_array", None) is not None and nsegs == 1 and beam <= 32
+
+        def wl_lse(g0, cidx, words, off, base, merge, n_groups, what, max_words):
+            """jlm_wordlist_lse; on the split rows (deep gather ring, 128 KB of LDS per workgroup) when the
+            model has them and the lists are long enough to be bound by the gather -- the short delta
+            lists of the incremental decoder (tens of words, thousands of groups) are bound by how many
+            workgroups fit a CU and stay on the 33-KB f32 kernel"""
+            if wl_split and 128 <= max_words <= 4064:
+                r = L.jlm_wordlist_lse_split(m.split_array, m.split_t_scale[0], m.split_descale[0], b2p, Tp, ldt, g0, cntp,
+                                             cidx, words, off, ip["sidx"], base, max_words, p.run_max.data_ptr(),
+                                             p.run_sum.data_ptr(), lsep, merge, beam, n_groups, st)
+                if r != -2:
+                    _lib.check(r, "jlm_wordlist_lse_split(%s)" % what)
+                    return
+            _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, g0, cntp, cidx, words, off, ip["sidx"], base,
+                                          p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, merge, beam, n_groups, st),
+                       "jlm_wordlist_lse(%s)" % what)
+
         for f in range(F):
             if join is not None:
                 main.wait_event(join)
                 join = None
             if dynamic and not self_norm and f >= 2:
                 # K11: older frames learn the words that first appear at frame f
-                _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"], cntp, ip["cidx"],
-                                              ip["dd_words"], ip["dd_off"], ip["sidx"], f * B,
-                                              p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 1, beam, (f - 1) * B, st),
-                           "jlm_wordlist_lse(merge)")
+                wl_lse(ip["g0"], ip["cidx"], ip["dd_words"], ip["dd_off"], f * B, 1, (f - 1) * B, "merge", p.max_words["dd"])
             # the full-vocabulary normaliser of frame f-1 left partial slices: beam_step folds them itself
             p.stS.lse_part = p.part.data_ptr() if pending_parts else None
             p.stS.ld_part, p.stS.n_parts = rmax, pending_parts
@@ -238,15 +253,11 @@ class DecodeEngine:
                 join.record(side)
             if not self_norm:
                 if dynamic:
-                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
-                                                  ip["di_words"], ip["di_off"], ip["sidx"], f * B,
-                                                  p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 0, beam, B, st),
-                               "jlm_wordlist_lse(init)")
+                    wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["di_words"], ip["di_off"], f * B, 0, B, "init",
+                           p.max_words["di"])
                 elif vmode == "select":
-                    _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, ip["g0"] + cell, cntp, ip["cidx"] + cell,
-                                                  ip["vs_words"], ip["vs_off"], ip["sidx"], 0,
-                                                  p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, 0, beam, B, st),
-                               "jlm_wordlist_lse(vocab_select)")
+                    wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["vs_words"], ip["vs_off"], 0, 0, B, "vocab_select",
+                           p.max_words["vs"])
                 else:
                     pending_parts = m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, rmax, ndev, st,
                                                       self.recorder, combine=False)
@@ -298,6 +309,12 @@ class DecodeEngine:
             p._set("di_off", dyn_lists[1])
             p._set("dd_words", dyn_lists[2])
             p._set("dd_off", dyn_lists[3])
+        # longest word list per kind of call (selected vocabulary / frame-initial / frame-delta lists)
+        def longest(offs):
+            o = np.asarray(offs)
+            return int(np.diff(o).max()) if o.size > 1 else 0
+        p.max_words = dict(vs=longest(vocab[1]) if vocab is not None else 0,
+                           di=longest(dyn_lists[1]) if dynamic else 0, dd=longest(dyn_lists[3]) if dynamic else 0)
         p.dev_ints.copy_(p.host_ints, non_blocking=True)
         eager = (not self.use_graph) or timing or (self.recorder is not None)
         ev = []

@@ -360,6 +360,40 @@ class FakeLib:
                 ls[:] = m + np.log(s)
         return 0
 
+    def jlm_wordlist_lse_split(self, seg, t_scale, descale, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base,
+                               max_words, run_max, run_sum, lse, merge, beam, n_groups, stream):
+        """jlm_wordlist_lse for one segment whose matrix is given as split rows"""
+        sg = seg._obj if hasattr(seg, "_obj") else (seg[0] if not hasattr(seg, "k") else seg)
+        if sg.k > 256 or sg.ldb % 16 or beam > 32 or max_words > 4096 - 32:
+            return -2
+        nv = sg.v_end - sg.v_start
+        Bfull = self._split_read(sg.B, nv, sg.ldb)[:, :sg.k]
+        for gb, nrows, a, words in self._groups(g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
+            if nrows <= 0:
+                continue
+            rm = view(_p(run_max) + 4 * gb, nrows, np.float32)
+            rs = view(_p(run_sum) + 8 * gb, nrows, np.float64)
+            ls = view(_p(lse) + 8 * gb, nrows, np.float64)
+            if len(words):
+                Tv = np.stack([view(_p(T) + 4 * ((gb + k) * ldt + sg.t_off), sg.k, np.float32) for k in range(nrows)])
+                w = words.astype(np.int64)
+                y = (Bfull[w - sg.v_start] @ (Tv.astype(np.float64) * float(t_scale)).T * float(descale)).astype(np.float32)
+                y = (y + view(b2, sg.v_end, np.float32)[w][:, None]).astype(np.float64)
+                m = y.max(axis=0)
+                s = np.exp(y - m[None, :]).sum(axis=0)
+            else:
+                m = np.full(nrows, NEG)
+                s = np.zeros(nrows)
+            if merge:
+                M = np.maximum(rm.astype(np.float64), m)
+                s = rs * np.exp(rm - M) + s * np.exp(m - M)
+                m = M
+            rm[:] = m
+            rs[:] = s
+            with np.errstate(divide="ignore"):
+                ls[:] = m + np.log(s)
+        return 0
+
     # ------------------------------------------------------------------- beam
     def jlm_beam_step(self, lat, st, frame, mode, max_cands, stream):
         lat, st = lat._obj if hasattr(lat, "_obj") else lat, st._obj if hasattr(st, "_obj") else st

@@ -465,6 +465,35 @@ def test_wordlist_lse(L, widths, beam, ng, mw, merge):
     np.testing.assert_allclose(lg[fin], lc[fin], rtol=1e-6, atol=3e-5)
 
 
+@pytest.mark.parametrize("width,beam,ng,mw,merge", [(32, 10, 20, 40, 0), (256, 20, 9, 700, 0), (256, 20, 9, 700, 1),
+                                                    (100, 10, 64, 300, 1), (200, 32, 5, 2500, 0), (48, 1, 7, 33, 0)])
+def test_wordlist_lse_split(L, width, beam, ng, mw, merge):
+    """split-f16 word-list LSE (deep gather ring) against the f64 restatement on the original f32 operands"""
+    rng = np.random.default_rng(width + beam + ng + merge)
+    P = _wordlist_problem(rng, 3000, [width], beam, ng, mw, dup=True)
+    ten = {k: _pair(P[k]) for k in ("T", "b2", "cnt", "cidx", "g0", "wl", "off", "wl_idx")}
+    rm, rmg = _pair(rng.standard_normal(P["G"]).astype(np.float32))
+    rs, rsg = _pair(rng.uniform(1.0, 50.0, size=P["G"]))
+    ls, lsg = _pair(np.full(P["G"], 123.0))
+    a = lambda k, i: ten[k][i].data_ptr()
+    assert FK.jlm_wordlist_lse(P["segs_c"], 1, a("b2", 0), a("T", 0), P["ldt"], a("g0", 0), a("cnt", 0), a("cidx", 0),
+                               a("wl", 0), a("off", 0), a("wl_idx", 0), 2, rm.data_ptr(), rs.data_ptr(), ls.data_ptr(),
+                               merge, beam, ng, 0) == 0
+    sp, ts, ds, bc, keep = _split_segments(L, P["segs_g"], None, 1, [6])
+    max_words = int(np.diff(P["off"]).max())
+    assert L.jlm_wordlist_lse_split(sp, ts[0], ds[0], a("b2", 1), a("T", 1), P["ldt"], a("g0", 1), a("cnt", 1), a("cidx", 1),
+                                    a("wl", 1), a("off", 1), a("wl_idx", 1), 2, max_words, rmg.data_ptr(), rsg.data_ptr(),
+                                    lsg.data_ptr(), merge, beam, ng, _st()) == 0
+    torch.cuda.synchronize()
+    got, want = lsg.cpu().numpy(), ls.numpy()
+    fin = np.isfinite(want)
+    assert (np.isfinite(got) == fin).all()
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-6, atol=3e-5)
+    lg = rmg.cpu().numpy().astype(np.float64) + np.log(rsg.cpu().numpy())
+    lc = rm.numpy().astype(np.float64) + np.log(rs.numpy())
+    np.testing.assert_allclose(lg[fin], lc[fin], rtol=1e-6, atol=3e-5)
+
+
 def _beam_problem(rng, B, beam, F, max_nodes):
     """random lattice + beam state, consistent up to frame F-1"""
     rmax, G = B * beam, F * B * beam
