@@ -202,7 +202,7 @@ def main():
     roofline = None
     if vstat:
         split = getattr(m, "split_array", None) is not None
-        kname = ("vocab_lse_split_kernel (jlm_vocab_lse_split)" if split else
+        kname = ("vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                  "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                  else "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
         traffic, traffic_note = None, None
@@ -210,7 +210,7 @@ def main():
         if m.stationary_ok and args.fixture == "mid-vtable" and os.path.exists(tpath):
             with open(tpath) as tf:
                 tj = json.load(tf)
-            if tj.get("kernel", "vocab_lse_stationary_kernel") in kname:
+            if tj.get("kernel", "vocab_lse_stationary_kernel").split("(")[0].strip() in kname:
                 traffic, traffic_note = tj["vocab_lse_hbm_bytes_per_call"], tj["note"]
         # split-f16 form: every algorithmic multiply-add is executed as 3 f16 MFMA passes, so the
         # ceiling for ALGORITHMIC flops is the dense f16 peak / 3
