@@ -219,6 +219,17 @@ int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale, float des
                            float *run_max, double *run_sum, double *lse,
                            int merge, int beam, int n_groups, void *stream);
 
+/* K11 for a whole frame in one launch (DynamicDecoder._incremental_decode, decoder_dynamic.py:133-148):
+ * every row g = fr * rmax + s * beam + slot, fr < n_old_frames, slot < cnt[fr * n_sent + s], of every
+ * sentence s merges the words wl[wl_off[wl_base + s] .. wl_off[wl_base + s + 1]) into its running
+ * (run_max, run_sum) and refreshes lse -- what jlm_wordlist_lse(merge = 1) does for n_old_frames * n_sent
+ * groups, but with one workgroup per sentence gathering the list once.  rmax = n_sent * beam.
+ * Returns -2 outside the kernel's shape (max_words > 128, k > 256, beam > 32). */
+int jlm_wordlist_merge_split(const jlm_segment *seg_host, float t_scale, float descale, const float *b2,
+                             const float *T, int ldt, const int *cnt, int n_sent, int beam, int n_old_frames,
+                             const int *wl, const int *wl_off, int wl_base, int max_words,
+                             float *run_max, double *run_sum, double *lse, void *stream);
+
 /* ------------------------------------------------------------------------
  * Lattice of a batch (CSR, built on the host by jlm_amd/lattice.py following
  * Decoder._build_lattice, decoder.py:79-135), resident in HBM for the decode.

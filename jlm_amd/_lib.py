@@ -56,6 +56,8 @@ _SIGS = {
                          c_int),
     "jlm_wordlist_lse_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, P, P, P, P, P, c_int, c_int, P, P, P,
                                c_int, c_int, c_int, P], c_int),
+    "jlm_wordlist_merge_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_int,
+                                 P, P, P, P], c_int),
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),

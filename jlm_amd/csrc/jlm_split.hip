@@ -700,3 +700,162 @@ extern "C" int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale
     JLM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Incremental vocabulary, K11 (decoder_dynamic.py:133-148): at frame f every OLDER row of a
+// sentence learns the words that first appear at f -- the same short list (tens of words) for all of
+// the sentence's rows.  The group-per-(frame, sentence) kernels above gather that list once per
+// older frame, (f - 1) x 256 workgroups of a few words each (62 us per call at f ~ 10, bound by
+// workgroup turnover).  Here: ONE workgroup per sentence gathers the list's split rows once (all
+// tiles requested up front, <= 128 words = 128 KB of LDS), then its 4 waves walk the sentence's older
+// rows in blocks of 32 (row operands split on the fly, 3 f16 MFMAs per k-step) and merge the list's
+// (max, sum exp) into each row's running pair.  Rows: g = frame * rmax + sentence * beam + slot,
+// slot < cnt[frame * n_sent + sentence] (the layout of jlm_beam_state).
+#define WLM_MAX_WORDS 128
+
+template <int NS>
+__global__ __launch_bounds__(256) void wordlist_merge_split_kernel(
+    jlm_segment sg, float t_scale, float descale, const float *__restrict__ b2, const float *__restrict__ T, int ldt,
+    const int *__restrict__ cnt, int n_sent, int beam, int n_old_frames, const int *__restrict__ wl,
+    const int *__restrict__ wl_off, int wl_base, float *__restrict__ run_max, double *__restrict__ run_sum,
+    double *__restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const int sent = blockIdx.x;
+    const int w0 = wl_off[wl_base + sent], nw = wl_off[wl_base + sent + 1] - w0;
+    if (nw <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, ldb = sg.ldb, rmax = n_sent * beam;
+    const int ntiles = (nw + 31) >> 5;
+    // LDS: [ntiles][NS / 4 chunks][32 words][64 values as split rows] | biases | word rows
+    constexpr int NCH = (NS + 3) / 4;
+    float *Ws = smem;
+    float *bias_l = smem + WLM_MAX_WORDS * NCH * 64;
+    int *wid_s = reinterpret_cast<int *>(bias_l + WLM_MAX_WORDS);
+    for (int i = tid; i < ntiles * 32; i += 256) {
+        const int w = wl[w0 + (i < nw ? i : 0)];                       // padded entries re-read the first word ...
+        wid_s[i] = w - sg.v_start;
+        bias_l[i] = i < nw ? b2[w] * LOG2E : JLM_NEG_BIG;              // ... and are switched off by their bias
+    }
+    __syncthreads();
+    {   // gather: a piece = 4 words x one 64-value chunk (16 granules), lane (lane >> 4, lane & 15); every piece
+        // of the list is requested before anything is waited for
+        const int lrow = lane >> 4, pslot = lane & 15;
+        const int npieces = ntiles * 8 * NCH;
+        for (int p = wave; p < npieces; p += 4) {
+            const int cchunk = p % NCH, w4 = p / NCH;                  // 64-value chunk, group of 4 words
+            const int r = w4 * 4 + lrow;                               // word position in the (padded) list
+            const int g = pslot ^ (r & 15);
+            const unsigned off = ((unsigned)wid_s[r] * (unsigned)ldb + (unsigned)min(cchunk * 64 + g * 4, ldb - 4)) * 4u;
+            GLDS16(reinterpret_cast<const char *>(sg.B) + off, Ws + ((size_t)((w4 >> 3) * NCH + cchunk) * 32 + ((w4 & 7) * 4)) * 64);
+        }
+    }
+    __syncthreads();                                                   // vmcnt(0): the whole list has landed
+    int goff[4][2];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) goff[jj][p] = li * 64 + (((4 * jj + 2 * h + p) ^ (li & 15)) * 4);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n_slots = n_old_frames * beam;                            // uncompacted (frame, slot) pairs of this sentence
+    for (int blk = wave; blk * 32 < n_slots; blk += 4) {
+        const int i = blk * 32 + li;
+        const int fr = i / beam, slot = i - fr * beam;
+        const bool row_ok = i < n_slots && slot < cnt[fr * n_sent + sent];
+        if (!__builtin_amdgcn_readfirstlane(__any(row_ok))) continue;
+        const int g = fr * rmax + sent * beam + slot;
+        const float *trow = T + (size_t)(row_ok ? g : 0) * ldt + sg.t_off;
+        f16x8 thi[NS], tlo[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = 16 * st + 8 * h + 4 * q;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[4 * q + e] = (row_ok && k < K) ? v[e] : 0.0f;
+            }
+            jlm_split8(x, t_scale * LOG2E, thi[st], tlo[st]);
+        }
+        float m = JLM_NEG_BIG, s = 0.0f;
+        for (int t = 0; t < ntiles; ++t) {
+            f32x16 acc0 = zero16, acc1 = zero16;
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const float *bs = Ws + (size_t)(t * NCH + (st >> 2)) * 32 * 64;
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(bs + goff[st & 3][1]);
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(bs + goff[st & 3][0]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, thi[st], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, tlo[st], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, thi[st], acc0, 0, 0, 0);
+            }
+            const float *bt = bias_l + t * 32 + 4 * h;
+            float v[16], tmax = JLM_NEG_BIG;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bt + 8 * jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[4 * jj + e] = fmaf(acc0[4 * jj + e] + acc1[4 * jj + e], descale, b4[e]);
+                    tmax = fmaxf(tmax, v[4 * jj + e]);
+                }
+            }
+            const float mn = fmaxf(m, tmax);
+            float add = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(v[r] - mn);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+            m = mn;
+        }
+        const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        if (h == 0 && row_ok) {                    // merge into the row's running pair (natural-log units)
+            float Mn = mm * LN2;
+            double Sd = (double)s;
+            const float pm = run_max[g];
+            const double ps = run_sum[g];
+            const float mx = fmaxf(pm, Mn);
+            Sd = ps * exp((double)pm - (double)mx) + Sd * exp((double)Mn - (double)mx);
+            run_max[g] = mx;
+            run_sum[g] = Sd;
+            lse[g] = (double)mx + log(Sd);
+        }
+    }
+}
+
+// Returns 0, a HIP error, or -2 when the shape is outside this kernel (use jlm_wordlist_lse with merge = 1).
+extern "C" int jlm_wordlist_merge_split(const jlm_segment *seg_host, float t_scale, float descale, const float *b2,
+                                        const float *T, int ldt, const int *cnt, int n_sent, int beam, int n_old_frames,
+                                        const int *wl, const int *wl_off, int wl_base, int max_words, float *run_max,
+                                        double *run_sum, double *lse, void *stream) {
+    const jlm_segment sg = *seg_host;
+    const int ns = (sg.k + 15) / 16;
+    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (max_words > WLM_MAX_WORDS) return -2;
+    if (n_sent <= 0 || n_old_frames <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define JLM_WLM_LAUNCH(N)                                                                                                  \
+    do {                                                                                                                   \
+        const int lds = (WLM_MAX_WORDS * ((N + 3) / 4) * 64 + 2 * WLM_MAX_WORDS) * 4;                                                      \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_merge_split_kernel<N>),                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
+                return -3;                                                                                                 \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(wordlist_merge_split_kernel<N>, dim3(n_sent), dim3(256), lds, st, sg, t_scale, descale, b2, T,  \
+                           ldt, cnt, n_sent, beam, n_old_frames, wl, wl_off, wl_base, run_max, run_sum, lse);              \
+    } while (0)
+    if (ns <= 4) JLM_WLM_LAUNCH(4);
+    else if (ns <= 8) JLM_WLM_LAUNCH(8);
+    else if (ns <= 12) JLM_WLM_LAUNCH(12);
+    else JLM_WLM_LAUNCH(16);
+#undef JLM_WLM_LAUNCH
+    JLM_LAUNCH_CHECK();
+    return 0;
+}

@@ -221,7 +221,17 @@ class DecodeEngine:
                 join = None
             if dynamic and not self_norm and f >= 2:
                 # K11: older frames learn the words that first appear at frame f
-                wl_lse(ip["g0"], ip["cidx"], ip["dd_words"], ip["dd_off"], f * B, 1, (f - 1) * B, "merge", p.max_words["dd"])
+                r = -2
+                if wl_split and p.max_words["dd"] <= 128:
+                    # one workgroup per sentence: its delta list is gathered once for all of its older rows
+                    r = L.jlm_wordlist_merge_split(m.split_array, m.split_t_scale[0], m.split_descale[0], b2p, Tp, ldt, cntp,
+                                                   B, beam, f - 1, ip["dd_words"], ip["dd_off"], f * B, p.max_words["dd"],
+                                                   p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, st)
+                    if r != -2:
+                        _lib.check(r, "jlm_wordlist_merge_split")
+                if r == -2:
+                    wl_lse(ip["g0"], ip["cidx"], ip["dd_words"], ip["dd_off"], f * B, 1, (f - 1) * B, "merge",
+                           p.max_words["dd"])
             # the full-vocabulary normaliser of frame f-1 left partial slices: beam_step folds them itself
             p.stS.lse_part = p.part.data_ptr() if pending_parts else None
             p.stS.ld_part, p.stS.n_parts = rmax, pending_parts

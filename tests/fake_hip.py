@@ -394,6 +394,43 @@ class FakeLib:
                 ls[:] = m + np.log(s)
         return 0
 
+    def jlm_wordlist_merge_split(self, seg, t_scale, descale, b2, T, ldt, cnt, n_sent, beam, n_old_frames, wl, wl_off,
+                                 wl_base, max_words, run_max, run_sum, lse, stream):
+        """every older row of every sentence merges the sentence's new words (jlm_wordlist_lse merge=1 per cell)"""
+        sg = seg._obj if hasattr(seg, "_obj") else (seg[0] if not hasattr(seg, "k") else seg)
+        if sg.k > 256 or sg.ldb % 16 or beam > 32 or max_words > 128:
+            return -2
+        nv = sg.v_end - sg.v_start
+        Bfull = self._split_read(sg.B, nv, sg.ldb)[:, :sg.k]
+        rmax = n_sent * beam
+        cntv = view(cnt, n_old_frames * n_sent, np.int32)
+        offs = view(_p(wl_off) + 4 * wl_base, n_sent + 1, np.int32)
+        for s in range(n_sent):
+            a, b = int(offs[s]), int(offs[s + 1])
+            if b <= a:
+                continue
+            w = view(_p(wl) + 4 * a, b - a, np.int32).astype(np.int64)
+            Bw = Bfull[w - sg.v_start]
+            bw = view(b2, sg.v_end, np.float32)[w]
+            for fr in range(n_old_frames):
+                n = min(int(cntv[fr * n_sent + s]), beam)
+                if n <= 0:
+                    continue
+                g = fr * rmax + s * beam
+                Tv = np.stack([view(_p(T) + 4 * ((g + k) * ldt + sg.t_off), sg.k, np.float32) for k in range(n)])
+                y = (Bw @ (Tv.astype(np.float64) * float(t_scale)).T * float(descale)).astype(np.float32)
+                y = (y + bw[:, None]).astype(np.float64)
+                m = y.max(axis=0)
+                sm = np.exp(y - m[None, :]).sum(axis=0)
+                rm = view(_p(run_max) + 4 * g, n, np.float32)
+                rs = view(_p(run_sum) + 8 * g, n, np.float64)
+                M = np.maximum(rm.astype(np.float64), m)
+                sm = rs * np.exp(rm - M) + sm * np.exp(m - M)
+                rm[:] = M
+                rs[:] = sm
+                view(_p(lse) + 8 * g, n, np.float64)[:] = M + np.log(sm)
+        return 0
+
     # ------------------------------------------------------------------- beam
     def jlm_beam_step(self, lat, st, frame, mode, max_cands, stream):
         lat, st = lat._obj if hasattr(lat, "_obj") else lat, st._obj if hasattr(st, "_obj") else st

@@ -494,6 +494,46 @@ def test_wordlist_lse_split(L, width, beam, ng, mw, merge):
     np.testing.assert_allclose(lg[fin], lc[fin], rtol=1e-6, atol=3e-5)
 
 
+@pytest.mark.parametrize("width,beam,B,nf,mw", [(256, 10, 7, 6, 40), (100, 20, 3, 19, 128), (32, 3, 20, 2, 5), (200, 10, 64, 12, 70)])
+def test_wordlist_merge_split(L, width, beam, B, nf, mw):
+    """per-sentence merge of a frame's new words into all older rows against its numpy restatement"""
+    rng = np.random.default_rng(width + beam + B + nf)
+    V = 3000
+    segs_c, segs_g, keep, ldt = _segments(rng, V, [width])
+    rmax, G = B * beam, nf * B * beam
+    T, Tg = _pair(rng.standard_normal((G, ldt)).astype(np.float32))
+    b2, b2g = _pair(rng.standard_normal(V).astype(np.float32))
+    cnt, cntg = _pair(rng.integers(0, beam + 1, size=nf * B).astype(np.int32))
+    lists = [rng.integers(0, V, size=int(rng.integers(0, mw + 1))).astype(np.int32) for _ in range(3 * B)]
+    lists[2 * B] = rng.integers(0, V, size=mw).astype(np.int32)
+    off = np.zeros(len(lists) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    wl, wlg = _pair(np.concatenate(lists + [np.zeros(1, np.int32)]))
+    offt, offg = _pair(off)
+    rm, rmg = _pair(rng.standard_normal(G).astype(np.float32))
+    rs, rsg = _pair(rng.uniform(1.0, 50.0, size=G))
+    ls, lsg = _pair(np.full(G, 123.0))
+    sp, ts, ds, bc, keep2 = _split_segments(L, segs_g, keep, 1, [6])
+    sp_c = (_lib.Segment * 1)()
+    host_rows = keep2[0].cpu()
+    sp_c[0] = _lib.Segment(sp[0].v_start, sp[0].v_end, sp[0].k, sp[0].t_off, host_rows.data_ptr(), sp[0].ldb)
+    args = lambda x: (ts[0], ds[0])
+    assert FK.jlm_wordlist_merge_split(sp_c, ts[0], ds[0], b2.data_ptr(), T.data_ptr(), ldt, cnt.data_ptr(), B, beam, nf,
+                                       wl.data_ptr(), offt.data_ptr(), 2 * B, mw, rm.data_ptr(), rs.data_ptr(),
+                                       ls.data_ptr(), 0) == 0
+    assert L.jlm_wordlist_merge_split(sp, ts[0], ds[0], b2g.data_ptr(), Tg.data_ptr(), ldt, cntg.data_ptr(), B, beam, nf,
+                                      wlg.data_ptr(), offg.data_ptr(), 2 * B, mw, rmg.data_ptr(), rsg.data_ptr(),
+                                      lsg.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lsg.cpu().numpy(), ls.numpy(), rtol=1e-6, atol=3e-5)
+    lg = rmg.cpu().numpy().astype(np.float64) + np.log(rsg.cpu().numpy())
+    lc = rm.numpy().astype(np.float64) + np.log(rs.numpy())
+    np.testing.assert_allclose(lg, lc, rtol=1e-6, atol=3e-5)
+    assert L.jlm_wordlist_merge_split(sp, ts[0], ds[0], b2g.data_ptr(), Tg.data_ptr(), ldt, cntg.data_ptr(), B, beam, nf,
+                                      wlg.data_ptr(), offg.data_ptr(), 2 * B, 129, rmg.data_ptr(), rsg.data_ptr(),
+                                      lsg.data_ptr(), _st()) == -2
+
+
 def _beam_problem(rng, B, beam, F, max_nodes):
     """random lattice + beam state, consistent up to frame F-1"""
     rmax, G = B * beam, F * B * beam
