@@ -26,10 +26,13 @@ re-upload of constants per batch).  submit()/collect() split a decode into the
 asynchronous device part and the host read-out, so the strings of batch i are
 built while the GPU decodes batch i+1 (two plans of the same shape alternate).
 
-hipGraph capture of the launch sequence is available (JLM_GRAPH=1) but off by
-default: measured on MI355X the host enqueues well ahead of the device, the GPU is
-already back-to-back busy (9.1 ms of kernels in a 9.15 ms step), so replay gains
-nothing and graph instantiation adds one-off 70 ms stalls.
+For the word-list decodes (vocab_select, incremental vocabulary) and self-normalised models a plan
+that has been launched eagerly twice captures its ~170-launch sequence in a hipGraph and replays it
+from then on (JLM_GRAPH=0 keeps eager launches): their kernels are short enough for the Python
+enqueue loop to be the bottleneck (interleaved A/B, tools/ab_engine.py: incremental 3.08 -> 2.72 ms,
+vocab_select 2.82 -> 2.42 ms per step).  The full-vocabulary decode is device bound and stays
+eager: with replay its two streams overlap worse (3.60 vs 3.15 ms).  One-off shapes never pay for
+a capture.
 """
 import os
 
@@ -52,7 +55,7 @@ class _Plan:
     def __init__(self, eng, key, caps):
         torch, m, dev = eng.torch, eng.m, eng.device
         self.key, self.caps = key, dict(caps)
-        kind, vmode, B, beam, F = key
+        kind, vmode, B, beam, F = key[:5]
         self.B, self.beam, self.F = B, beam, F
         rmax, ncell = B * beam, F * B
         G = F * rmax
@@ -139,7 +142,7 @@ class DecodeEngine:
         self.last_state = None
         self.recorder = None            # optional model.KernelRecorder (bench.py): forces eager launches
         self.last_n_live = None
-        self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "0") == "1"
+        self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "1") == "1"
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"
         self.plans = []
         self._side = {}            # side stream of each launch stream (edge logits beside the normaliser)
@@ -151,8 +154,8 @@ class DecodeEngine:
         self._rr = 0
 
     # ------------------------------------------------------------------ plans
-    def _plan_for(self, kind, vmode, lat, need):
-        key = (kind, vmode, lat.n_sent, lat.beam, lat.n_frames)
+    def _plan_for(self, kind, vmode, lat, need, size_class=()):
+        key = (kind, vmode, lat.n_sent, lat.beam, lat.n_frames, size_class)
         for i, p in enumerate(self.plans):
             if p.key == key and p.fits(need) and not p.busy:
                 self.plans.append(self.plans.pop(i))
@@ -171,7 +174,7 @@ class DecodeEngine:
     def _enqueue(self, p, timing):
         """The whole launch sequence of one batch (no host synchronisation inside)."""
         torch, m, L = self.torch, self.m, _lib.lib()
-        kind, vmode, B, beam, F = p.key
+        kind, vmode, B, beam, F = p.key[:5]
         rmax = p.rmax
         dynamic = kind == "dynamic"
         self_norm = m.self_norm
@@ -302,7 +305,18 @@ class DecodeEngine:
         vmode = "dynamic" if dynamic else ("select" if vocab is not None else "full")
         need = dict(nodes=lat.n_nodes, vs=len(vocab[0]) if vocab is not None else 0,
                     di=len(dyn_lists[0]) if dynamic else 0, dd=len(dyn_lists[2]) if dynamic else 0, cands=lat.max_cands)
-        p = self._plan_for(kind, vmode, lat, need)
+
+        # longest word list per kind of call (selected vocabulary / frame-initial / frame-delta lists).  Which
+        # kernel a call uses depends on it, and a captured graph bakes that choice in, so the size class is
+        # part of the plan's identity.
+        def longest(offs):
+            o = np.asarray(offs)
+            return int(np.diff(o).max()) if o.size > 1 else 0
+        max_words = dict(vs=longest(vocab[1]) if vocab is not None else 0,
+                         di=longest(dyn_lists[1]) if dynamic else 0, dd=longest(dyn_lists[3]) if dynamic else 0)
+        size_class = tuple((v < 128, v <= 128, v <= 4064) for v in (max_words["vs"], max_words["di"], max_words["dd"]))
+        p = self._plan_for(kind, vmode, lat, need, size_class)
+        p.max_words = max_words
         p.busy = True
         p._set("sent_len", lat.sent_len)
         p._set("end_off", lat.end_off)
@@ -319,24 +333,19 @@ class DecodeEngine:
             p._set("di_off", dyn_lists[1])
             p._set("dd_words", dyn_lists[2])
             p._set("dd_off", dyn_lists[3])
-        # longest word list per kind of call (selected vocabulary / frame-initial / frame-delta lists)
-        def longest(offs):
-            o = np.asarray(offs)
-            return int(np.diff(o).max()) if o.size > 1 else 0
-        p.max_words = dict(vs=longest(vocab[1]) if vocab is not None else 0,
-                           di=longest(dyn_lists[1]) if dynamic else 0, dd=longest(dyn_lists[3]) if dynamic else 0)
         p.dev_ints.copy_(p.host_ints, non_blocking=True)
-        eager = (not self.use_graph) or timing or (self.recorder is not None)
+        p.uses = getattr(p, "uses", 0) + 1
+        # replay pays where the step is bound by the Python enqueue loop: the word-list decodes (vocab_select,
+        # incremental) and self-normalised models, whose kernels are all short.  The full-vocabulary decode is
+        # device bound and runs better eagerly on its two streams (3.15 vs 3.60 ms, tools/ab_engine.py).
+        graph_ok = self.use_graph and (p.key[1] != "full" or self.m.self_norm)
+        eager = (not graph_ok) or timing or (self.recorder is not None) or (p.graph is None and p.uses <= 2)
         ev = []
         if eager:
             ev = self._enqueue(p, timing)
             p.warm = True
         else:
-            if p.graph is None:
-                if not p.warm:                     # first use of this shape: lazy kernel attributes, allocator warm-up
-                    self._enqueue(p, False)
-                    torch.cuda.synchronize()
-                    p.warm = True
+            if p.graph is None:                    # third use of this plan: worth a capture
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._enqueue(p, False)

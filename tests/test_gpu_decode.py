@@ -70,11 +70,15 @@ def test_step_logits_within_1e4_of_reference(name, fx, golden_lm):
             np.testing.assert_allclose(pred.sum(axis=1), golden_lm[key + "/predsum"], rtol=1e-4)
 
 
+@pytest.mark.parametrize("fast", [False, True], ids=["timed", "fast"])
 @pytest.mark.parametrize("case", gc.DECODE_CASES, ids=[c[0] for c in gc.DECODE_CASES])
-def test_decode_matches_reference_golden(case, fx, golden_decode):
+def test_decode_matches_reference_golden(case, fast, fx, golden_decode):
+    """timed: per-frame HIP events, one stream (what eval.py's perf logs need); fast: the throughput path --
+    alternating streams, side stream, graph replay when enabled"""
     name, fixture, kind, kwargs, spec = case
     f = fx(fixture)
     dec = _decoder(f, kind)
+    dec.perf_timing = not fast
     sents = gc.case_sentences(spec, f["alphabet"])
     gold = golden_decode[name]
     assert [g["input"] for g in gold] == sents
@@ -115,6 +119,7 @@ def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
 def test_single_sentence_equals_batch(fx):
     f = fx("small-vtable")
     dec = _decoder(f, "static")
+    dec.perf_timing = True
     sents = synth.make_ragged_sentences(9, 1, 18, seed=31, alphabet=f["alphabet"])
     batch = dec.decode_batch(sents, beam_width=6)
     for s, b in zip(sents, batch):

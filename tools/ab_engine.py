@@ -1,56 +1,50 @@
-"""A/B of engine options in ONE process, interleaved (the chip's clocks drift between runs, so
-separate bench runs cannot resolve a few per cent): configs[1] batch, pipelined submit/collect."""
+"""A/B of engine options in ONE process, interleaved (the chip's clocks drift between runs and boxes, so
+separate bench runs cannot resolve a few per cent): pipelined submit/collect as Decoder.decode_batch does.
+usage: ab_engine.py [fixture] [static|static-vs|dynamic]"""
 import os, sys, time, tempfile
+from collections import deque
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import torch
 from jlm_amd import config as jconfig, synth
 from jlm_amd.decoder import Decoder
-from jlm_amd.lattice import BatchLattice
+from jlm_amd.decoder_dynamic import DynamicDecoder
 root = os.path.join(tempfile.gettempdir(), "jlm_dbg")
-cfg, _l, _r, al = synth.build_fixture(root, sys.argv[1] if len(sys.argv) > 1 else "mid-vtable")
+fixture = sys.argv[1] if len(sys.argv) > 1 else "mid-vtable"
+mode = sys.argv[2] if len(sys.argv) > 2 else "static"
+cfg, _l, _r, al = synth.build_fixture(root, fixture)
 jconfig.set_root(root)
-dec = Decoder(1); dec.perf_timing = False
+dec = (DynamicDecoder if mode == "dynamic" else Decoder)(1); dec.perf_timing = False
 eng = dec._engine
 sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
+from jlm_amd.lattice import BatchLattice
 lat = BatchLattice(dec._builder, sents, 10)
+kw = {}
+if mode == "static-vs":
+    words, off, lists = lat.static_vocab(0, False, False, len(dec.w2i)); kw = dict(vocab=(words, off))
+if mode == "dynamic":
+    iw, io, dw, do, _ = lat.dynamic_vocab(0, False, False, len(dec.w2i)); kw = dict(dyn_lists=(iw, io, dw, do))
+kind = "dynamic" if mode == "dynamic" else "static"
 
-def run_pipe(n=12):
-    prev = None
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n):
-        tk = eng.submit(lat, "static", topN=10)
-        if prev is not None: eng.collect(prev)
-        prev = tk
-    eng.collect(prev)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
-
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-
-def run_pipe2(n=12, depth=2):
-    """consecutive steps on alternating streams: the device work of step i+1 may overlap step i's"""
-    from collections import deque
+def run_pipe(n, depth):
     q = deque()
     torch.cuda.synchronize(); t = time.perf_counter()
-    for it in range(n):
-        with torch.cuda.stream(streams[it % 2]):
-            q.append(eng.submit(lat, "static", topN=10))
+    for _ in range(n):
+        q.append(eng.submit(lat, kind, topN=10, **kw))
         if len(q) > depth: eng.collect(q.popleft())
     while q: eng.collect(q.popleft())
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-variants = {"eager+side": (False, True), "2 streams d2": (False, True, 2), "2 streams d3": (False, True, 3), "eager": (False, False)}
+variants = {"1 stream eager": (1, False), "1 stream graph": (1, True), "2 streams eager": (2, False), "2 streams graph": (2, True)}
 def run(v):
-    eng.use_graph, eng.use_side = v[0], v[1]
-    return run_pipe2(12, v[2]) if len(v) > 2 else run_pipe(12)
-for _ in range(3):
-    for v in variants.values():
-        run(v)
+    eng.n_streams, eng.use_graph = v
+    eng._rr = 0
+    return run_pipe(12, v[0])
+for _ in range(4):
+    for v in variants.values(): run(v)
 res = {k: [] for k in variants}
 for rep in range(8):
-    for k, v in variants.items():
-        res[k].append(run(v))
+    for k, v in variants.items(): res[k].append(run(v))
 for k, v in res.items():
-    print("%-12s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
+    print("%-16s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
