@@ -388,25 +388,33 @@ class DecodeEngine:
 
     @staticmethod
     def _read_out(lat, nodes_h, len_h, score_h, topN):
+        """n-best lists of the batch from the back-traces: [(score, [word, ...])] per sentence, best first.
+        Vectorised: one gather of all paths' node ids, one node -> string lookup, two tolist() calls."""
         B, beam = lat.n_sent, lat.beam
-        # flatten every path (reversed: last word first), drop the <eos> root
-        sel = []
+        R = min(beam, topN)
+        ln = np.asarray(len_h).reshape(B, beam)[:, :R]
+        # ranks are filled from 0; a sentence's list ends at its first empty rank
+        valid = np.logical_and.accumulate(ln > 0, axis=1)
+        nrank = valid.sum(axis=1)
+        rows = (np.arange(B)[:, None] * beam + np.arange(R)[None, :])[valid]          # path rows, sentence-major
+        k = ln[valid].astype(np.int64) - 1                                             # words per path (root dropped)
+        kmax = int(k.max()) if k.size else 0
+        flat_words = []
+        if kmax > 0:
+            cols = np.arange(kmax)[None, :]
+            keep = cols < k[:, None]
+            src = np.where(keep, k[:, None] - 1 - cols, 0)                             # reversed: last word first in the trace
+            ids = np.take_along_axis(np.asarray(nodes_h)[rows][:, :max(kmax, 1)], src, axis=1)[keep]
+            flat_words = lat.words_of(ids).tolist()
+        ends = np.cumsum(k).tolist()
+        scores = np.asarray(score_h)[rows].tolist()
+        out, p, a = [], 0, 0
         for s in range(B):
-            for r in range(min(beam, topN)):
-                i = s * beam + r
-                n = int(len_h[i])
-                if n == 0:
-                    break
-                sel.append((i, n))
-        words = np.zeros(0, dtype=object)
-        if sel and any(n > 1 for _, n in sel):
-            flat = np.concatenate([nodes_h[i, :n - 1][::-1] for i, n in sel])
-            words = lat.words_of(flat)
-        out = [[] for _ in range(B)]
-        pos = 0
-        for i, n in sel:
-            k = n - 1
-            ws = words[pos:pos + k].tolist() if k else []
-            pos += k
-            out[i // beam].append((float(score_h[i]), ws))
+            lst = []
+            for _ in range(int(nrank[s])):
+                e = ends[p]
+                lst.append((scores[p], flat_words[a:e]))
+                a = e
+                p += 1
+            out.append(lst)
         return out
