@@ -55,6 +55,7 @@ def main():
 
     import numpy as np
     import torch
+    import jlm_amd          # before the HIP runtime initialises: it defaults GPU_MAX_HW_QUEUES (jlm_amd/__init__.py)
     import __graft_entry__ as ge
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,0 +1,31 @@
+"""MI355X-native LSTM inference + lattice beam-search decoders behind the JLM reference's API."""
+import os
+import sys
+
+
+def _want_hw_queues(n=8):
+    """The decode engine keeps up to four HIP streams busy (two batches in flight, each with a side
+    stream for its edge logits).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4,
+    one of them the null stream's); streams that share a queue serialise, and with 4 queues a side
+    stream lands on the other batch's queue -- the two-stream overlap is gone (3.8 instead of 2.8 ms per
+    step, tools/probes/streams_probe.py).  The variable is read when the HIP runtime initialises, so it
+    can only be defaulted here if that has not happened yet; the engine asks hw_queues_ok() and falls
+    back to running the edge logits on the batch's own stream."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        try:
+            return int(cur) >= n
+        except ValueError:
+            return False
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    return True
+
+
+_HW_QUEUES_OK = _want_hw_queues()
+
+
+def hw_queues_ok():
+    return _HW_QUEUES_OK

@@ -46,5 +46,6 @@ for _ in range(4):
 res = {k: [] for k in variants}
 for rep in range(8):
     for k, v in variants.items(): res[k].append(run(v))
+print("streams created:", len(eng._streams), "plans:", len(eng.plans))
 for k, v in res.items():
     print("%-16s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
