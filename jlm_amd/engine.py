@@ -144,6 +144,7 @@ class DecodeEngine:
         self.last_n_live = None
         self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "1") == "1"
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"       # edge logits beside the normaliser
+        self.graph_full = os.environ.get("JLM_GRAPH_FULL", "0") == "1"  # replay for the full-vocabulary decode too
         self.plans = []
         self._side = {}            # side stream of each launch stream (edge logits beside the normaliser)
         # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
@@ -342,7 +343,7 @@ class DecodeEngine:
         # replay pays where the step is bound by the Python enqueue loop: the word-list decodes (vocab_select,
         # incremental) and self-normalised models, whose kernels are all short.  The full-vocabulary decode is
         # device bound and runs better eagerly on its two streams (3.15 vs 3.60 ms, tools/ab_engine.py).
-        graph_ok = self.use_graph and (p.key[1] != "full" or self.m.self_norm)
+        graph_ok = self.use_graph and (p.key[1] != "full" or self.m.self_norm or self.graph_full)
         eager = (not graph_ok) or timing or (self.recorder is not None) or (p.graph is None and p.uses <= 2)
         ev = []
         if eager:

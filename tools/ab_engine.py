@@ -39,6 +39,7 @@ def run_pipe(n, depth):
 variants = {"1 stream eager": (1, False), "1 stream graph": (1, True), "2 streams eager": (2, False), "2 streams graph": (2, True)}
 def run(v):
     eng.n_streams, eng.use_graph = v
+    eng.graph_full = True            # let the variants decide
     eng._rr = 0
     return run_pipe(12, v[0])
 for _ in range(4):
