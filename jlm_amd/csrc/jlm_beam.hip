@@ -14,7 +14,7 @@
 // word per pass -> coalesced), 32 words per pass; rows are processed 8 at a time
 // out of registers; partial dots are reduced over the 8 lanes with 3 xor-shuffles.
 #define WL_THREADS 256
-#define WL_ROWS 8
+#define WL_ROWS 16        // hypothesis rows per pass: beam <= 16 reads every weight row once
 
 template <int MODE>   // 0: edge logits, 1: log-sum-exp over the list
 __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
@@ -61,16 +61,39 @@ __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
             float acc[WL_ROWS];
 #pragma unroll
             for (int r = 0; r < WL_ROWS; ++r) acc[r] = 0.0f;
-            for (int kc = sub; kc < K4; kc += 8) {
-                const f32x4 bv = brow[kc];
+            // the word's whole share of the weight row is requested before any of it is used (k <= 256: at
+            // most 8 x 16 B per lane): one memory round trip per word instead of one per 32 k-values
+            f32x4 bv[8];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const int kc = sub + 8 * c8;
+                bv[c8] = (kc < K4 && kc < 64) ? brow[kc] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const int kc = sub + 8 * c8;
+                if (kc >= K4 || kc >= 64) continue;
 #pragma unroll
                 for (int r = 0; r < WL_ROWS; ++r) {
                     if (rc + r < nrows) {
                         const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)(rc + r) * ldt + toff + kc * 4);
-                        acc[r] = fmaf(bv[0], tv[0], acc[r]);
-                        acc[r] = fmaf(bv[1], tv[1], acc[r]);
-                        acc[r] = fmaf(bv[2], tv[2], acc[r]);
-                        acc[r] = fmaf(bv[3], tv[3], acc[r]);
+                        acc[r] = fmaf(bv[c8][0], tv[0], acc[r]);
+                        acc[r] = fmaf(bv[c8][1], tv[1], acc[r]);
+                        acc[r] = fmaf(bv[c8][2], tv[2], acc[r]);
+                        acc[r] = fmaf(bv[c8][3], tv[3], acc[r]);
+                    }
+                }
+            }
+            for (int kc = sub + 64; kc < K4; kc += 8) {            // k > 256 (untied models): the tail, as before
+                const f32x4 bw = brow[kc];
+#pragma unroll
+                for (int r = 0; r < WL_ROWS; ++r) {
+                    if (rc + r < nrows) {
+                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)(rc + r) * ldt + toff + kc * 4);
+                        acc[r] = fmaf(bw[0], tv[0], acc[r]);
+                        acc[r] = fmaf(bw[1], tv[1], acc[r]);
+                        acc[r] = fmaf(bw[2], tv[2], acc[r]);
+                        acc[r] = fmaf(bw[3], tv[3], acc[r]);
                     }
                 }
             }
