@@ -111,3 +111,62 @@ def test_model_helpers(fx):
         want.append(-np.log(p[0, w]))
         prev = w
     np.testing.assert_allclose(nll, want, rtol=1e-4)
+
+
+def _rescaled_fixture(tmp_path, name, edit):
+    """a copy of fixture `name` whose weights went through edit(dict) -> same model family, other ranges"""
+    import os
+    import pickle
+    root = str(tmp_path / name)
+    cfg, _lx, _rd, alphabet = synth.build_fixture(root, name)
+    wp = os.path.join(root, "train", "experiments", "1", "weights", "lstm_weights.pkl")
+    with open(wp, "rb") as fh:
+        w = pickle.load(fh)
+    edit(w)
+    with open(wp, "wb") as fh:
+        pickle.dump(w, fh)
+    return dict(root=root, cfg=cfg, alphabet=alphabet)
+
+
+def _scale_out(k_out, k_proj):
+    def edit(w):
+        for key in list(w):
+            if key.startswith("LM"):
+                w[key] = [b * np.float32(k_out) for b in w[key]] if isinstance(w[key], list) else w[key] * np.float32(k_out)
+            if key == "PM":
+                w[key] = w[key] * np.float32(k_proj)
+    return edit
+
+
+def _big_bias(w):
+    n = w["b2"].shape[0]
+    w["b2"] = (w["b2"] + np.linspace(-40.0, 40.0, n).astype(np.float32)[np.random.RandomState(5).permutation(n)]).astype(np.float32)
+
+
+def _zero_rows(w):
+    for key in list(w):
+        if key.startswith("LM") and not isinstance(w[key], list):
+            w[key] = w[key].copy()
+            w[key][3::7] = 0.0
+    w["PM"] = w["PM"].copy()
+    w["PM"][:, 1::5] = 0.0
+
+
+@pytest.mark.parametrize("name,edit,tag", [
+    ("small-vtable", _scale_out(16.0, 1.0 / 16.0), "large output embeddings, small projection"),
+    ("small-tied", _scale_out(1.0 / 64.0, 64.0), "small embeddings, large projection"),
+    ("small-vtable", _big_bias, "biases spread over +-40"),
+    ("small-tied", _big_bias, "biases spread over +-40"),
+    ("small-vtable", _scale_out(1.0, 1e-3), "projection ~1e-3: logits are the biases"),
+    ("small-tied", _zero_rows, "zero embedding rows and projection columns"),
+], ids=lambda v: v if isinstance(v, str) else getattr(v, "__name__", "edit"))
+def test_operand_ranges_of_the_split_kernels(name, edit, tag, tmp_path):
+    """The split-f16 kernels choose power-of-two scales from the weights' ranges (DeviceModel._build_split);
+    the decode must stay on the oracle whatever those ranges are."""
+    f = _rescaled_fixture(tmp_path, name, edit)
+    d, o = _pair(f, "static")
+    assert d.model.dev.split_array is not None
+    sents = synth.make_ragged_sentences(6, 3, 15, seed=123, alphabet=f["alphabet"])
+    got = d.decode_batch(sents, beam_width=6)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=6), (tag, s))
