@@ -71,6 +71,7 @@ class Decoder():
         self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
+        self._pool = None                # worker thread that builds the lattices of upcoming chunks
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20
         # batches (tools/probes/stall_probe.py).  Park them in the permanent generation.
@@ -109,15 +110,19 @@ class Decoder():
             raise ValueError("empty input string")
         if not inputs:
             return []
-        out, inflight = [], deque()
-        for i in range(0, len(inputs), self.max_batch):
+        def prepare(i):
+            """host side of chunk i: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
+            if not vocab_select:
+                return lat, None, None
+            words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+            return lat, (words, off), lists[-1]
+
+        out, inflight = [], deque()
+        for lat, vocab, last_list in self._prefetched(prepare, range(0, len(inputs), self.max_batch)):
             self.last_lattice = lat
-            vocab = None
             if vocab_select:
-                words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
-                vocab = (words, off)
-                self.lattice_vocab = lists[-1]
+                self.lattice_vocab = last_list
             inflight.append(self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing))
             # two chunks stay in flight (the engine alternates streams); the strings of chunk i-2 are
             # built while the GPU decodes chunks i-1 and i
@@ -129,6 +134,25 @@ class Decoder():
             self._log_perf()
         self.perf_sen += len(inputs)
         return out
+
+    def _prefetched(self, prepare, starts, ahead=2):
+        """prepare(start) for every chunk, in order, `ahead` chunks before they are consumed: with more than
+        one chunk the lattices are built on a worker thread (one, so the order of any RNG use is kept) while
+        this thread enqueues launches and builds strings."""
+        starts = list(starts)
+        if len(starts) <= 1:
+            for i in starts:
+                yield prepare(i)
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jlm-lattice")
+        futs = deque(self._pool.submit(prepare, i) for i in starts[:ahead])
+        for j in range(len(starts)):
+            item = futs.popleft().result()
+            if j + ahead < len(starts):
+                futs.append(self._pool.submit(prepare, starts[j + ahead]))
+            yield item
 
     def decode(self, input, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
                random_sampling=False):

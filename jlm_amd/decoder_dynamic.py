@@ -50,10 +50,12 @@ class DynamicDecoder(Decoder):
             self.perf_log_fix_vocab.extend([0.0] * max(n, 1))
             self.perf_log_fix_lattice_path_prob.extend([0.0] * max(n, 1))
 
-        for i in range(0, len(inputs), self.max_batch):
+        def prepare(i):
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
+            return (lat,) + tuple(lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i)))
+
+        for lat, iw, io, dw, do, lv_final in self._prefetched(prepare, range(0, len(inputs), self.max_batch)):
             self.last_lattice = lat
-            iw, io, dw, do, lv_final = lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i))
             self.lattice_vocab = lv_final[-1]
             inflight.append(self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN,
                                                 timing=self.perf_timing))
