@@ -277,7 +277,10 @@ class DecodeEngine:
                     wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["vs_words"], ip["vs_off"], 0, 0, B, "vocab_select",
                            p.max_words["vs"])
                 else:
-                    pending_parts = m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, rmax, ndev, st,
+                    # frame 0 has one row per sentence: telling the kernel so lets it cut the vocabulary into
+                    # more ranges (one resident round of workgroups) instead of leaving nine tenths of the CUs idle
+                    bound = B if f == 0 else rmax
+                    pending_parts = m.full_vocab_lse(Tp, rows, p.part.data_ptr(), rmax, p.n_part, lsep, bound, ndev, st,
                                                       self.recorder, combine=False)
             if timing:
                 e2.record()
