@@ -40,8 +40,8 @@ SPLIT_PASSES = 3                    # f16x3: hi.hi + hi.lo + lo.hi per f32-grade
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="sentences per GPU per step")
     ap.add_argument("--length", type=int, default=20, help="kana per sentence")
     ap.add_argument("--beam", type=int, default=10)
