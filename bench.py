@@ -161,7 +161,7 @@ def main():
     # host-inclusive rate (not `value`): kana strings in -> n-best strings out through the product
     # entry point; decode_batch pipelines its chunks (native lattice build + upload of chunk i+1 and
     # string read-out of chunk i-1 run while the GPU decodes chunk i)
-    e2e_steps = max(2, min(6, args.steps))
+    e2e_steps = max(2, min(24, args.steps))
     dec.max_batch = args.batch
     dec.decode_batch(sents * 2, beam_width=args.beam, **dkw)
     barrier()

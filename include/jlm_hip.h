@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 2
+#define JLM_ABI_VERSION 3
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
 int jlm_device_arch(int dev, char *buf, int buflen);
@@ -286,6 +286,62 @@ int jlm_backtrace(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
  * pred[r, :] = self_norm ? exp(y[r, :]) : softmax(y[r, :]). */
 int jlm_softmax_rows(const float *y, float *pred, int ld, int n_rows, int n_cols,
                      int self_norm, void *stream);
+
+/* ------------------------------------------------------------------------
+ * ABI 3: the frame loop itself.  Decoder.decode (decoder/decoder.py:220-241:
+ * for every frame build the candidates, keep the best `beam`, step the LSTM of
+ * the survivors) and DynamicDecoder.decode / _incremental_decode
+ * (decoder/decoder_dynamic.py:177-194, 93-175) as ONE call that enqueues the
+ * whole launch sequence of a batch -- per frame
+ *   [incremental: merge the frame's new words into all older rows]  jlm_wordlist_merge_split | jlm_wordlist_lse(merge)
+ *   jlm_beam_step                (folds the previous frame's normaliser slices)
+ *   jlm_lstm_step(_split), jlm_gemm_nt(_split) (T projection)
+ *   jlm_edge_logits              (on `side_stream` when given, forked after T and joined before the next beam step)
+ *   jlm_vocab_lse_split | _stationary | jlm_wordlist_lse(_split)
+ * and jlm_backtrace at the end -- exactly the calls a host would make one by
+ * one through the entry points above (jlm_amd/engine.py does, for timing and
+ * for models outside this call's shapes), without ~170 trips through the host
+ * language's FFI per batch.  Nothing here synchronises with the device.
+ */
+typedef struct {
+    const jlm_segment *segs;        /* f32 segments (edge logits, short word lists) */
+    int n_segs;
+    const float *b2;
+    int H, ldt;
+    int untied;                     /* T aliases h: no T projection (model.py:189-191) */
+    int self_norm;                  /* no normaliser at all (model.py:117-118) */
+    int split_lstm;                 /* state rows and gate matrix are split rows */
+    /* jlm_lstm_step operands (split_lstm == 0) */
+    const float *emb; int ld_emb; const float *wt; const float *gate_bias; int kpad, E;
+    /* jlm_lstm_step_split operands (split_lstm == 1; input side = xgate table) */
+    const void *wt_split; int kpad_split; float gate_descale, h_scale; const float *xgate;
+    /* T projection: [n_t, H] panel, plain or split rows */
+    const float *pmt; const void *pmt_split; int n_t; float t_descale;
+    /* full-vocabulary normaliser: split segments (NULL: f32 rows-stationary form) */
+    const jlm_segment *split_segs; const float *split_t_scale; const float *split_descale; const int *split_bias_col;
+} jlm_decode_model;
+
+typedef struct {
+    int kind;                       /* 0 static, full vocabulary; 1 static, selected vocabulary; 2 incremental */
+    int max_cands;
+    void *h; float *c; float *T;    /* [G, H] state rows (f32 or split), [G, H] f32, [G, ldt] f32 */
+    const int *g0, *cidx, *sidx;    /* [n_frames*n_sent]: first row of a cell, cell index, sentence index */
+    const int *sg_word, *sg_off, *sg_node;   /* lattice edges grouped by START (frame, sentence): word, CSR, node id */
+    float *edge;                    /* == jlm_beam_state.edge */
+    const int *vs_words, *vs_off; int vs_max;   /* kind 1: per-sentence selected vocabulary, longest list */
+    const int *di_words, *di_off; int di_max;   /* kind 2: vocabulary a frame starts with, per (frame, sentence) */
+    const int *dd_words, *dd_off; int dd_max;   /* kind 2: words new at a frame, per (frame, sentence) */
+    float *run_max; double *run_sum;            /* kinds 1, 2: running (max, sum exp) per row */
+    float *part; int max_parts;                 /* kind 0: [max_parts][rmax][2] partial slices */
+    int *out_nodes; int *out_len; double *out_score; int stride;    /* jlm_backtrace outputs */
+} jlm_decode_plan;
+
+/* Returns 0, a hipError_t, or -2 when the model is outside the shapes this call
+ * covers (full vocabulary with a segment of k > 256: enqueue the calls one by
+ * one then).  st_host->lse_part / n_parts are managed by the call. */
+int jlm_decode_frames(const jlm_decode_model *model_host, const jlm_decode_plan *plan_host,
+                      const jlm_lattice *lat_host, const jlm_beam_state *st_host,
+                      void *stream, void *side_stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,30 @@ class BeamState(Structure):
                 ("live_base", c_void_p), ("lse_part", c_void_p), ("ld_part", c_int), ("n_parts", c_int)]
 
 
+class DecodeModel(Structure):
+    """jlm_decode_model (include/jlm_hip.h)."""
+    _fields_ = [("segs", POINTER(Segment)), ("n_segs", c_int), ("b2", c_void_p), ("H", c_int), ("ldt", c_int),
+                ("untied", c_int), ("self_norm", c_int), ("split_lstm", c_int),
+                ("emb", c_void_p), ("ld_emb", c_int), ("wt", c_void_p), ("gate_bias", c_void_p), ("kpad", c_int), ("E", c_int),
+                ("wt_split", c_void_p), ("kpad_split", c_int), ("gate_descale", c_float), ("h_scale", c_float),
+                ("xgate", c_void_p),
+                ("pmt", c_void_p), ("pmt_split", c_void_p), ("n_t", c_int), ("t_descale", c_float),
+                ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
+                ("split_bias_col", POINTER(c_int))]
+
+
+class DecodePlan(Structure):
+    """jlm_decode_plan (include/jlm_hip.h)."""
+    _fields_ = [("kind", c_int), ("max_cands", c_int), ("h", c_void_p), ("c", c_void_p), ("T", c_void_p),
+                ("g0", c_void_p), ("cidx", c_void_p), ("sidx", c_void_p),
+                ("sg_word", c_void_p), ("sg_off", c_void_p), ("sg_node", c_void_p), ("edge", c_void_p),
+                ("vs_words", c_void_p), ("vs_off", c_void_p), ("vs_max", c_int),
+                ("di_words", c_void_p), ("di_off", c_void_p), ("di_max", c_int),
+                ("dd_words", c_void_p), ("dd_off", c_void_p), ("dd_max", c_int),
+                ("run_max", c_void_p), ("run_sum", c_void_p), ("part", c_void_p), ("max_parts", c_int),
+                ("out_nodes", c_void_p), ("out_len", c_void_p), ("out_score", c_void_p), ("stride", c_int)]
+
+
 P = c_void_p
 _SIGS = {
     "jlm_abi_version": ([], c_int),
@@ -61,6 +85,7 @@ _SIGS = {
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
+    "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P], c_int),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -88,7 +113,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 2:
+        if l.jlm_abi_version() != 3:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -1,0 +1,136 @@
+// jlm_decode.hip -- the frame loop of a batched decode as one C-ABI call (jlm_decode_frames, include/jlm_hip.h).
+// Host code only: it enqueues the launchers of jlm_gemm.hip / jlm_split.hip / jlm_beam.hip in the order
+// jlm_amd/engine.py documents, so a batch costs one FFI call instead of ~170.
+#include <hip/hip_runtime.h>
+#include "../../include/jlm_hip.h"
+
+namespace {
+
+// fork/join events for the edge-logit side stream.  A wait binds to the record that precedes it at
+// enqueue time, so a small rotating pool is enough however many batches are in flight.
+struct EventPool {
+    static constexpr int N = 32;
+    hipEvent_t ev[N];
+    int next = 0;
+    bool ready = false;
+    hipError_t get(hipEvent_t *out) {
+        if (!ready) {
+            for (int i = 0; i < N; ++i) {
+                hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+                if (e != hipSuccess) return e;
+            }
+            ready = true;
+        }
+        *out = ev[next];
+        next = (next + 1) % N;
+        return hipSuccess;
+    }
+};
+thread_local EventPool g_events;
+
+#define JLM_TRY(x) do { int rc_ = (x); if (rc_ != 0) return rc_; } while (0)
+#define JLM_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+}  // namespace
+
+extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_plan *p, const jlm_lattice *lat,
+                                 const jlm_beam_state *st_in, void *stream, void *side_stream) {
+    const int B = lat->n_sent, beam = lat->beam, F = lat->n_frames;
+    const int rmax = B * beam;
+    const bool dynamic = p->kind == 2, select = p->kind == 1, full = p->kind == 0;
+    const int mode = m->self_norm ? 1 : (dynamic ? 2 : 0);
+    const bool wl_split = m->split_segs != nullptr && m->n_segs == 1 && beam <= 32;
+    if (full && !m->self_norm)
+        for (int i = 0; i < m->n_segs; ++i)
+            if (m->segs[i].k > 256) return -2;
+    jlm_beam_state st = *st_in;
+    hipStream_t main_s = (hipStream_t)stream, side_s = (hipStream_t)side_stream;
+    hipEvent_t join = nullptr;
+    int pending_parts = 0;
+
+    // word-list normaliser: split rows (deep gather ring) for lists of 128 .. 4064 words, else the f32 kernel
+    auto wl_lse = [&](const int *g0, const int *cidx, const int *words, const int *off, int base, int merge, int n_groups,
+                      int max_words) -> int {
+        if (wl_split && max_words >= 128 && max_words <= 4064) {
+            int r = jlm_wordlist_lse_split(m->split_segs, m->split_t_scale[0], m->split_descale[0], m->b2, p->T, m->ldt, g0,
+                                           st.cnt, cidx, words, off, p->sidx, base, max_words, p->run_max, p->run_sum, st.lse,
+                                           merge, beam, n_groups, stream);
+            if (r != -2) return r;
+        }
+        return jlm_wordlist_lse(m->segs, m->n_segs, m->b2, p->T, m->ldt, g0, st.cnt, cidx, words, off, p->sidx, base,
+                                p->run_max, p->run_sum, st.lse, merge, beam, n_groups, stream);
+    };
+
+    for (int f = 0; f < F; ++f) {
+        if (join) {
+            JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
+            join = nullptr;
+        }
+        if (dynamic && !m->self_norm && f >= 2) {
+            int r = -2;
+            if (wl_split && p->dd_max <= 128)
+                r = jlm_wordlist_merge_split(m->split_segs, m->split_t_scale[0], m->split_descale[0], m->b2, p->T, m->ldt,
+                                             st.cnt, B, beam, f - 1, p->dd_words, p->dd_off, f * B, p->dd_max, p->run_max,
+                                             p->run_sum, st.lse, stream);
+            if (r == -2) r = wl_lse(p->g0, p->cidx, p->dd_words, p->dd_off, f * B, 1, (f - 1) * B, p->dd_max);
+            JLM_TRY(r);
+        }
+        st.lse_part = pending_parts ? p->part : nullptr;
+        st.ld_part = rmax;
+        st.n_parts = pending_parts;
+        JLM_TRY(jlm_beam_step(lat, &st, f, mode, p->max_cands, stream));
+        pending_parts = 0;
+        if (f == F - 1) break;
+        const int *rows = st.live + (size_t)f * rmax;
+        const int *ndev = st.n_live + f;
+        if (m->split_lstm)
+            JLM_TRY(jlm_lstm_step_split(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, nullptr, 0, m->wt_split, nullptr,
+                                        m->kpad_split, m->H, 0, m->gate_descale, m->h_scale, m->xgate, rmax, ndev, stream));
+        else
+            JLM_TRY(jlm_lstm_step((const float *)p->h, p->c, m->H, (float *)p->h, p->c, rows, st.bp, st.word, m->emb,
+                                  m->ld_emb, m->wt, m->gate_bias, m->kpad, m->H, m->E, rmax, ndev, stream));
+        if (!m->untied) {
+            if (m->split_lstm)
+                JLM_TRY(jlm_gemm_nt_split(p->h, m->H, rows, m->pmt_split, m->H, nullptr, p->T, m->ldt, rows, nullptr,
+                                          m->t_descale, rmax, m->n_t, m->H, ndev, stream));
+            else
+                JLM_TRY(jlm_gemm_nt((const float *)p->h, m->H, rows, m->pmt, m->H, nullptr, p->T, m->ldt, rows, nullptr, rmax,
+                                    m->n_t, m->H, ndev, stream));
+        }
+        const int cell = f * B;
+        void *est = stream;
+        if (side_s) {          // the edge logits need only T: they run beside the normaliser
+            hipEvent_t fork;
+            JLM_HIP(g_events.get(&fork));
+            JLM_HIP(hipEventRecord(fork, main_s));
+            JLM_HIP(hipStreamWaitEvent(side_s, fork, 0));
+            est = side_stream;
+        }
+        JLM_TRY(jlm_edge_logits(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell, p->sg_word,
+                                p->sg_off, p->sidx, cell, p->sg_node, p->edge, beam, B, est));
+        if (side_s) {
+            JLM_HIP(g_events.get(&join));
+            JLM_HIP(hipEventRecord(join, side_s));
+        }
+        if (!m->self_norm) {
+            if (dynamic)
+                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, cell, 0, B, p->di_max));
+            else if (select)
+                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, 0, 0, B, p->vs_max));
+            else {
+                // frame 0 has one row per sentence: the bound lets the kernel cut the vocabulary into more ranges
+                const int bound = f == 0 ? B : rmax;
+                int r = m->split_segs
+                            ? jlm_vocab_lse_split(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col,
+                                                  m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax, p->max_parts, bound,
+                                                  ndev, stream)
+                            : jlm_vocab_lse_stationary(m->segs, m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax,
+                                                       p->max_parts, bound, ndev, stream);
+                if (r < 0) return r;
+                pending_parts = r;
+            }
+        }
+    }
+    if (join) JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
+    return jlm_backtrace(lat, &st, p->out_nodes, p->out_len, p->out_score, p->stride, stream);
+}

@@ -71,7 +71,9 @@ class Decoder():
         self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
-        self._pool = None                # worker thread that builds the lattices of upcoming chunks
+        self._pool = None                # worker threads that build the lattices of upcoming chunks
+        self.prefetch_workers = max(1, min(4, (os.cpu_count() or 2) // 16))   # each build uses up to 16 threads itself
+        self._pool1 = None
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20
         # batches (tools/probes/stall_probe.py).  Park them in the permanent generation.
@@ -119,7 +121,8 @@ class Decoder():
             return lat, (words, off), lists[-1]
 
         out, inflight = [], deque()
-        for lat, vocab, last_list in self._prefetched(prepare, range(0, len(inputs), self.max_batch)):
+        workers = 1 if (samples and random_sampling) else self.prefetch_workers
+        for lat, vocab, last_list in self._prefetched(prepare, range(0, len(inputs), self.max_batch), workers):
             self.last_lattice = lat
             if vocab_select:
                 self.lattice_vocab = last_list
@@ -135,23 +138,33 @@ class Decoder():
         self.perf_sen += len(inputs)
         return out
 
-    def _prefetched(self, prepare, starts, ahead=2):
-        """prepare(start) for every chunk, in order, `ahead` chunks before they are consumed: with more than
-        one chunk the lattices are built on a worker thread (one, so the order of any RNG use is kept) while
-        this thread enqueues launches and builds strings."""
+    def _prefetched(self, prepare, starts, workers=1):
+        """prepare(start) for every chunk, results in order, up to ``workers`` + 1 chunks ahead of the consumer:
+        with more than one chunk the lattices are built on worker threads (the native builder releases the GIL)
+        while this thread enqueues launches and builds strings.  workers=1 keeps the calls themselves in
+        order (needed when prepare draws from the global RNG: random_sampling)."""
         starts = list(starts)
         if len(starts) <= 1:
             for i in starts:
                 yield prepare(i)
             return
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jlm-lattice")
-        futs = deque(self._pool.submit(prepare, i) for i in starts[:ahead])
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(workers, self.prefetch_workers))
+        if workers == 1:
+            if self._pool1 is None:          # a pool of ONE thread runs its tasks in submission order
+                self._pool1 = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jlm-lattice")
+            pool = self._pool1
+        else:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=self.prefetch_workers, thread_name_prefix="jlm-lattice")
+            pool = self._pool
+        ahead = workers + 1
+        submit = lambda i: pool.submit(prepare, i)
+        futs = deque(submit(i) for i in starts[:ahead])
         for j in range(len(starts)):
             item = futs.popleft().result()
             if j + ahead < len(starts):
-                futs.append(self._pool.submit(prepare, starts[j + ahead]))
+                futs.append(submit(starts[j + ahead]))
             yield item
 
     def decode(self, input, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,

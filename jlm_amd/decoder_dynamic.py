@@ -54,14 +54,17 @@ class DynamicDecoder(Decoder):
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
             return (lat,) + tuple(lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i)))
 
-        for lat, iw, io, dw, do, lv_final in self._prefetched(prepare, range(0, len(inputs), self.max_batch)):
+        workers = 1 if (samples and random_sampling) else self.prefetch_workers
+        last_lv = None
+        for lat, iw, io, dw, do, lv_final in self._prefetched(prepare, range(0, len(inputs), self.max_batch), workers):
             self.last_lattice = lat
-            self.lattice_vocab = lv_final[-1]
+            last_lv = lv_final
             inflight.append(self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN,
                                                 timing=self.perf_timing))
             if len(inflight) > self.pipeline_depth:
                 finish(inflight.popleft())
         while inflight:
             finish(inflight.popleft())
+        self.lattice_vocab = last_lv[-1]          # the reference leaves the LAST sentence's dict behind
         self.perf_sen += len(inputs)
         return out

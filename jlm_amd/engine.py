@@ -42,6 +42,22 @@ from . import _lib
 from .model import _Stamp
 
 
+_READOUT = [False]
+
+
+def _readout_ext():
+    """jlm_amd._readout (built by __graft_entry__.build()), or None; JLM_NATIVE_READOUT=0 disables it."""
+    if _READOUT[0] is False:
+        ext = None
+        if os.environ.get("JLM_NATIVE_READOUT", "1") != "0":
+            try:
+                from . import _readout as ext
+            except ImportError:
+                ext = None
+        _READOUT[0] = ext
+    return _READOUT[0]
+
+
 def _round_up(x, m):
     return (int(x) + m - 1) // m * m
 
@@ -120,6 +136,20 @@ class _Plan:
                                   self.edge.data_ptr(), self.live_base.data_ptr(), None, 0, 0)
         self.graph = None
         self.warm = False
+        # jlm_decode_plan: the same buffers for the native frame loop (jlm_decode_frames)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        d = self.desc = _lib.DecodePlan()
+        d.kind = 2 if dynamic else (1 if vmode == "select" else 0)
+        d.max_cands = caps["cands"]
+        d.h, d.c, d.T = self.h.data_ptr(), self.c.data_ptr(), self.T.data_ptr()
+        d.g0, d.cidx, d.sidx = self.ip["g0"], self.ip["cidx"], self.ip["sidx"]
+        d.sg_word, d.sg_off, d.sg_node, d.edge = self.ip["sg_word"], self.ip["sg_off"], self.ip["sg_node"], self.edge.data_ptr()
+        d.vs_words, d.vs_off = self.ip["vs_words"], self.ip["vs_off"]
+        d.di_words, d.di_off = self.ip["di_words"], self.ip["di_off"]
+        d.dd_words, d.dd_off = self.ip["dd_words"], self.ip["dd_off"]
+        d.run_max, d.run_sum, d.part, d.max_parts = ptr(self.run_max), ptr(self.run_sum), ptr(self.part), self.n_part
+        d.out_nodes, d.out_len, d.out_score = self.out_nodes.data_ptr(), self.out_len.data_ptr(), self.out_score.data_ptr()
+        d.stride = self.stride
 
     def _set(self, name, arr):
         arr = np.asarray(arr, dtype=np.int32).reshape(-1)
@@ -142,9 +172,12 @@ class DecodeEngine:
         self.last_state = None
         self.recorder = None            # optional model.KernelRecorder (bench.py): forces eager launches
         self.last_n_live = None
-        self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "1") == "1"
+        self.use_graph = self.device.type == "cuda" and os.environ.get("JLM_GRAPH", "0") == "1"
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"       # edge logits beside the normaliser
         self.graph_full = os.environ.get("JLM_GRAPH_FULL", "0") == "1"  # replay for the full-vocabulary decode too
+        # the frame loop as ONE native call (jlm_decode_frames) instead of ~170 ctypes calls per batch;
+        # JLM_NATIVE_LOOP=0 (and timing / recorder runs) enqueue the launches one by one from Python
+        self.native_loop = os.environ.get("JLM_NATIVE_LOOP", "1") != "0"
         self.plans = []
         self._side = {}            # side stream of each launch stream (edge logits beside the normaliser)
         # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
@@ -192,6 +225,16 @@ class DecodeEngine:
             side = self._side.get(st)
             if side is None:
                 side = self._side[st] = torch.cuda.Stream()
+        native = getattr(L, "jlm_decode_frames", None) if self.native_loop else None
+        if native is not None and self.recorder is None and not timing:
+            p.cnt.zero_()
+            p.n_live.zero_()
+            d = p.desc
+            d.vs_max, d.di_max, d.dd_max = p.max_words["vs"], p.max_words["di"], p.max_words["dd"]
+            rc = native(m.decode_desc(), d, p.latS, p.stS, st, side.cuda_stream if side is not None else None)
+            if rc != -2:
+                _lib.check(rc, "jlm_decode_frames")
+                return []
         ip = p.ip
         H, ldt = m.H, m.ldt
         hp, cp, Tp = p.h.data_ptr(), p.c.data_ptr(), p.T.data_ptr()
@@ -397,7 +440,20 @@ class DecodeEngine:
     @staticmethod
     def _read_out(lat, nodes_h, len_h, score_h, topN):
         """n-best lists of the batch from the back-traces: [(score, [word, ...])] per sentence, best first.
-        Vectorised: one gather of all paths' node ids, one node -> string lookup, two tolist() calls."""
+        Built by the C extension jlm_amd._readout (csrc/jlm_readout.c: 0.4 ms for 2 560 paths) when it is
+        there, else by the numpy implementation below (1.8 ms) -- same result, tests/test_readout.py."""
+        ext = _readout_ext()
+        if ext is None:
+            return DecodeEngine._read_out_py(lat, nodes_h, len_h, score_h, topN)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        nodes_h = i32(nodes_h)
+        return ext.nbest(nodes_h, i32(len_h), np.ascontiguousarray(score_h, dtype=np.float64), i32(lat.node_lex),
+                         i32(lat.node_sent), i32(lat.node_start), lat.builder.lex_list, lat.texts, lat.n_sent, lat.beam,
+                         int(topN), nodes_h.shape[-1])
+
+    @staticmethod
+    def _read_out_py(lat, nodes_h, len_h, score_h, topN):
+        """numpy form of _read_out: one gather of all paths' node ids, one node -> string lookup, two tolist() calls."""
         B, beam = lat.n_sent, lat.beam
         R = min(beam, topN)
         ln = np.asarray(len_h).reshape(B, beam)[:, :R]

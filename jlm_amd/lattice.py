@@ -64,7 +64,8 @@ class LatticeBuilder:
         self.eos = w2i['<eos>']
         self.unk = w2i['<unk>']
         self.lexicon = lexicon
-        self.lex_words = np.array([x[0] for x in lexicon], dtype=object)
+        self.lex_list = [x[0] for x in lexicon]
+        self.lex_words = np.array(self.lex_list, dtype=object)
         self.table = {}
         self.max_len = 1
         for reading, ids in reading_dict.items():

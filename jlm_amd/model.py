@@ -15,6 +15,7 @@ libjlm_hip.so (exact-f32 MFMA).  :class:`DeviceModel` holds the packed weight
 panels in HBM and is shared with the batched decoders, which never come back
 to numpy between frames.
 """
+import ctypes
 import json
 import os
 import pickle
@@ -330,6 +331,31 @@ class DeviceModel:
             self.t_descale = 2.0 ** -(14 + eP)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+
+    def decode_desc(self):
+        """jlm_decode_model of this model (include/jlm_hip.h): what jlm_decode_frames needs to enqueue
+        the frame loop by itself.  The arrays it points into stay owned by this object."""
+        d = getattr(self, "_decode_desc", None)
+        if d is None:
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            d = _lib.DecodeModel()
+            d.segs, d.n_segs, d.b2 = self.seg_array, self.n_segs, self.b2.data_ptr()
+            d.H, d.ldt = self.H, self.ldt
+            d.untied, d.self_norm, d.split_lstm = int(self.mode == "untied"), int(self.self_norm), int(self.split_lstm)
+            d.emb, d.ld_emb, d.wt, d.gate_bias = self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr()
+            d.kpad, d.E = self.kpad, self.Epad
+            if self.split_lstm:
+                d.wt_split, d.kpad_split = self.wt_split.data_ptr(), self.kpad_split
+                d.gate_descale, d.h_scale, d.xgate = self.gate_descale, self.h_scale, self.xgate.data_ptr()
+                d.pmt_split, d.t_descale = self.pmt_split.data_ptr(), self.t_descale
+            d.pmt, d.n_t = ptr(self.pmt), (self.pmt.shape[0] if self.pmt is not None else 0)
+            if self.split_array is not None:
+                d.split_segs = self.split_array
+                d.split_t_scale = ctypes.cast(self.split_t_scale, ctypes.POINTER(ctypes.c_float))
+                d.split_descale = ctypes.cast(self.split_descale, ctypes.POINTER(ctypes.c_float))
+                d.split_bias_col = ctypes.cast(self.split_bias_col, ctypes.POINTER(ctypes.c_int))
+            self._decode_desc = d
+        return d
 
     # -- enqueue helpers (all on torch's current HIP stream) ------------------
     def stream(self):

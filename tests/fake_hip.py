@@ -43,7 +43,95 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 2
+        return 3
+
+    # ------------------------------------------------------- the frame loop (ABI 3)
+    def jlm_decode_frames(self, m, p, lat, st, stream, side_stream):
+        """Same call order as jlm_amd/csrc/jlm_decode.hip, over the doubles below: checks that the
+        engine fills jlm_decode_model / jlm_decode_plan the way the individual calls were fed."""
+        B, beam, F = lat.n_sent, lat.beam, lat.n_frames
+        rmax = B * beam
+        dynamic, select, full = p.kind == 2, p.kind == 1, p.kind == 0
+        mode = 1 if m.self_norm else (2 if dynamic else 0)
+        split = bool(m.split_segs)
+        wl_split = split and m.n_segs == 1 and beam <= 32
+        if full and not m.self_norm and any(m.segs[i].k > 256 for i in range(m.n_segs)):
+            return -2
+        off = lambda base, n: (base or 0) + 4 * n
+
+        def wl_lse(g0, cidx, words, woff, base, merge, n_groups, max_words):
+            if wl_split and 128 <= max_words <= 4064:
+                r = self.jlm_wordlist_lse_split(m.split_segs, m.split_t_scale[0], m.split_descale[0], m.b2, p.T, m.ldt, g0,
+                                                st.cnt, cidx, words, woff, p.sidx, base, max_words, p.run_max, p.run_sum,
+                                                st.lse, merge, beam, n_groups, stream)
+                if r != -2:
+                    return r
+            return self.jlm_wordlist_lse(m.segs, m.n_segs, m.b2, p.T, m.ldt, g0, st.cnt, cidx, words, woff, p.sidx, base,
+                                         p.run_max, p.run_sum, st.lse, merge, beam, n_groups, stream)
+
+        pending = 0
+        for f in range(F):
+            if dynamic and not m.self_norm and f >= 2:
+                r = -2
+                if wl_split and p.dd_max <= 128:
+                    r = self.jlm_wordlist_merge_split(m.split_segs, m.split_t_scale[0], m.split_descale[0], m.b2, p.T, m.ldt,
+                                                      st.cnt, B, beam, f - 1, p.dd_words, p.dd_off, f * B, p.dd_max,
+                                                      p.run_max, p.run_sum, st.lse, stream)
+                if r == -2:
+                    r = wl_lse(p.g0, p.cidx, p.dd_words, p.dd_off, f * B, 1, (f - 1) * B, p.dd_max)
+                if r:
+                    return r
+            st.lse_part = p.part if pending else None
+            st.ld_part, st.n_parts = rmax, pending
+            r = self.jlm_beam_step(lat, st, f, mode, p.max_cands, stream)
+            if r:
+                return r
+            pending = 0
+            if f == F - 1:
+                break
+            rows, ndev = off(st.live, f * rmax), off(st.n_live, f)
+            if m.split_lstm:
+                r = self.jlm_lstm_step_split(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, None, 0, m.wt_split, None,
+                                             m.kpad_split, m.H, 0, m.gate_descale, m.h_scale, m.xgate, rmax, ndev, stream)
+            else:
+                r = self.jlm_lstm_step(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, m.emb, m.ld_emb, m.wt, m.gate_bias,
+                                       m.kpad, m.H, m.E, rmax, ndev, stream)
+            if r:
+                return r
+            if not m.untied:
+                if m.split_lstm:
+                    r = self.jlm_gemm_nt_split(p.h, m.H, rows, m.pmt_split, m.H, None, p.T, m.ldt, rows, None, m.t_descale,
+                                               rmax, m.n_t, m.H, ndev, stream)
+                else:
+                    r = self.jlm_gemm_nt(p.h, m.H, rows, m.pmt, m.H, None, p.T, m.ldt, rows, None, rmax, m.n_t, m.H, ndev,
+                                         stream)
+                if r:
+                    return r
+            cell = f * B
+            r = self.jlm_edge_logits(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
+                                     p.sg_word, p.sg_off, p.sidx, cell, p.sg_node, p.edge, beam, B, stream)
+            if r:
+                return r
+            if not m.self_norm:
+                if dynamic:
+                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.di_words, p.di_off, cell, 0, B, p.di_max)
+                elif select:
+                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.vs_words, p.vs_off, 0, 0, B, p.vs_max)
+                else:
+                    bound = B if f == 0 else rmax
+                    if split:
+                        r = self.jlm_vocab_lse_split(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col,
+                                                     m.n_segs, m.b2, p.T, m.ldt, rows, p.part, rmax, p.max_parts, bound, ndev,
+                                                     stream)
+                    else:
+                        r = self.jlm_vocab_lse_stationary(m.segs, m.n_segs, m.b2, p.T, m.ldt, rows, p.part, rmax,
+                                                          p.max_parts, bound, ndev, stream)
+                    if r < 0:
+                        return r
+                    pending, r = r, 0
+                if r:
+                    return r
+        return self.jlm_backtrace(lat, st, p.out_nodes, p.out_len, p.out_score, p.stride, stream)
 
     # ------------------------------------------------------------------ K1-K3
     def jlm_lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,

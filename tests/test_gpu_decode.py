@@ -116,6 +116,30 @@ def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
         np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("fixture,kind,kw", [
+    ("small-vtable", "static", {}), ("small-tied", "static", {"vocab_select": True}),
+    ("small-tied", "dynamic", {"vocab_select": True}), ("small-untied", "static", {}),
+    ("small-tied-sn", "static", {})])
+def test_native_frame_loop_equals_call_by_call_loop(fixture, kind, kw, fx):
+    """jlm_decode_frames (one C call per batch) enqueues the same launches as the engine's Python loop:
+    same kernels, same operands -> identical n-best and bit-identical scores.  (An untied model's
+    full-vocabulary decode is outside the native call's shapes: it must fall back, not fail.)"""
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    eng = dec._engine
+    sents = synth.make_ragged_sentences(14, 1, 17, seed=91, alphabet=f["alphabet"])
+    assert eng.native_loop
+    a = dec.decode_batch(sents, beam_width=6, **kw)
+    eng.native_loop = False
+    try:
+        b = dec.decode_batch(sents, beam_width=6, **kw)
+    finally:
+        eng.native_loop = True
+    for x, y in zip(a, b):
+        assert [w for _, w in x] == [w for _, w in y]
+        assert [v for v, _ in x] == [v for v, _ in y]
+
+
 def test_single_sentence_equals_batch(fx):
     f = fx("small-vtable")
     dec = _decoder(f, "static")

@@ -109,3 +109,25 @@ def test_dynamic_lattice_vocab_matches_reference_lists(fx, fake):
         dec.decode(s, vocab_select=True, samples=7, top_sampling=True)
         o.decode(s, vocab_select=True, samples=7, top_sampling=True)
         assert dec.lattice_vocab == o.lattice_vocab
+
+
+@pytest.mark.parametrize("kind,kw", [("static", {}), ("static", {"vocab_select": True}), ("dynamic", {"vocab_select": True})])
+def test_chunked_pipeline_equals_one_batch(kind, kw, fx, fake):
+    """decode_batch over many chunks (lattices prefetched by several worker threads, chunks in flight on
+    alternating plans, results in input order) returns what one big batch returns."""
+    f = fx("small-tied")
+    dec = _decoder(f, kind)
+    sents = gc.case_sentences(("ragged", 23, 1, 14, 77), f["alphabet"])
+    whole = dec.decode_batch(sents, beam_width=5, **kw)
+    lv_whole = dec.lattice_vocab
+    dec.max_batch, dec.prefetch_workers = 4, 3
+    def same(a, b):            # the numpy double's BLAS sums depend on the batch shape in the last bits
+        assert [[w for _, w in x] for x in a] == [[w for _, w in x] for x in b]
+        for x, y in zip(a, b):
+            np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=1e-7)
+    chunked = dec.decode_batch(sents, beam_width=5, **kw)
+    same(chunked, whole)
+    if kw:
+        assert dec.lattice_vocab == lv_whole           # the last sentence's lists, as the reference leaves them
+    dec.prefetch_workers = 1
+    same(dec.decode_batch(sents, beam_width=5, **kw), whole)

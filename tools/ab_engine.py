@@ -36,9 +36,11 @@ def run_pipe(n, depth):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-variants = {"1 stream eager": (1, False), "1 stream graph": (1, True), "2 streams eager": (2, False), "2 streams graph": (2, True)}
+variants = {"1 stream eager": (1, False, True), "1 stream graph": (1, True, True), "2 streams eager": (2, False, True),
+            "2 streams graph": (2, True, True), "2 streams eager, python loop": (2, False, False),
+            "1 stream eager, python loop": (1, False, False)}
 def run(v):
-    eng.n_streams, eng.use_graph = v
+    eng.n_streams, eng.use_graph, eng.native_loop = v
     eng.graph_full = True            # let the variants decide
     eng._rr = 0
     return run_pipe(12, v[0])
@@ -49,4 +51,4 @@ for rep in range(8):
     for k, v in variants.items(): res[k].append(run(v))
 print("streams created:", len(eng._streams), "plans:", len(eng.plans))
 for k, v in res.items():
-    print("%-16s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
+    print("%-30s median %.3f ms/step  min %.3f  (%s)" % (k, np.median(v), min(v), " ".join("%.2f" % x for x in v)))
