@@ -242,17 +242,28 @@ def main():
         from oracle import jlm_oracle as orc
         o = (orc.OracleDynamicDecoder if args.decoder == "dynamic" else orc.OracleDecoder)(root, 1)
         n = min(args.cpu_sentences, len(sents))
+        # BLAS threads = the CPUs this job may use (the box shows 256 hardware threads behind a cgroup quota
+        # of 16; more threads than that only get the process throttled)
+        from jlm_amd import usable_cpus
+        cores = usable_cpus()
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=cores)
+        except ImportError:
+            limit = None
         t2 = time.perf_counter()
         ref_out = [o.decode(s, beam_width=args.beam, **dkw) for s in sents[:n]]
         cdt = time.perf_counter() - t2
+        if limit is not None:
+            limit.restore_original_limits()
         gpu_out = dec.decode_batch(sents[:n], beam_width=args.beam, **dkw)
         same = sum(1 for a, b in zip(ref_out, gpu_out) if a[0][1] == b[0][1])
-        cpu = {"value": round(sum(len(s) for s in sents[:n]) / cdt, 2), "unit": "chars/s", "cores": os.cpu_count(),
+        cpu = {"value": round(sum(len(s) for s in sents[:n]) / cdt, 2), "unit": "chars/s", "cores": cores,
                "kind": "port",
                "sample": "%d of the step's %d sentences, sentence-at-a-time numpy oracle (oracle/jlm_oracle.py), "
-                         "BLAS threads = all cores; lstm %.1f%% / proj+softmax %.1f%% of its time; "
+                         "BLAS threads = usable CPUs (affinity capped by the cgroup quota; %d hardware threads visible); lstm %.1f%% / proj+softmax %.1f%% of its time; "
                          "1-best identical to the GPU path on %d/%d" % (
-                             n, len(sents), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
+                             n, len(sents), os.cpu_count(), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
 
     value = total_chars_per_step * args.steps / dt
     line = {

@@ -329,7 +329,9 @@ typedef struct {
     const int *sg_word, *sg_off, *sg_node;   /* lattice edges grouped by START (frame, sentence): word, CSR, node id */
     float *edge;                    /* == jlm_beam_state.edge */
     const int *vs_words, *vs_off; int vs_max;   /* kind 1: per-sentence selected vocabulary, longest list */
-    const int *di_words, *di_off; int di_max;   /* kind 2: vocabulary a frame starts with, per (frame, sentence) */
+    /* kind 2: the vocabulary a (frame, sentence) cell c starts with = di_words[di_off[2c] .. di_off[2c+1])
+     * (slices of per-sentence sequences, include/jlm_host.h jlm_dynamic_vocab); di_idx[c] = 2 * sentence */
+    const int *di_words, *di_off, *di_idx; int di_max;
     const int *dd_words, *dd_off; int dd_max;   /* kind 2: words new at a frame, per (frame, sentence) */
     float *run_max; double *run_sum;            /* kinds 1, 2: running (max, sum exp) per row */
     float *part; int max_parts;                 /* kind 0: [max_parts][rmax][2] partial slices */

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define JLM_HOST_ABI_VERSION 1
+#define JLM_HOST_ABI_VERSION 2
 int jlm_host_abi_version(void);
 
 typedef struct jlm_lexicon jlm_lexicon;
@@ -62,15 +62,22 @@ int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int
  *   init list  of cell (k, s) = lv[k] + delta[k+1]   (what frame k's rows are first normalised over;
  *                                frame 0 keeps duplicated sampled ids, as the reference does)
  *   delta list of cell (i, s) = delta[i]             (appended to every older frame at step i)
- * extra_ids / extra_off (may be NULL): per-sentence sampled ids appended to lv[0] in the given
- * order (top_sampling: 0..samples-1; random_sampling: the caller's np.random draw).
- * Offsets have n_frames*n_sent + 1 entries.  Returns the init total; *delta_total the delta
- * total; if either exceeds its capacity only the offsets are valid (retry with larger arrays). */
+ * Because lv[] is cumulative, every init list is a slice of one per-sentence sequence
+ *   seq_s = surplus copies of lv[0]'s duplicates ++ sorted(set(lv[0])) ++ delta[1] ++ ... ++ delta[L]
+ * (same multiset as the reference's list; the order inside a log-sum-exp is free): the call
+ * returns the sequences back to back in seq_words and, per cell c = k * n_sent + s, the slice
+ *   init_range[2c] .. init_range[2c+1]   (empty for k >= sent_len[s])
+ * -- O(L) words per sentence instead of O(L^2).  The delta lists are a CSR over cells
+ * (delta_off: n_frames*n_sent + 1 entries).
+ * extra_ids / extra_off (may be NULL): per-sentence sampled ids appended to lv[0]
+ * (top_sampling: 0..samples-1; random_sampling: the caller's np.random draw).
+ * Returns the total sequence length; *delta_total the delta total; if either exceeds its
+ * capacity only init_range / delta_off are valid (retry with larger arrays). */
 int64_t jlm_dynamic_vocab(const int32_t *node_word, const int32_t *end_off, const int32_t *sent_len,
                           int32_t n_sent, int32_t n_frames,
                           const int32_t *extra_ids, const int32_t *extra_off,
-                          int64_t init_cap, int64_t delta_cap,
-                          int32_t *init_words, int32_t *init_off,
+                          int64_t seq_cap, int64_t delta_cap,
+                          int32_t *seq_words, int32_t *init_range,
                           int32_t *delta_words, int32_t *delta_off, int64_t *delta_total,
                           int32_t n_threads);
 

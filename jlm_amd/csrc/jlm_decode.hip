@@ -49,15 +49,15 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
     int pending_parts = 0;
 
     // word-list normaliser: split rows (deep gather ring) for lists of 128 .. 4064 words, else the f32 kernel
-    auto wl_lse = [&](const int *g0, const int *cidx, const int *words, const int *off, int base, int merge, int n_groups,
-                      int max_words) -> int {
+    auto wl_lse = [&](const int *g0, const int *cidx, const int *words, const int *off, const int *idx, int base, int merge,
+                      int n_groups, int max_words) -> int {
         if (wl_split && max_words >= 128 && max_words <= 4064) {
             int r = jlm_wordlist_lse_split(m->split_segs, m->split_t_scale[0], m->split_descale[0], m->b2, p->T, m->ldt, g0,
-                                           st.cnt, cidx, words, off, p->sidx, base, max_words, p->run_max, p->run_sum, st.lse,
+                                           st.cnt, cidx, words, off, idx, base, max_words, p->run_max, p->run_sum, st.lse,
                                            merge, beam, n_groups, stream);
             if (r != -2) return r;
         }
-        return jlm_wordlist_lse(m->segs, m->n_segs, m->b2, p->T, m->ldt, g0, st.cnt, cidx, words, off, p->sidx, base,
+        return jlm_wordlist_lse(m->segs, m->n_segs, m->b2, p->T, m->ldt, g0, st.cnt, cidx, words, off, idx, base,
                                 p->run_max, p->run_sum, st.lse, merge, beam, n_groups, stream);
     };
 
@@ -72,7 +72,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 r = jlm_wordlist_merge_split(m->split_segs, m->split_t_scale[0], m->split_descale[0], m->b2, p->T, m->ldt,
                                              st.cnt, B, beam, f - 1, p->dd_words, p->dd_off, f * B, p->dd_max, p->run_max,
                                              p->run_sum, st.lse, stream);
-            if (r == -2) r = wl_lse(p->g0, p->cidx, p->dd_words, p->dd_off, f * B, 1, (f - 1) * B, p->dd_max);
+            if (r == -2) r = wl_lse(p->g0, p->cidx, p->dd_words, p->dd_off, p->sidx, f * B, 1, (f - 1) * B, p->dd_max);
             JLM_TRY(r);
         }
         st.lse_part = pending_parts ? p->part : nullptr;
@@ -114,9 +114,9 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         }
         if (!m->self_norm) {
             if (dynamic)
-                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, cell, 0, B, p->di_max));
+                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, p->di_idx, 2 * cell, 0, B, p->di_max));
             else if (select)
-                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, 0, 0, B, p->vs_max));
+                JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, p->sidx, 0, 0, B, p->vs_max));
             else {
                 // frame 0 has one row per sentence: the bound lets the kernel cut the vocabulary into more ranges
                 const int bound = f == 0 ? B : rmax;

@@ -201,73 +201,91 @@ extern "C" int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *nod
 }
 
 // Word lists of the incremental-vocabulary decoder (decoder_dynamic.py:30-46,112-127), see
-// include/jlm_host.h.  Pass 1 (sizes) and pass 2 (fill) share the per-sentence computation.
+// include/jlm_host.h.  Every list the device needs is a slice of ONE per-sentence sequence
+//   seq_s = dup(lv0) ++ uniq(lv0) ++ delta[1] ++ delta[2] ++ ... ++ delta[L]
+// (lv0 = frame 0's words + the sampled ids, which the reference does not de-duplicate; dup() = its
+// surplus copies), because lv[k] is cumulative: as a multiset, the list frame k's rows are first
+// normalised over, lv[k] + delta[k+1], is seq_s[n_dup .. end of delta[k+1]) for k >= 1 and
+// seq_s[0 .. end of delta[1]) for k = 0.  Materialising the lists themselves is O(L^2) words per
+// sentence (1.7 M ints and 15 ms of host time per 256 x 20-kana batch); the sequence is O(L).
 namespace {
-struct DynLists {
-    std::vector<std::vector<int32_t>> init, delta;   // per frame
+struct DynSeq {
+    std::vector<int32_t> seq;        // the sequence above
+    std::vector<int32_t> cum;        // cum[i] = end of delta[i] inside seq (cum[0] = end of uniq(lv0))
+    int32_t n_dup = 0;
 };
 void dyn_sentence(const int32_t *node_word, const int32_t *end_off, int B, int s, int L, const int32_t *extra, int n_extra,
-                  DynLists &out) {
-    out.init.assign(L + 1, {});
-    out.delta.assign(L + 1, {});
+                  DynSeq &out) {
     auto frame_words = [&](int f, std::vector<int32_t> &v) {
         v.assign(node_word + end_off[(int64_t)f * B + s], node_word + end_off[(int64_t)f * B + s + 1]);
         std::sort(v.begin(), v.end());
     };
     std::vector<int32_t> lv0, seen, fw, d, merged;
-    frame_words(0, lv0);                                    // sorted, NOT de-duplicated (decoder_dynamic.py:34-43)
+    frame_words(0, lv0);                                    // NOT de-duplicated (decoder_dynamic.py:34-43)
     lv0.insert(lv0.end(), extra, extra + n_extra);
+    std::sort(lv0.begin(), lv0.end());
+    out.seq.clear(); out.cum.assign(L + 1, 0);
+    for (size_t i = 1; i < lv0.size(); ++i)
+        if (lv0[i] == lv0[i - 1]) out.seq.push_back(lv0[i]);          // surplus copies first
+    out.n_dup = (int32_t)out.seq.size();
     seen = lv0;
-    std::sort(seen.begin(), seen.end());
     seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
-    std::vector<int32_t> prev_list = lv0;                   // lv[k] as the reference's list (k = 0 keeps duplicates)
+    out.seq.insert(out.seq.end(), seen.begin(), seen.end());
+    out.cum[0] = (int32_t)out.seq.size();
     for (int i = 1; i <= L; ++i) {
         frame_words(i, fw);
         fw.erase(std::unique(fw.begin(), fw.end()), fw.end());
         d.clear();
         std::set_difference(fw.begin(), fw.end(), seen.begin(), seen.end(), std::back_inserter(d));
-        out.delta[i] = d;
-        out.init[i - 1] = prev_list;                        // init[k] = lv[k] + delta[k+1]
-        out.init[i - 1].insert(out.init[i - 1].end(), d.begin(), d.end());
-        merged.clear();
-        std::merge(seen.begin(), seen.end(), d.begin(), d.end(), std::back_inserter(merged));
-        seen.swap(merged);
-        prev_list = seen;                                   // lv[i] = sorted(set(lv[i-1]) | frame words)
+        out.seq.insert(out.seq.end(), d.begin(), d.end());
+        out.cum[i] = (int32_t)out.seq.size();
+        if (!d.empty()) {
+            merged.clear();
+            std::merge(seen.begin(), seen.end(), d.begin(), d.end(), std::back_inserter(merged));
+            seen.swap(merged);
+        }
     }
 }
 }  // namespace
 
 extern "C" int64_t jlm_dynamic_vocab(const int32_t *node_word, const int32_t *end_off, const int32_t *sent_len,
                                      int32_t n_sent, int32_t n_frames, const int32_t *extra_ids, const int32_t *extra_off,
-                                     int64_t init_cap, int64_t delta_cap, int32_t *init_words, int32_t *init_off,
+                                     int64_t seq_cap, int64_t delta_cap, int32_t *seq_words, int32_t *init_range,
                                      int32_t *delta_words, int32_t *delta_off, int64_t *delta_total, int32_t n_threads) {
     const int B = n_sent, F = n_frames;
-    std::vector<DynLists> all(B);
+    std::vector<DynSeq> all(B);
     parallel_for(B, n_threads, [&](int s) {
         const int32_t *ex = extra_ids ? extra_ids + extra_off[s] : nullptr;
         const int nex = extra_ids ? extra_off[s + 1] - extra_off[s] : 0;
         dyn_sentence(node_word, end_off, B, s, sent_len[s], ex, nex, all[s]);
     });
-    const int64_t ncell = (int64_t)F * B;
-    int64_t ti = 0, td = 0;
-    init_off[0] = 0; delta_off[0] = 0;
+    std::vector<int64_t> base(B + 1, 0);
+    for (int s = 0; s < B; ++s) base[s + 1] = base[s] + (int64_t)all[s].seq.size();
+    int64_t td = 0;
+    delta_off[0] = 0;
     for (int f = 0; f < F; ++f)
         for (int s = 0; s < B; ++s) {
             const int64_t c = (int64_t)f * B + s;
-            if (f <= sent_len[s]) { ti += (int64_t)all[s].init[f].size(); td += (int64_t)all[s].delta[f].size(); }
-            init_off[c + 1] = (int32_t)ti; delta_off[c + 1] = (int32_t)td;
+            const DynSeq &x = all[s];
+            const int L = sent_len[s];
+            if (f >= 1 && f <= L) td += x.cum[f] - x.cum[f - 1];
+            delta_off[c + 1] = (int32_t)td;
+            // init list of cell (f, s): lv[f] + delta[f+1]; rows of the last frame are never normalised
+            int64_t b = 0, e = 0;
+            if (f < L) { b = base[s] + (f == 0 ? 0 : x.n_dup); e = base[s] + x.cum[f + 1]; }
+            init_range[2 * c] = (int32_t)b; init_range[2 * c + 1] = (int32_t)e;
         }
-    (void)ncell;
     *delta_total = td;
-    if (ti > init_cap || td > delta_cap) return ti;
+    if (base[B] > seq_cap || td > delta_cap) return base[B];
     parallel_for(B, n_threads, [&](int s) {
-        for (int f = 0; f <= sent_len[s]; ++f) {
+        const DynSeq &x = all[s];
+        std::memcpy(seq_words + base[s], x.seq.data(), x.seq.size() * sizeof(int32_t));
+        for (int f = 1; f <= sent_len[s]; ++f) {
             const int64_t c = (int64_t)f * B + s;
-            std::memcpy(init_words + init_off[c], all[s].init[f].data(), all[s].init[f].size() * sizeof(int32_t));
-            std::memcpy(delta_words + delta_off[c], all[s].delta[f].data(), all[s].delta[f].size() * sizeof(int32_t));
+            std::memcpy(delta_words + delta_off[c], x.seq.data() + x.cum[f - 1], (size_t)(x.cum[f] - x.cum[f - 1]) * sizeof(int32_t));
         }
     });
-    return ti;
+    return base[B];
 }
 
 extern "C" int jlm_host_abi_version(void) { return JLM_HOST_ABI_VERSION; }

@@ -72,7 +72,8 @@ class Decoder():
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
         self._pool = None                # worker threads that build the lattices of upcoming chunks
-        self.prefetch_workers = max(1, min(4, (os.cpu_count() or 2) // 16))   # each build uses up to 16 threads itself
+        from . import usable_cpus
+        self.prefetch_workers = max(1, min(3, usable_cpus() // 4))    # each build uses up to 4 threads itself
         self._pool1 = None
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20

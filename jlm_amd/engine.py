@@ -66,7 +66,7 @@ class _Plan:
     """Device buffers + captured graph for one decode shape."""
 
     INT_ARRAYS = ("sent_len", "end_off", "node_start", "node_word", "sg_off", "sg_word", "sg_node", "g0", "cidx", "sidx",
-                  "vs_words", "vs_off", "di_words", "di_off", "dd_words", "dd_off")
+                  "sidx2", "vs_words", "vs_off", "di_words", "di_off", "dd_words", "dd_off")
 
     def __init__(self, eng, key, caps):
         torch, m, dev = eng.torch, eng.m, eng.device
@@ -77,8 +77,8 @@ class _Plan:
         G = F * rmax
         self.rmax, self.G, self.ncell = rmax, G, ncell
         sizes = dict(sent_len=B, end_off=ncell + 1, node_start=caps["nodes"], node_word=caps["nodes"], sg_off=ncell + 1,
-                     sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell,
-                     vs_words=caps["vs"], vs_off=B + 1, di_words=caps["di"], di_off=ncell + 1, dd_words=caps["dd"],
+                     sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell, sidx2=ncell,
+                     vs_words=caps["vs"], vs_off=B + 1, di_words=caps["di"], di_off=2 * ncell, dd_words=caps["dd"],
                      dd_off=ncell + 1)
         off, self.ioff = 0, {}
         for n in self.INT_ARRAYS:
@@ -96,6 +96,9 @@ class _Plan:
         self._set("g0", (np.arange(F, dtype=np.int32)[:, None] * rmax + np.arange(B, dtype=np.int32)[None, :] * beam))
         self._set("cidx", np.arange(ncell, dtype=np.int32))
         self._set("sidx", np.tile(np.arange(B, dtype=np.int32), F))
+        # the incremental decoder's frame-initial lists are (begin, end) slices of per-sentence sequences
+        # (lattice.dynamic_vocab): list number 2 * cell reads its two offsets from di_off[2 * cell .. + 1]
+        self._set("sidx2", 2 * np.tile(np.arange(B, dtype=np.int32), F))
         f64, f32, i32 = torch.float64, torch.float32, torch.int32
         dynamic = kind == "dynamic"
         e = lambda n, dt: torch.empty(n, device=dev, dtype=dt)
@@ -145,7 +148,7 @@ class _Plan:
         d.g0, d.cidx, d.sidx = self.ip["g0"], self.ip["cidx"], self.ip["sidx"]
         d.sg_word, d.sg_off, d.sg_node, d.edge = self.ip["sg_word"], self.ip["sg_off"], self.ip["sg_node"], self.edge.data_ptr()
         d.vs_words, d.vs_off = self.ip["vs_words"], self.ip["vs_off"]
-        d.di_words, d.di_off = self.ip["di_words"], self.ip["di_off"]
+        d.di_words, d.di_off, d.di_idx = self.ip["di_words"], self.ip["di_off"], self.ip["sidx2"]
         d.dd_words, d.dd_off = self.ip["dd_words"], self.ip["dd_off"]
         d.run_max, d.run_sum, d.part, d.max_parts = ptr(self.run_max), ptr(self.run_sum), ptr(self.part), self.n_part
         d.out_nodes, d.out_len, d.out_score = self.out_nodes.data_ptr(), self.out_len.data_ptr(), self.out_score.data_ptr()
@@ -250,19 +253,19 @@ class DecodeEngine:
         pending_parts = 0
         wl_split = getattr(m, "split_array", None) is not None and nsegs == 1 and beam <= 32
 
-        def wl_lse(g0, cidx, words, off, base, merge, n_groups, what, max_words):
+        def wl_lse(g0, cidx, words, off, base, merge, n_groups, what, max_words, idx=None):
             """jlm_wordlist_lse; on the split rows (deep gather ring, 128 KB of LDS per workgroup) when the
             model has them and the lists are long enough to be bound by the gather -- the short delta
             lists of the incremental decoder (tens of words, thousands of groups) are bound by how many
             workgroups fit a CU and stay on the 33-KB f32 kernel"""
             if wl_split and 128 <= max_words <= 4064:
                 r = L.jlm_wordlist_lse_split(m.split_array, m.split_t_scale[0], m.split_descale[0], b2p, Tp, ldt, g0, cntp,
-                                             cidx, words, off, ip["sidx"], base, max_words, p.run_max.data_ptr(),
+                                             cidx, words, off, idx or ip["sidx"], base, max_words, p.run_max.data_ptr(),
                                              p.run_sum.data_ptr(), lsep, merge, beam, n_groups, st)
                 if r != -2:
                     _lib.check(r, "jlm_wordlist_lse_split(%s)" % what)
                     return
-            _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, g0, cntp, cidx, words, off, ip["sidx"], base,
+            _lib.check(L.jlm_wordlist_lse(segs, nsegs, b2p, Tp, ldt, g0, cntp, cidx, words, off, idx or ip["sidx"], base,
                                           p.run_max.data_ptr(), p.run_sum.data_ptr(), lsep, merge, beam, n_groups, st),
                        "jlm_wordlist_lse(%s)" % what)
 
@@ -314,8 +317,8 @@ class DecodeEngine:
                 join.record(side)
             if not self_norm:
                 if dynamic:
-                    wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["di_words"], ip["di_off"], f * B, 0, B, "init",
-                           p.max_words["di"])
+                    wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["di_words"], ip["di_off"], 2 * f * B, 0, B, "init",
+                           p.max_words["di"], ip["sidx2"])
                 elif vmode == "select":
                     wl_lse(ip["g0"] + cell, ip["cidx"] + cell, ip["vs_words"], ip["vs_off"], 0, 0, B, "vocab_select",
                            p.max_words["vs"])
@@ -364,7 +367,8 @@ class DecodeEngine:
             o = np.asarray(offs)
             return int(np.diff(o).max()) if o.size > 1 else 0
         max_words = dict(vs=longest(vocab[1]) if vocab is not None else 0,
-                         di=longest(dyn_lists[1]) if dynamic else 0, dd=longest(dyn_lists[3]) if dynamic else 0)
+                         di=int((dyn_lists[1][1::2] - dyn_lists[1][0::2]).max()) if dynamic else 0,
+                         dd=longest(dyn_lists[3]) if dynamic else 0)
         size_class = tuple((v < 128, v <= 128, v <= 4064) for v in (max_words["vs"], max_words["di"], max_words["dd"]))
         p = self._plan_for(kind, vmode, lat, need, size_class)
         p.max_words = max_words
@@ -431,7 +435,7 @@ class DecodeEngine:
         """lat: BatchLattice.  kind: 'static' | 'dynamic'.
         vocab: (words, off) CSR of per-sentence selected vocabularies (static
         vocab_select) or None for the full vocabulary.
-        dyn_lists: (init_words, init_off, delta_words, delta_off) for 'dynamic'.
+        dyn_lists: (seq_words, init_range, delta_words, delta_off) for 'dynamic' (BatchLattice.dynamic_vocab).
         -> list (per sentence) of [(neg_log_prob, [word, ...])][:topN]"""
         if lat.n_sent == 0:
             return []

@@ -43,7 +43,7 @@ def host_lib():
             l.jlm_static_vocab.restype = L64
             l.jlm_dynamic_vocab.argtypes = [P, P, P, I, I, P, P, L64, L64, P, P, P, P, P, I]
             l.jlm_dynamic_vocab.restype = L64
-            _host = l if l.jlm_host_abi_version() == 1 else False
+            _host = l if l.jlm_host_abi_version() == 2 else False
     return _host or None
 
 
@@ -82,7 +82,8 @@ class LatticeBuilder:
                 if len(reading) > self.max_len:
                     self.max_len = len(reading)
         self._native = None
-        self.n_threads = min(16, os.cpu_count() or 1)
+        from . import usable_cpus
+        self.n_threads = min(4, usable_cpus())     # per build; decode_batch runs several builds side by side
         self.use_native = os.environ.get("JLM_NATIVE_LATTICE", "1") != "0"
 
     def native(self):
@@ -287,7 +288,11 @@ class BatchLattice:
           delta lists cell (i, s): sorted(set(lv[i]) - set(lv[i-1])), appended to
                       every older frame at step i (decoder_dynamic.py:112-127)
 
-        -> (init_words, init_off, delta_words, delta_off, lv_final) where
+        lv[] is cumulative, so every init list is a slice of one per-sentence sequence
+        (include/jlm_host.h, jlm_dynamic_vocab): O(L) words per sentence instead of O(L^2).
+
+        -> (seq_words, init_range, delta_words, delta_off, lv_final): init list of cell c =
+        seq_words[init_range[2c] : init_range[2c+1]]; delta lists are a CSR over cells;
         lv_final[s][k] is the reference's ``lattice_vocab[k]`` list after the
         decode (original order + appended deltas)."""
         B, F = self.n_sent, self.n_frames
@@ -300,18 +305,30 @@ class BatchLattice:
         lib = host_lib()
         if lib is not None and self.builder.use_native:
             return self._dynamic_vocab_native(lib, extra)
-        init = [[] for _ in range(F * B)]
+        seq, rng = [], np.zeros(2 * F * B, dtype=np.int32)
         delta = [[] for _ in range(F * B)]
         for s in range(B):
             lv, d = self._dyn_lists_python(s, extra[s] if extra else [])
             L = int(self.sent_len[s])
+            base = len(seq)
+            lv0 = sorted(lv[0])
+            dup = [x for i, x in enumerate(lv0) if i and lv0[i - 1] == x]
+            seq += dup + sorted(set(lv0))
+            cum = [len(seq)]
             for i in range(1, L + 1):
                 delta[i * B + s] = d[i]
+                seq += d[i]
+                cum.append(len(seq))
             for k in range(L):
-                init[k * B + s] = lv[k] + d[k + 1]
-        iw, io = _csr(init)
+                c = k * B + s
+                rng[2 * c], rng[2 * c + 1] = (base if k == 0 else base + len(dup)), cum[k + 1]
         dw, do = _csr(delta)
-        return iw, io, dw, do, _LazyFinal(self, extra)
+        return np.asarray(seq, dtype=np.int32), rng, dw, do, _LazyFinal(self, extra)
+
+    def dynamic_init_list(self, dyn, k, s):
+        """The init list of cell (k, s) out of dynamic_vocab()'s result (tests, debugging)."""
+        c = k * self.n_sent + s
+        return dyn[0][int(dyn[1][2 * c]):int(dyn[1][2 * c + 1])].tolist()
 
     def _dyn_lists_python(self, s, extra):
         L = int(self.sent_len[s])
@@ -342,22 +359,23 @@ class BatchLattice:
             ex_off = np.zeros(B + 1, dtype=np.int32)
             np.cumsum([len(e) for e in extra], out=ex_off[1:])
             ex_ids = np.fromiter((x for e in extra for x in e), dtype=np.int32, count=int(ex_off[-1]))
-        io = np.zeros(ncell + 1, dtype=np.int32)
+        rng = np.zeros(2 * ncell, dtype=np.int32)
         do = np.zeros(ncell + 1, dtype=np.int32)
         dtot = np.zeros(1, dtype=np.int64)
         nw = np.ascontiguousarray(self.node_word)
-        icap, dcap = max(1024, self.n_nodes * 8), max(1024, self.n_nodes + B)
+        n_extra = int(ex_off[-1]) if ex_off is not None else 0
+        scap, dcap = self.n_nodes + 2 * n_extra + B, self.n_nodes + n_extra + B     # upper bounds: one pass
         while True:
-            iw = np.empty(icap, dtype=np.int32)
+            sw = np.empty(scap, dtype=np.int32)
             dw = np.empty(dcap, dtype=np.int32)
             n = lib.jlm_dynamic_vocab(_ptr(nw), _ptr(self.end_off), _ptr(self.sent_len), B, F,
                                       _ptr(ex_ids) if ex_ids is not None else None,
-                                      _ptr(ex_off) if ex_off is not None else None, icap, dcap, _ptr(iw), _ptr(io),
+                                      _ptr(ex_off) if ex_off is not None else None, scap, dcap, _ptr(sw), _ptr(rng),
                                       _ptr(dw), _ptr(do), _ptr(dtot), self.builder.n_threads)
-            if n <= icap and int(dtot[0]) <= dcap:
+            if n <= scap and int(dtot[0]) <= dcap:
                 break
-            icap, dcap = max(icap, int(n)), max(dcap, int(dtot[0]))
-        return iw[:int(n)], io, dw[:int(dtot[0])], do, _LazyFinal(self, extra)
+            scap, dcap = max(scap, int(n)), max(dcap, int(dtot[0]))
+        return sw[:int(n)], rng, dw[:int(dtot[0])], do, _LazyFinal(self, extra)
 
 
 class _LazyFinal:

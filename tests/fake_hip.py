@@ -59,14 +59,14 @@ class FakeLib:
             return -2
         off = lambda base, n: (base or 0) + 4 * n
 
-        def wl_lse(g0, cidx, words, woff, base, merge, n_groups, max_words):
+        def wl_lse(g0, cidx, words, woff, idx, base, merge, n_groups, max_words):
             if wl_split and 128 <= max_words <= 4064:
                 r = self.jlm_wordlist_lse_split(m.split_segs, m.split_t_scale[0], m.split_descale[0], m.b2, p.T, m.ldt, g0,
-                                                st.cnt, cidx, words, woff, p.sidx, base, max_words, p.run_max, p.run_sum,
+                                                st.cnt, cidx, words, woff, idx, base, max_words, p.run_max, p.run_sum,
                                                 st.lse, merge, beam, n_groups, stream)
                 if r != -2:
                     return r
-            return self.jlm_wordlist_lse(m.segs, m.n_segs, m.b2, p.T, m.ldt, g0, st.cnt, cidx, words, woff, p.sidx, base,
+            return self.jlm_wordlist_lse(m.segs, m.n_segs, m.b2, p.T, m.ldt, g0, st.cnt, cidx, words, woff, idx, base,
                                          p.run_max, p.run_sum, st.lse, merge, beam, n_groups, stream)
 
         pending = 0
@@ -78,7 +78,7 @@ class FakeLib:
                                                       st.cnt, B, beam, f - 1, p.dd_words, p.dd_off, f * B, p.dd_max,
                                                       p.run_max, p.run_sum, st.lse, stream)
                 if r == -2:
-                    r = wl_lse(p.g0, p.cidx, p.dd_words, p.dd_off, f * B, 1, (f - 1) * B, p.dd_max)
+                    r = wl_lse(p.g0, p.cidx, p.dd_words, p.dd_off, p.sidx, f * B, 1, (f - 1) * B, p.dd_max)
                 if r:
                     return r
             st.lse_part = p.part if pending else None
@@ -114,9 +114,9 @@ class FakeLib:
                 return r
             if not m.self_norm:
                 if dynamic:
-                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.di_words, p.di_off, cell, 0, B, p.di_max)
+                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.di_words, p.di_off, p.di_idx, 2 * cell, 0, B, p.di_max)
                 elif select:
-                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.vs_words, p.vs_off, 0, 0, B, p.vs_max)
+                    r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.vs_words, p.vs_off, p.sidx, 0, 0, B, p.vs_max)
                 else:
                     bound = B if f == 0 else rmax
                     if split:

@@ -71,6 +71,19 @@ def test_native_dynamic_vocab_lists(kw, fx):
     for a, c in zip(outs[0][:4], outs[1][:4]):
         np.testing.assert_array_equal(a, c)
     assert outs[0][4][-1] == outs[1][4][-1]
+    # the init list of every cell is, as a multiset, the reference's lv[k] + delta[k+1] (decoder_dynamic.py:30-46,112-127)
+    lat = lattice.BatchLattice(b, sents, 5)
+    np.random.seed(11)
+    extra = None
+    if kw.get("random_sampling"):
+        extra = [[int(x) for x in np.random.randint(len(v.w2i), size=kw["samples"])] for _ in sents]
+    elif kw.get("top_sampling"):
+        extra = [list(range(kw["samples"]))] * len(sents)
+    for s in range(len(sents)):
+        lv, d = lat._dyn_lists_python(s, extra[s] if extra else [])
+        for k in range(len(sents[s])):
+            assert sorted(lat.dynamic_init_list(outs[1], k, s)) == sorted(lv[k] + d[k + 1]), (s, k)
+        assert lat.dynamic_init_list(outs[1], len(sents[s]), s) == []
     # the final per-frame lists of a sentence equal the reference's lattice_vocab after its decode
     if not kw.get("random_sampling"):
         o = orc.OracleDynamicDecoder(f["root"], 1)

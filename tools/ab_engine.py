@@ -23,7 +23,7 @@ kw = {}
 if mode == "static-vs":
     words, off, lists = lat.static_vocab(0, False, False, len(dec.w2i)); kw = dict(vocab=(words, off))
 if mode == "dynamic":
-    iw, io, dw, do, _ = lat.dynamic_vocab(0, False, False, len(dec.w2i)); kw = dict(dyn_lists=(iw, io, dw, do))
+    kw = dict(dyn_lists=lat.dynamic_vocab(0, False, False, len(dec.w2i))[:4])
 kind = "dynamic" if mode == "dynamic" else "static"
 
 def run_pipe(n, depth):
