@@ -170,6 +170,27 @@ def main():
     barrier()
     e2e = chars_per_step * e2e_steps / (time.perf_counter() - t1) * world
 
+    # diagnostic (not `value`): does this box overlap the two batches in flight?  The same pipelined loop
+    # with one stream and with the engine's two; on most boxes 3.6 vs 2.6 ms, on some the two are equal
+    # (the queues of the two streams are not run side by side there) and `value` is the one-stream rate.
+    overlap = None
+    if not args.end_to_end and eng.n_streams >= 2:
+        def timed_ms(n):
+            barrier()
+            t = time.perf_counter()
+            run_steps(n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        keep = eng.n_streams
+        two = timed_ms(12)
+        eng.n_streams = 1
+        run_steps(3)
+        one = timed_ms(12)
+        eng.n_streams = keep
+        eng._rr = 0
+        overlap = {"one_stream_ms_per_step": round(one, 3), "two_streams_ms_per_step": round(two, 3),
+                   "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -283,7 +304,7 @@ def main():
                    "fixture": args.fixture, "sentences_per_gpu": args.batch, "kana_per_sentence": args.length,
                    "beam": args.beam, "decoder": args.decoder, "timed": "end_to_end" if args.end_to_end else "device",
                    "parallelism": "sentence-sharded x%d, no collective" % world},
-        "end_to_end_chars_per_s": round(e2e, 1),
+        "end_to_end_chars_per_s": round(e2e, 1), "stream_overlap": overlap,
         "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,
 
     }

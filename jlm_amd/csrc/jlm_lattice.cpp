@@ -214,36 +214,37 @@ struct DynSeq {
     std::vector<int32_t> cum;        // cum[i] = end of delta[i] inside seq (cum[0] = end of uniq(lv0))
     int32_t n_dup = 0;
 };
+// "seen" is a per-thread stamp array over word ids (stamp == this sentence's ticket: already in the
+// vocabulary), so a frame costs its own words only -- no merge of the whole cumulative set per frame.
 void dyn_sentence(const int32_t *node_word, const int32_t *end_off, int B, int s, int L, const int32_t *extra, int n_extra,
                   DynSeq &out) {
-    auto frame_words = [&](int f, std::vector<int32_t> &v) {
-        v.assign(node_word + end_off[(int64_t)f * B + s], node_word + end_off[(int64_t)f * B + s + 1]);
-        std::sort(v.begin(), v.end());
+    thread_local std::vector<uint32_t> stamp;
+    thread_local uint32_t ticket = 0;
+    if (++ticket == 0) { std::fill(stamp.begin(), stamp.end(), 0u); ticket = 1; }
+    auto seen = [&](int32_t w) -> bool {              // marks w; true if it was marked before
+        if ((size_t)w >= stamp.size()) stamp.resize((size_t)w + 1024, 0u);
+        if (stamp[w] == ticket) return true;
+        stamp[w] = ticket;
+        return false;
     };
-    std::vector<int32_t> lv0, seen, fw, d, merged;
-    frame_words(0, lv0);                                    // NOT de-duplicated (decoder_dynamic.py:34-43)
+    std::vector<int32_t> lv0, fw;
+    lv0.assign(node_word + end_off[s], node_word + end_off[s + 1]);     // frame 0, NOT de-duplicated (decoder_dynamic.py:34-43)
     lv0.insert(lv0.end(), extra, extra + n_extra);
     std::sort(lv0.begin(), lv0.end());
     out.seq.clear(); out.cum.assign(L + 1, 0);
     for (size_t i = 1; i < lv0.size(); ++i)
         if (lv0[i] == lv0[i - 1]) out.seq.push_back(lv0[i]);          // surplus copies first
     out.n_dup = (int32_t)out.seq.size();
-    seen = lv0;
-    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
-    out.seq.insert(out.seq.end(), seen.begin(), seen.end());
+    for (int32_t w : lv0)
+        if (!seen(w)) out.seq.push_back(w);                            // sorted(set(lv0))
     out.cum[0] = (int32_t)out.seq.size();
     for (int i = 1; i <= L; ++i) {
-        frame_words(i, fw);
-        fw.erase(std::unique(fw.begin(), fw.end()), fw.end());
-        d.clear();
-        std::set_difference(fw.begin(), fw.end(), seen.begin(), seen.end(), std::back_inserter(d));
-        out.seq.insert(out.seq.end(), d.begin(), d.end());
+        fw.clear();
+        for (const int32_t *w = node_word + end_off[(int64_t)i * B + s], *e = node_word + end_off[(int64_t)i * B + s + 1]; w < e; ++w)
+            if (!seen(*w)) fw.push_back(*w);
+        std::sort(fw.begin(), fw.end());                               // delta[i] = sorted(set(lv[i]) - set(lv[i-1]))
+        out.seq.insert(out.seq.end(), fw.begin(), fw.end());
         out.cum[i] = (int32_t)out.seq.size();
-        if (!d.empty()) {
-            merged.clear();
-            std::merge(seen.begin(), seen.end(), d.begin(), d.end(), std::back_inserter(merged));
-            seen.swap(merged);
-        }
     }
 }
 }  // namespace

@@ -177,8 +177,12 @@ class Decoder():
 
 
 class CharRNNDecoder(Decoder):
-    """Placeholder so that ``from decoder import Decoder, CharRNNDecoder``
-    (reference decoder/eval.py:7) resolves; out of scope."""
+    """Placeholder so that ``from decoder import Decoder, CharRNNDecoder`` (reference decoder/eval.py:7)
+    resolves.  The reference's class (decoder/decoder.py:244-341) cannot decode: its ``_check_oov`` reads
+    ``self.vocab.words``, which ``Vocab`` (train/data.py:15-26) does not define, so the first lattice
+    look-up raises AttributeError (verified against the reference on the synthetic fixtures) -- there is
+    no behaviour to pin an implementation to."""
 
     def __init__(self, *a, **k):
-        raise NotImplementedError("CharRNNDecoder is outside the scope of this build (SURVEY.md 8f)")
+        raise NotImplementedError("CharRNNDecoder: the reference's class raises AttributeError on its first lattice "
+                                  "look-up (Vocab has no .words), so there is nothing to be a drop-in for; DESIGN.md 8")

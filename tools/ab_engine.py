@@ -15,7 +15,7 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "static"
 cfg, _l, _r, al = synth.build_fixture(root, fixture)
 jconfig.set_root(root)
 dec = (DynamicDecoder if mode == "dynamic" else Decoder)(1); dec.perf_timing = False
-eng = dec._engine
+eng = dec._engine; eng.MAX_PLANS = 8
 sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
 from jlm_amd.lattice import BatchLattice
 lat = BatchLattice(dec._builder, sents, 10)
@@ -36,12 +36,18 @@ def run_pipe(n, depth):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-variants = {"1 stream eager": (1, False, True), "1 stream graph": (1, True, True), "2 streams eager": (2, False, True),
-            "2 streams graph": (2, True, True), "2 streams eager, python loop": (2, False, False),
-            "1 stream eager, python loop": (1, False, False)}
+variants = {"1 stream": (1, False, True, True), "2 streams": (2, False, True, True), "2 streams, no side stream": (2, False, True, False),
+            "3 streams": (3, False, True, True), "3 streams, no side stream": (3, False, True, False),
+            "4 streams, no side stream": (4, False, True, False),
+            "2 streams graph": (2, True, True, True), "2 streams, python loop": (2, False, False, True)}
+only = os.environ.get("AB_ONLY")
+if only:
+    variants = {k: v for k, v in variants.items() if any(o.strip() == k for o in only.split(";"))}
 def run(v):
-    eng.n_streams, eng.use_graph, eng.native_loop = v
+    eng.n_streams, eng.use_graph, eng.native_loop, eng.use_side = v
     eng.graph_full = True            # let the variants decide
+    if len(eng._streams) < eng.n_streams:
+        eng._streams += [torch.cuda.Stream() for _ in range(eng.n_streams - len(eng._streams))]
     eng._rr = 0
     return run_pipe(12, v[0])
 for _ in range(4):

@@ -18,7 +18,7 @@ dec.max_batch = 256
 kw = dict(vocab_select=True) if mode != "static" else {}
 sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
 dec.decode_batch(sents * 4, beam_width=10, **kw)
-for n in (6, chunks):
+for n in (1, 1, 6, 6, 6, chunks):
     torch.cuda.synchronize(); t = time.perf_counter()
     dec.decode_batch(sents * n, beam_width=10, **kw)
     dt = time.perf_counter() - t
