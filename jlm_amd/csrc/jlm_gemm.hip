@@ -26,6 +26,18 @@
 // A and B use the same assignment, hence the sum over k is complete.
 // Accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "jlm_common.h"
+
+// Per-workgroup timeline of the tile GEMMs (-DJLM_PROFILE builds only, tools/probes/gate_profile.py): thread 0 of a
+// workgroup stamps the 100 MHz wall clock at kernel start, after the prologue, after the main loop and at the end.
+#ifdef JLM_PROFILE
+static __device__ unsigned long long jlm_wg_time[4096][4];
+#define JLM_WG_T(i) do { if (threadIdx.x == 0) jlm_wg_time[blockIdx.x & 4095][i] = wall_clock64(); } while (0)
+extern "C" int jlm_prof_read_wg_gemm(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_wg_time), sizeof(jlm_wg_time)) == hipSuccess ? 0 : -1;
+}
+#else
+#define JLM_WG_T(i) (void)0
+#endif
 #include <stdlib.h>
 
 #define BK 32
@@ -113,9 +125,11 @@ struct TileMap {
 struct EpiStore {
     float *C; const int *c_map; int ldc; const float *bias;
     float scale = 1.0f;                    // split-f16 mainloop: 2^-(eA + eB); 1 (exact) for the f32 mainloop
+    template <class Cfg> struct Pre {};
+    template <class Cfg> __device__ void prepare(Pre<Cfg> &, int, int) const {}
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
-                        int M, int N, float *) const {
+                        int M, int N, float *, const Pre<Cfg> &) const {
 #pragma unroll
         for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
@@ -149,13 +163,39 @@ struct EpiGate {
     const float *xgate = nullptr;          // optional [V, 4H] table  emb . W_x^T + bias  (packed column order):
     const int *word = nullptr;             //   the GEMM then contracts over the state only and bias is unused
     int ld_gate = 0;                       //   = H (a table row has 4 H floats)
+    // Row indices of the thread's epilogue rows, loaded at kernel start: the chain rows[] -> prev[] / word[] is two
+    // dependent global loads, which otherwise sit between the last MFMA and the first gate (once per 32/64-row pass).
+    template <class Cfg> struct Pre {
+        static constexpr int RPP = 256 / (Cfg::BN / 16);
+        static constexpr int N = Cfg::BM / RPP;
+        int g[N], p[N], w[N];
+    };
+    template <class Cfg> __device__ void prepare(Pre<Cfg> &pre, int m0, int M) const {
+        constexpr int TPR = Cfg::BN / 16;
+#pragma unroll
+        for (int i = 0; i < Pre<Cfg>::N; ++i) {
+            const int row = m0 + i * Pre<Cfg>::RPP + (int)threadIdx.x / TPR;
+            int g = -1, p = -1, w = 0;
+            if (row < M) {
+                g = rows ? rows[row] : row;
+                p = prev[g];
+                if (xgate) w = word[g];
+            }
+            pre.g[i] = g; pre.p[i] = p; pre.w[i] = w;
+        }
+    }
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
-                        int M, int, float *smem) const {
+                        int M, int, float *smem, const Pre<Cfg> &pre) const {
         constexpr int BN = Cfg::BN, NT = Cfg::NT;
-        static_assert((BN == 64 || BN == 128) && Cfg::WAVES_N == 2 && Cfg::NTHREADS == 256 && Cfg::BM % 64 == 0,
-                      "gate epilogue: tiles of 64-column groups (4 gates x 16 units), 64 rows at a time");
-        constexpr int CT_LD = BN + 4;          // transposition buffer [64][CT_LD]: 64 rows of the tile at a time
+        // STRIP: one row of four waves, each owning a 32-column strip of all MT row blocks (the one-tile-per-CU
+        // form of the LSTM step, TileCfg<1, 4, MT, 1>): the tile passes through LDS 32 rows at a time
+        constexpr bool STRIP = Cfg::WAVES_M == 1 && Cfg::WAVES_N == 4 && NT == 1;
+        static_assert((BN == 64 || BN == 128) && Cfg::NTHREADS == 256 &&
+                          (STRIP ? BN == 128 : (Cfg::WAVES_N == 2 && Cfg::BM % 64 == 0)),
+                      "gate epilogue: tiles of 64-column groups (4 gates x 16 units), 64 (strip form: 32) rows at a time");
+        constexpr int PR = STRIP ? 32 : 64;    // rows of the tile per pass
+        constexpr int CT_LD = BN + 4;          // transposition buffer [PR][CT_LD]
         constexpr int TPR = BN / 16;           // threads per row, 4 units (x 4 gates) each
         constexpr int RPP = 256 / TPR;         // rows per pass
         float *ct = smem;
@@ -170,31 +210,55 @@ struct EpiGate {
             bo = *reinterpret_cast<const f32x4 *>(bias + n0 + cb + 32);
             bg = *reinterpret_cast<const f32x4 *>(bias + n0 + cb + 48);
         }
+        // Strip form (one workgroup per CU, nobody else to hide behind): the table rows and old cell states of ALL the
+        // thread's rows are requested up front, so the passes below wait for one memory round trip, not one each.
+        constexpr int NPRE = Pre<Cfg>::N;
+        constexpr bool PF_ALL = STRIP;
+        f32x4 xi[PF_ALL ? NPRE : 1], xf[PF_ALL ? NPRE : 1], xo[PF_ALL ? NPRE : 1], xg[PF_ALL ? NPRE : 1], cpv[PF_ALL ? NPRE : 1];
+        if (PF_ALL) {
 #pragma unroll
-        for (int rh = 0; rh < Cfg::BM / 64; ++rh) {
-            if (rh > 0) __syncthreads();       // the previous 64 rows have been consumed
+            for (int pi = 0; pi < NPRE; ++pi) {
+                xi[pi] = bi; xf[pi] = bf; xo[pi] = bo; xg[pi] = bg;
+                cpv[pi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pre.g[pi] < 0) continue;
+                if (xgate) {
+                    const float *xr = xgate + (size_t)pre.w[pi] * (size_t)(4 * ld_gate) + n0 + cb;
+                    xi[pi] = *reinterpret_cast<const f32x4 *>(xr);
+                    xf[pi] = *reinterpret_cast<const f32x4 *>(xr + 16);
+                    xo[pi] = *reinterpret_cast<const f32x4 *>(xr + 32);
+                    xg[pi] = *reinterpret_cast<const f32x4 *>(xr + 48);
+                }
+                if (pre.p[pi] >= 0) cpv[pi] = *reinterpret_cast<const f32x4 *>(c_in + (size_t)pre.p[pi] * ld + u0);
+            }
+        }
+#pragma unroll
+        for (int rh = 0; rh < Cfg::BM / PR; ++rh) {
+            if (rh > 0) __syncthreads();       // the previous rows have been consumed
 #pragma unroll
             for (int mt = 0; mt < Cfg::MT; ++mt) {
                 const int blk = wm * Cfg::MT + mt;           // 32-row block of the tile held by this wave
-                if ((blk >> 1) != rh) continue;
+                if (blk / (PR / 32) != rh) continue;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int r = (blk & 1) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                        const int r = (blk % (PR / 32)) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                         ct[r * CT_LD + (wn * NT + nt) * 32 + (lane & 31)] = acc[mt][nt][reg] * scale;
                     }
             }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < 64 / RPP; ++it) {
+            for (int it = 0; it < PR / RPP; ++it) {
                 const int r = tid / TPR + it * RPP;
-                const int row = m0 + rh * 64 + r;
+                const int row = m0 + rh * PR + r;
                 if (row >= M) continue;
-                const int g = rows ? rows[row] : row;
-                const int p = prev[g];
-                if (xgate) {               // 4 x 16 B of the word's precomputed input-side pre-activations
-                    const float *xr = xgate + (size_t)word[g] * (size_t)(4 * ld_gate) + n0 + cb;
+                const int pi = rh * (PR / RPP) + it;
+                const int g = pre.g[pi];
+                const int p = pre.p[pi];
+                if (PF_ALL) {
+                    bi = xi[pi]; bf = xf[pi]; bo = xo[pi]; bg = xg[pi];
+                } else if (xgate) {        // 4 x 16 B of the word's precomputed input-side pre-activations
+                    const float *xr = xgate + (size_t)pre.w[pi] * (size_t)(4 * ld_gate) + n0 + cb;
                     bi = *reinterpret_cast<const f32x4 *>(xr);
                     bf = *reinterpret_cast<const f32x4 *>(xr + 16);
                     bo = *reinterpret_cast<const f32x4 *>(xr + 32);
@@ -205,7 +269,8 @@ struct EpiGate {
                 const f32x4 zo = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb + 32) + bo;
                 const f32x4 zg = *reinterpret_cast<const f32x4 *>(ct + r * CT_LD + cb + 48) + bg;
                 f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-                if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
+                if (PF_ALL) cp = cpv[pi];
+                else if (p >= 0) cp = *reinterpret_cast<const f32x4 *>(c_in + (size_t)p * ld + u0);
                 f32x4 cn, hn;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -237,9 +302,11 @@ struct EpiLse {
     const float *bias;     // per vocabulary row of this segment
     float *part;           // float2 [tiles][ld_part]
     int ld_part, tile0;
+    template <class Cfg> struct Pre {};
+    template <class Cfg> __device__ void prepare(Pre<Cfg> &, int, int) const {}
     template <class Cfg>
     __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
-                        int M, int N, float *smem) const {
+                        int M, int N, float *smem, const Pre<Cfg> &) const {
         float2 *red = reinterpret_cast<float2 *>(smem);      // [WAVES_M][BN]
 #pragma unroll
         for (int nt = 0; nt < Cfg::NT; ++nt) {
@@ -314,6 +381,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm2_kernel(ARows A, BRows B, 
     const int M = A.count(), N = B.count();
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (m0 >= M || n0 >= N) return;
+    typename Epi::template Pre<Cfg> pre;
+    epi.template prepare<Cfg>(pre, m0, M);      // index loads of the epilogue, in flight under the mainloop
     float *As = smem;                         // [2][BM][32]
     float *Bs = smem + 2 * BM * 32;           // [2][BN][32]
     const int tid = threadIdx.x;
@@ -396,7 +465,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm2_kernel(ARows A, BRows B, 
         }
         __syncthreads();          // hipcc drains the DMA (vmcnt(0)) here: the next buffer is complete
     }
-    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem, pre);
 }
 
 template <class Cfg, class ARows, class BRows, class Epi>
@@ -438,6 +507,9 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRow
     const int M = A.count(), N = B.count();
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (m0 >= M || n0 >= N) return;
+    JLM_WG_T(0);
+    typename Epi::template Pre<Cfg> pre;
+    epi.template prepare<Cfg>(pre, m0, M);      // index loads of the epilogue, in flight under the mainloop
     float *As = smem;                         // [2][BM][32]
     float *Bs = smem + 2 * BM * 32;           // [2][BN][32]
     const int tid = threadIdx.x;
@@ -487,6 +559,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRow
     for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * h + p) ^ ((li >> 1) & 7)) * 4);
+    JLM_WG_T(1);
     issue(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -523,7 +596,9 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split_kernel(ARows A, BRow
         }
         __syncthreads();
     }
-    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+    JLM_WG_T(2);
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem, pre);
+    JLM_WG_T(3);
 }
 
 // NST-stage form (NST = 3 is what is instantiated) for grids that do not fill the chip (the T projection: 240 workgroups, one per CU, so the
@@ -540,6 +615,9 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split3_kernel(ARows A, BRo
     const int M = A.count(), N = B.count();
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (m0 >= M || n0 >= N) return;
+    JLM_WG_T(0);
+    typename Epi::template Pre<Cfg> pre;
+    epi.template prepare<Cfg>(pre, m0, M);      // index loads of the epilogue, in flight under the mainloop
     float *As = smem;                         // [NST][BM][32]
     float *Bs = smem + NST * BM * 32;         // [NST][BN][32]
     const int tid = threadIdx.x;
@@ -590,6 +668,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split3_kernel(ARows A, BRo
     for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * h + p) ^ ((li >> 1) & 7)) * 4);
+    JLM_WG_T(1);
 #pragma unroll
     for (int q = 0; q < NST - 1; ++q)
         if (q < nk) issue(q * BK, q);
@@ -624,8 +703,10 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split3_kernel(ARows A, BRo
                                                                              acc[mt][nt], 0, 0, 0);
         stg = stg == NST - 1 ? 0 : stg + 1;
     }
+    JLM_WG_T(2);
     __syncthreads();                          // the epilogues reuse the staging memory
-    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem);
+    epi.template run<Cfg>(acc, m0, n0, wm, wn, lane, M, N, smem, pre);
+    JLM_WG_T(3);
 }
 
 template <class Cfg, class ARows, class BRows, class Epi, int NST>
@@ -730,6 +811,12 @@ extern "C" int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_s
     if (tile < 0) { const char *e = getenv("JLM_GATE_TILE"); tile = e ? atoi(e) : 128; }
     const int tiles_n = 4 * H / (tile == 256 ? 128 : 64);
     const int xcd = (tiles_n % 8 == 0) ? 2 : 0;
+    // 160: one 160 x 128 tile per CU (16 x 16 = 256 workgroups at 2 560 rows, H = 512), four waves each owning a
+    // 32-column strip, a 4-stage LDS ring -- every operand byte crosses L2 -> LDS 16 times instead of 20 / 32
+    if (tile == 160 && (4 * H) % 128 == 0) {
+        const int xc = ((4 * H / 128) % 8 == 0) ? 2 : 0;
+        return launch_gemm_split3<TileCfg<1, 4, 5, 1>, GateRows, PlainRows, EpiGate, 4>(A, B, Kc, epi, xc, (hipStream_t)stream);
+    }
     if (tile == 256 && (4 * H) % 128 == 0) return launch_gemm_split<Cfg128>(A, B, Kc, epi, xcd, (hipStream_t)stream);
     if (tile == 128) return launch_gemm_split<TileCfg<2, 2, 2, 1>>(A, B, Kc, epi, xcd, (hipStream_t)stream);
     return launch_gemm_split<Cfg64>(A, B, Kc, epi, xcd, (hipStream_t)stream);
