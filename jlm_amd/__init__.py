@@ -54,4 +54,9 @@ def usable_cpus():
                 n = min(n, max(1, -(-quota // period)))
         except (OSError, ValueError):
             pass
+    # one process per GPU (torchrun): the ranks of a node share the quota
+    try:
+        n //= max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        pass
     return max(1, n)

@@ -472,6 +472,7 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     if (lat.n_sent <= 0) return 0;
     if (mode == 2 && !st.ysum) return -1;
     if (mode < 0 || mode > 2) return -1;
+    if (lat.beam < 1 || lat.beam > 64) return -1;      // one lane of the sentence's wave per surviving hypothesis
     if (st.lse_part && (!st.live_base || st.n_parts < 1 || mode != 0)) return -1;
     if (max_cands < 1) max_cands = 1;
     size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0) +

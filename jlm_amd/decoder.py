@@ -108,6 +108,8 @@ class Decoder():
                      random_sampling=False):
         if beam_width is None:
             raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+        if not 1 <= int(beam_width) <= 64:
+            raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
         inputs = list(inputs)
         if any(len(x) == 0 for x in inputs):
             raise ValueError("empty input string")

@@ -32,6 +32,8 @@ class DynamicDecoder(Decoder):
                      random_sampling=False):
         if beam_width is None:
             raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+        if not 1 <= int(beam_width) <= 64:
+            raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
         if not vocab_select:
             raise TypeError("'NoneType' object is not subscriptable")      # decoder_dynamic.py:114
         inputs = list(inputs)

@@ -61,6 +61,8 @@ def test_empty_batch_and_bad_input(fx):
         d.decode_batch(["アイ", ""])
     with pytest.raises(ValueError):
         d.decode("アイ", beam_width=None)
+    with pytest.raises(ValueError):
+        d.decode("アイ", beam_width=65)        # one wave lane per surviving hypothesis: 64 is the widest beam
 
 
 def test_odd_vocabulary_size(tmp_path):

@@ -99,6 +99,10 @@ def test_dynamic_requires_vocab_select(fx, fake):
         dec.decode("アイウ", vocab_select=False)
     with pytest.raises(ValueError):
         dec.decode("アイウ", beam_width=None, vocab_select=True)
+    with pytest.raises(ValueError):
+        dec.decode("アイウ", beam_width=65, vocab_select=True)
+    with pytest.raises(ValueError):
+        dec.decode("アイウ", beam_width=0, vocab_select=True)
 
 
 def test_dynamic_lattice_vocab_matches_reference_lists(fx, fake):
