@@ -7,22 +7,26 @@
 namespace {
 
 // fork/join events for the edge-logit side stream.  A wait binds to the record that precedes it at
-// enqueue time, so a small rotating pool is enough however many batches are in flight.
+// enqueue time, so a small rotating pool per device is enough however many batches are in flight.
 struct EventPool {
-    static constexpr int N = 32;
-    hipEvent_t ev[N];
-    int next = 0;
-    bool ready = false;
+    static constexpr int N = 32, MAX_DEV = 16;
+    hipEvent_t ev[MAX_DEV][N];
+    int next[MAX_DEV] = {0};
+    bool ready[MAX_DEV] = {false};
     hipError_t get(hipEvent_t *out) {
-        if (!ready) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+        if (!ready[dev]) {
             for (int i = 0; i < N; ++i) {
-                hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+                e = hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming);
                 if (e != hipSuccess) return e;
             }
-            ready = true;
+            ready[dev] = true;
         }
-        *out = ev[next];
-        next = (next + 1) % N;
+        *out = ev[dev][next[dev]];
+        next[dev] = (next[dev] + 1) % N;
         return hipSuccess;
     }
 };
