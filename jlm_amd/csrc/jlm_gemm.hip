@@ -835,7 +835,11 @@ extern "C" int jlm_gemm_nt_split(const void *Ap, int lda, const int *a_rows, con
     const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     static int stages = -1;                    // 3 stages: 17.4 -> 13.8 us on the T projection; 4 and 6 are no better
     if (stages < 0) { const char *e = getenv("JLM_T_STAGES"); stages = e ? atoi(e) : 3; }
-    if (tiles64 <= 256 && stages == 3) return launch_gemm_split3<Cfg64, PlainRows, PlainRows, EpiStore, 3>(A, B, K, epi, 0, (hipStream_t)stream);
+    // XCD map 1: the column tiles of one row tile run on the same XCD, so a gathered A row crosses the fabric into ONE L2
+    // instead of up to tiles_n of them (T projection: 36.6 MB fetched per launch for 9.4 MB of operands with the linear map)
+    static int txcd = -1;
+    if (txcd < 0) { const char *e = getenv("JLM_T_XCD"); txcd = e ? atoi(e) : 1; }
+    if (tiles64 <= 256 && stages == 3) return launch_gemm_split3<Cfg64, PlainRows, PlainRows, EpiStore, 3>(A, B, K, epi, txcd, (hipStream_t)stream);
     if (tiles128 < 512) return launch_gemm_split<Cfg64>(A, B, K, epi, 0, (hipStream_t)stream);
     return launch_gemm_split<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
 }
