@@ -15,10 +15,12 @@ jconfig.set_root(root)
 dec = (DynamicDecoder if mode == "dynamic" else Decoder)(1)
 dec.perf_timing = False
 dec.max_batch = 256
+if os.environ.get('E2E_DEPTH'):
+    dec.pipeline_depth = int(os.environ['E2E_DEPTH']); dec._engine.MAX_PLANS = 8
 kw = dict(vocab_select=True) if mode != "static" else {}
 sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
 dec.decode_batch(sents * 4, beam_width=10, **kw)
-for n in (1, 1, 6, 6, 6, chunks):
+for n in (6, chunks, chunks, chunks):
     torch.cuda.synchronize(); t = time.perf_counter()
     dec.decode_batch(sents * n, beam_width=10, **kw)
     dt = time.perf_counter() - t
