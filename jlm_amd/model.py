@@ -30,6 +30,42 @@ from . import config as _config
 GATES = "ifog"
 
 
+# Host-side helpers of the reference's module (decoder/model.py:12-33) for the numpy arrays predict() hands back
+# (``find_top_N(pred[0], 10)``, ``sample(pred[0])`` in its __main__ smoke, model.py:232-235).  The decode path never calls
+# them: on the device these are the gate epilogue (jlm_lstm_step), jlm_softmax_rows and the fused log-sum-exp.
+def sigmoid(x):
+    """model.py:12-13: 1 / (exp(-x) + 1), no clamping (overflow -> 0 is benign)."""
+    return 1.0 / (np.exp(-np.asarray(x)) + 1.0)
+
+
+def softmax(w):
+    """model.py:15-20: row softmax with max subtraction; a 1-D input is treated as one row ([1, n] comes back)."""
+    w = np.asarray(w)
+    assert w.ndim == 2 or w.ndim == 1, 'softmax dim error %d' % w.ndim
+    if w.ndim == 1:
+        w = w[None, :]
+    e = np.exp(w - w.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def tanh(x):
+    """model.py:22-23."""
+    return np.tanh(x)
+
+
+def find_top_N(a, N):
+    """model.py:25-26: indices of the N largest entries, largest first."""
+    return np.argsort(a)[::-1][:N]
+
+
+def sample(a, temperature=1.0):
+    """model.py:28-33: draw an index from the distribution ``a`` re-shaped by a temperature (global numpy RNG)."""
+    logp = np.log(np.asarray(a, dtype=np.float64)) / temperature
+    p = np.exp(logp)
+    p = p / p.sum()
+    return int(np.argmax(np.random.multinomial(1, p, 1)))
+
+
 def _pad(x, m):
     return (x + m - 1) // m * m
 
@@ -585,3 +621,47 @@ class LSTM_Model():
             probs.append(pred[0, inp])
             pred = self.predict([inp])[0]
         return [-np.log(p) for p in probs]
+
+
+def show_prob(model, w2i, inputs):
+    """Per-word -log p of a word sequence and their total (the reference's show_prob, model.py:208-211, which reads
+    module globals and, through the broken evaluate, cannot run)."""
+    results = model.evaluate(w2i['<eos>'], [w2i[word] for word in inputs])
+    print(results)
+    print(sum(results))
+    return results
+
+
+def main(argv=None):
+    """The reference module's smoke run (model.py:213-245): sample 100 words from the model starting at <eos>, print
+    them and their -log p, then the same words shuffled -- a trained model scores its own sample better."""
+    import argparse
+    from random import shuffle
+    from .data import Vocab
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("-e", "--experiment_id", type=int, default=0)
+    ap.add_argument("--root", default=None, help="JLM root (data/, train/experiments/); default $JLM_ROOT")
+    ap.add_argument("--steps", type=int, default=100)
+    args = ap.parse_args(argv)
+    if args.root:
+        _config.set_root(args.root)
+    config = _config.load_config_dict(args.experiment_id)
+    vocab = Vocab(config['vocab_size'])
+    model = LSTM_Model(experiment_id=args.experiment_id)
+    word, result = '<eos>', []
+    for _ in range(args.steps):
+        result.append(word)
+        pred = model.predict([vocab.w2i[word]])[0]
+        word = vocab.i2w[sample(pred[0])]
+    print('--- generated sentence')
+    print(' '.join(x.split('/')[0] for x in result))
+    a = show_prob(model, vocab.w2i, result)
+    print('--- random sentence by same collection of words, check the difference to see if the model is correct')
+    shuffle(result)
+    print(' '.join(x.split('/')[0] for x in result))
+    b = show_prob(model, vocab.w2i, result)
+    return sum(a), sum(b)
+
+
+if __name__ == "__main__":
+    main()

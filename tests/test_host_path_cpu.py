@@ -135,3 +135,26 @@ def test_chunked_pipeline_equals_one_batch(kind, kw, fx, fake):
         assert dec.lattice_vocab == lv_whole           # the last sentence's lists, as the reference leaves them
     dec.prefetch_workers = 1
     same(dec.decode_batch(sents, beam_width=5, **kw), whole)
+
+
+def test_module_helpers_match_the_oracle_and_smoke_main_runs(fx, fake, capsys):
+    """decoder/model.py:12-33 helpers (host side, for predict()'s numpy outputs) and its __main__ smoke (model.py:213-245)."""
+    from jlm_amd import model as jm
+    rng = np.random.RandomState(3)
+    x = rng.randn(4, 37) * 5
+    np.testing.assert_allclose(jm.softmax(x), orc.softmax(x), rtol=1e-12)
+    assert jm.softmax(x[0]).shape == (1, 37)
+    np.testing.assert_allclose(jm.sigmoid(x), orc.sigmoid(x), rtol=1e-12)
+    np.testing.assert_allclose(jm.tanh(x), np.tanh(x))
+    assert jm.find_top_N(np.array([0.1, 0.5, 0.2, 0.9]), 2).tolist() == [3, 1]
+    np.random.seed(5)
+    draws = [jm.sample([0.05, 0.9, 0.05]) for _ in range(50)]
+    assert max(set(draws), key=draws.count) == 1 and set(draws) <= {0, 1, 2}
+    np.random.seed(7)
+    assert jm.sample([0.2, 0.3, 0.5], temperature=1e-3) == 2         # a cold temperature is an arg-max
+    f = fx("small-tied")
+    np.random.seed(11)
+    a, b = jm.main(["-e", "1", "--root", f["root"], "--steps", "12"])
+    out = capsys.readouterr().out
+    assert "--- generated sentence" in out and "--- random sentence" in out
+    assert np.isfinite(a) and np.isfinite(b) and a > 0 and b > 0
