@@ -7,9 +7,11 @@
 namespace {
 
 // fork/join events for the edge-logit side stream.  A wait binds to the record that precedes it at
-// enqueue time, so a small rotating pool per device is enough however many batches are in flight.
+// enqueue time, so a rotating pool per device is enough; it is sized so that an event is not recorded
+// again before the batches that could still be waiting on it (two or three in flight, two events per
+// frame) have long been enqueued.
 struct EventPool {
-    static constexpr int N = 32, MAX_DEV = 16;
+    static constexpr int N = 512, MAX_DEV = 16;
     hipEvent_t ev[MAX_DEV][N];
     int next[MAX_DEV] = {0};
     bool ready[MAX_DEV] = {false};
