@@ -140,6 +140,31 @@ def test_native_frame_loop_equals_call_by_call_loop(fixture, kind, kw, fx):
         assert [v for v, _ in x] == [v for v, _ in y]
 
 
+@pytest.mark.parametrize("fixture,kind,kw", [("small-vtable", "static", {}), ("small-tied", "static", {"vocab_select": True}),
+                                             ("small-tied", "dynamic", {"vocab_select": True})])
+def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
+    """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- two streams, side
+    streams, native frame loop, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
+    a time on one stream with the call-by-call loop.  Same kernels, same operands: bit-identical results."""
+    f = fx(fixture)
+    dec = _decoder(f, kind)
+    eng = dec._engine
+    dec.perf_timing = False
+    sents = synth.make_ragged_sentences(24 * 48, 1, 22, seed=123, alphabet=f["alphabet"])
+    keep = (dec.max_batch, eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers)
+    try:
+        dec.max_batch, dec.prefetch_workers = 48, 3
+        fast = dec.decode_batch(sents, beam_width=8, **kw)
+        eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers = 1, False, 0, 1
+        slow = []
+        for i in range(0, len(sents), 48):
+            slow.extend(dec.decode_batch(sents[i:i + 48], beam_width=8, **kw))
+    finally:
+        dec.max_batch, eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers = keep
+    assert len(fast) == len(slow) == len(sents)
+    assert fast == slow
+
+
 def test_single_sentence_equals_batch(fx):
     f = fx("small-vtable")
     dec = _decoder(f, "static")

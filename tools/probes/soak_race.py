@@ -1,0 +1,42 @@
+"""Race hunt: many ragged chunks through the pipelined product path (two streams, side streams, native frame loop,
+lattice prefetch threads) against the same sentences decoded one chunk at a time on one stream with the call-by-call
+Python loop.  Same kernels, same operands: every n-best list and every score must be bit-identical."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from jlm_amd import config as jconfig, synth
+from jlm_amd.decoder import Decoder
+from jlm_amd.decoder_dynamic import DynamicDecoder
+chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+root = os.path.join(tempfile.gettempdir(), "jlm_dbg")
+bad = 0
+for fixture, cls, kw in (("mid-vtable", Decoder, {}), ("mid-tied", Decoder, dict(vocab_select=True)),
+                         ("mid-tied", DynamicDecoder, dict(vocab_select=True)), ("mid-tied", Decoder, {})):
+    cfg, _l, _r, al = synth.build_fixture(root, fixture)
+    jconfig.set_root(root)
+    dec = cls(1)
+    dec.perf_timing = False
+    dec.max_batch = 192
+    sents = synth.make_ragged_sentences(192 * chunks, 1, 30, seed=99, alphabet=al)
+    t = time.perf_counter()
+    fast = dec.decode_batch(sents, beam_width=10, **kw)
+    t_fast = time.perf_counter() - t
+    eng = dec._engine
+    eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers = 1, False, 0, 1
+    t = time.perf_counter()
+    slow = []
+    for i in range(0, len(sents), 192):
+        slow.extend(dec.decode_batch(sents[i:i + 192], beam_width=10, **kw))
+    t_slow = time.perf_counter() - t
+    n_diff = sum(1 for a, b in zip(fast, slow) if a != b)
+    bad += n_diff
+    print("%-11s %-15s %-22s %6d sentences: %d differ   pipelined %.2f s, serial %.2f s" % (
+        fixture, cls.__name__, kw, len(sents), n_diff, t_fast, t_slow))
+    if n_diff:
+        for i, (a, b) in enumerate(zip(fast, slow)):
+            if a != b:
+                print("  first difference at sentence", i, sents[i], a[:2], b[:2]); break
+    del dec
+    torch.cuda.empty_cache()
+print("TOTAL differing sentences:", bad)
+sys.exit(1 if bad else 0)
