@@ -192,7 +192,11 @@ class DecodeEngine:
 
     # ------------------------------------------------------------------ plans
     def _plan_for(self, kind, vmode, lat, need, size_class=()):
-        key = (kind, vmode, lat.n_sent, lat.beam, lat.n_frames, size_class)
+        # Buffers are sized for the frame count rounded up to 8 so that ragged inputs (every chunk has its own longest
+        # sentence) share plans instead of allocating ~1 GB of state rows and pinned staging per distinct length; the
+        # frame loop runs lat.n_frames.  A captured graph bakes the loop in, so with replay the exact count is the key.
+        fkey = lat.n_frames if self.use_graph else _round_up(lat.n_frames, 8)
+        key = (kind, vmode, lat.n_sent, lat.beam, fkey, size_class)
         for i, p in enumerate(self.plans):
             if p.key == key and p.fits(need) and not p.busy:
                 self.plans.append(self.plans.pop(i))
@@ -211,7 +215,8 @@ class DecodeEngine:
     def _enqueue(self, p, timing):
         """The whole launch sequence of one batch (no host synchronisation inside)."""
         torch, m, L = self.torch, self.m, _lib.lib()
-        kind, vmode, B, beam, F = p.key[:5]
+        kind, vmode, B, beam = p.key[:4]
+        F = p.latS.n_frames                 # this batch's frames (<= the plan's capacity p.F)
         rmax = p.rmax
         dynamic = kind == "dynamic"
         self_norm = m.self_norm
@@ -373,6 +378,8 @@ class DecodeEngine:
         p = self._plan_for(kind, vmode, lat, need, size_class)
         p.max_words = max_words
         p.busy = True
+        assert lat.n_frames <= p.F
+        p.latS.n_frames = lat.n_frames
         p._set("sent_len", lat.sent_len)
         p._set("end_off", lat.end_off)
         p._set("node_start", lat.node_start)
@@ -423,7 +430,7 @@ class DecodeEngine:
         if done is not None:
             done.synchronize()
         if self.recorder is not None:
-            self.last_n_live = p.h_nlive.numpy().copy()
+            self.last_n_live = p.h_nlive.numpy()[:p.latS.n_frames].copy()
         if timing:
             self.last_timing = [(a.seconds_to(b), b.seconds_to(c2)) for a, b, c2 in ev]
         self.last_state = p

@@ -19,12 +19,14 @@ if os.environ.get('E2E_DEPTH'):
     dec.pipeline_depth = int(os.environ['E2E_DEPTH']); dec._engine.MAX_PLANS = 8
 kw = dict(vocab_select=True) if mode != "static" else {}
 sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
+if os.environ.get('E2E_RAGGED'):
+    sents = synth.make_ragged_sentences(256, 1, 30, seed=99, alphabet=al)
 dec.decode_batch(sents * 4, beam_width=10, **kw)
 for n in (6, chunks, chunks, chunks):
     torch.cuda.synchronize(); t = time.perf_counter()
     dec.decode_batch(sents * n, beam_width=10, **kw)
     dt = time.perf_counter() - t
-    print("%s %s: %d chunks  %.3f ms/chunk  %.0f chars/s" % (fixture, mode, n, dt / n * 1e3, 5120 * n / dt))
+    print("%s %s: %d chunks  %.3f ms/chunk  %.0f chars/s" % (fixture, mode, n, dt / n * 1e3, sum(len(x) for x in sents) * n / dt))
 pr = cProfile.Profile()
 pr.enable()
 dec.decode_batch(sents * chunks, beam_width=10, **kw)
