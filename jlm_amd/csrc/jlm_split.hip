@@ -106,8 +106,8 @@ struct LseSplitArgs {
 };
 
 JLM_PROF_READER(jlm_prof_read_split)
-#ifdef JLM_PROFILE
-// per-workgroup timeline (constant 100 MHz clock): start, end, segment, row tile
+#if defined(JLM_PROFILE) || defined(JLM_WGTIME)
+// per-workgroup timeline (-DJLM_WGTIME: these stamps only, none of JLM_PROFILE's probes inside the loops) (constant 100 MHz clock): start, end, segment, row tile
 static __device__ unsigned long long jlm_prof_wg[1024][4];
 extern "C" int jlm_prof_read_wg(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof_wg), sizeof(jlm_prof_wg)) == hipSuccess ? 0 : -1;
@@ -366,8 +366,12 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
     // all row tiles of its vocabulary ranges, which stay in its L2
     const int b = blockIdx.x;
     int p, pt;
-    if ((a.n_parts & 7) == 0) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
-    else { p = b / n_ptiles; pt = b % n_ptiles; }
+    // n_parts = 8 q + r: the first 8 q ranges are dealt to the XCDs (block b runs on XCD b % 8), range p on XCD p % 8 with
+    // all of its row tiles; the r < 8 ranges left over follow linearly -- their few workgroups land one or two per XCD, on the
+    // CUs the 8 q ranges leave idle (10 row tiles: 3 x 10 = 30 of an XCD's 32 CUs)
+    const int nb8 = (a.n_parts & ~7) * n_ptiles;
+    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { const int bb = b - nb8; p = (a.n_parts & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
     if (p >= a.n_parts || pt * (32 * NW) >= n_paths) return;
     int si = 0;
     while (si + 1 < a.n_segs && p >= a.part_first[si + 1]) ++si;
@@ -377,7 +381,7 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
     const int pis = p - a.part_first[si], npis = a.part_first[si + 1] - a.part_first[si];
     float2 *prow = part + (size_t)p * ld_part;
     const int ns = (sg.k + 15) >> 4;
-#ifdef JLM_PROFILE
+#if defined(JLM_PROFILE) || defined(JLM_WGTIME)
     const unsigned long long wg_t0 = wall_clock64();
 #endif
 #define JLM_LSE_CASE(NS_, MT_)                                                                                           \
@@ -393,7 +397,7 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
     else if (ns <= 13) JLM_LSE_CASE(13, 4);
     else JLM_LSE_CASE(16, 2);
 #undef JLM_LSE_CASE
-#ifdef JLM_PROFILE
+#if defined(JLM_PROFILE) || defined(JLM_WGTIME)
     if (threadIdx.x == 0 && b < 1024) {
         jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si; jlm_prof_wg[b][3] = pt;
     }
@@ -422,8 +426,12 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
     LseSplitArgs a;
     a.n_segs = n_segs;
-    static int c0 = -1;
-    if (c0 < 0) { const char *e = getenv("JLM_LSE_C0"); c0 = e ? atoi(e) : 4; }
+    static int c0x2 = -1, np8 = -1;            // cost constant in half k-steps; JLM_LSE_NP8=1: range count a multiple of 8
+    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 5; }
+    // JLM_LSE_NP8=0 lets the range count use every CU (25 ranges x 10 row tiles = 250 workgroups instead of 240: the kernel
+    // alone runs 3 % faster), but the 16 CUs the multiple of 8 leaves idle are where the other batch in flight runs its
+    // small kernels meanwhile: the decode is 2.8 % slower with them taken (2.59 vs 2.52 ms per step, tools/ab_engine.py)
+    if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
     long work[JLM_MAX_SEGMENTS], total = 0;
     int ntiles[JLM_MAX_SEGMENTS];
     for (int i = 0; i < n_segs; ++i) {
@@ -440,12 +448,9 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         const int bmv = ns > 13 ? 64 : 128;
         ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
         // Cost of a vocabulary row ~ (k-steps + c0): the MFMAs plus a per-row constant (fold, staging).
-        // Single-segment timings (tools/probes/lse_cost_calib.py) give c0 = 1.6; in the mixed launch the
-        // fold-heavy workgroups (short k) share SIMDs with MFMA-heavy ones and finish later
-        // (tools/probes/lse_wg_timeline.py), which argues for more.  The launch time itself is flat
-        // (+-2 %) for c0 in 2..24 on the (200, 100, 50) model: the SIMDs, not one workgroup's critical
-        // path, are what is full.
-        work[i] = (long)(sg.v_end - sg.v_start) * (ns + c0);
+        // The per-workgroup timeline of the mixed launch (tools/probes/lse_wg_timeline.py on a -DJLM_WGTIME
+        // build) gives 9.0 / 5.4 / 3.76 us per 128-word tile at 13 / 7 / 4 k-steps = 0.58 (k-steps + 2.5).
+        work[i] = (long)(sg.v_end - sg.v_start) * (2 * ns + c0x2);
         total += work[i];
     }
     static int nw = -1;
@@ -456,7 +461,7 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     int np = ((nw == 8 ? 1 : 2) * 256) / n_ptiles; // one resident round: 2 four-wave / 1 eight-wave workgroup per CU
     if (np < n_segs) np = n_segs;
     if (np > cap) np = cap;
-    if (np >= 8) np &= ~7;
+    if (np >= 8 && np8) np &= ~7;
     if (np < n_segs) np = n_segs;
     int given = 0, k[JLM_MAX_SEGMENTS];
     for (int i = 0; i < n_segs; ++i) {

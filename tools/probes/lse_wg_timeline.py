@@ -3,7 +3,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from jlm_amd import _lib
-L = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "..", "build_prof", "libjlm_hip_prof.so"))
+L = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "..", "build_prof", os.environ.get("JLM_PROF_LIB", "libjlm_hip_prof.so")))
 L.jlm_vocab_lse_split.restype = ctypes.c_int
 L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [
     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -28,7 +28,8 @@ for _ in range(5): npart = f()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
 L.jlm_prof_read_wg(buf)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4)[:npart * 20].astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4).astype(np.int64)
+a = a[a[:, 0] > 0]                       # 8-wave form: parts x 10 row blocks; 4-wave (JLM_LSE_WAVES=4): parts x 20
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0      # us
 print("parts", npart, "WGs", len(a), "kernel span %.1f us" % en.max())
