@@ -36,7 +36,7 @@ def run_pipe(n, depth):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n * 1e3
 
-variants = {"1 stream": (1, False, True, True), "2 streams": (2, False, True, True), "2 streams, no side stream": (2, False, True, False),
+variants = {"1 stream": (1, False, True, True), "1 stream, no side stream": (1, False, True, False), "2 streams": (2, False, True, True), "2 streams, no side stream": (2, False, True, False),
             "3 streams": (3, False, True, True), "3 streams, no side stream": (3, False, True, False),
             "4 streams, no side stream": (4, False, True, False),
             "2 streams graph": (2, True, True, True), "2 streams, python loop": (2, False, False, True)}
