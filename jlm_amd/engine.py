@@ -354,7 +354,9 @@ class DecodeEngine:
             self._streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
         strm = self._streams[self._rr]
         self._rr = (self._rr + 1) % self.n_streams
-        strm.wait_stream(torch.cuda.current_stream())      # after whatever the caller queued (weight uploads, ...)
+        cur = torch.cuda.current_stream()
+        if not cur.query():                                  # after whatever the caller queued (weight uploads, ...);
+            strm.wait_stream(cur)                            # nothing pending there in the steady state: no event, no wait
         with torch.cuda.stream(strm):
             return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
 
