@@ -114,6 +114,29 @@ extern "C" int jlm_prof_read_wg(unsigned long long *out) {
 }
 #endif
 
+// -DJLM_TILETRACE: ONE wave (workgroup JLM_TT_BLOCK, wave 0) stamps the shader clock along its 4th tile: after every
+// k-step's last MFMA issue, before / after the chunk barriers, around the fold (tools/probes/lse_tile_trace.py)
+#ifdef JLM_TILETRACE
+#ifndef JLM_TT_BLOCK
+#define JLM_TT_BLOCK 8
+#endif
+static __device__ unsigned long long jlm_tile_trace[3][128];     // per k-step class: [0] = count, then (tag, clock) pairs
+extern "C" int jlm_tile_trace_read(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_tile_trace), sizeof(jlm_tile_trace)) == hipSuccess ? 0 : -1;
+}
+#define JLM_TT(tag)                                                                     \
+    do {                                                                                \
+        if (tt_on && tt_n < 60) {                                                       \
+            jlm_tile_trace[tt_cls][1 + 2 * tt_n] = (unsigned long long)(tag);           \
+            jlm_tile_trace[tt_cls][2 + 2 * tt_n] = clock64();                           \
+            ++tt_n;                                                                     \
+            jlm_tile_trace[tt_cls][0] = tt_n;                                           \
+        }                                                                               \
+    } while (0)
+#else
+#define JLM_TT(tag) (void)0
+#endif
+
 // BG: the bias rides in the GEMM -- column sg.k of the split rows holds bias * 2^eB and the row operand
 // gets 1.0 there -- so the fold is max3 / fma / exp / add per logit (the fma forms acc * 2^-(eT+eB) - max
 // in one go) and stages no bias through LDS.  Needs a spare column (k % 16 != 0).
@@ -235,7 +258,17 @@ __device__ __forceinline__ void lse_split_body(
     __syncthreads();
     JLM_PROF_MARK(p_t2);
     int buf = 0;
+#ifdef JLM_TILETRACE
+    int tt_n = 0;
+    const int tt_cls = NS <= 4 ? 2 : (NS <= 7 ? 1 : 0);
+    // the first range of each segment, row tile 0: any workgroup whose pis == 0 && pt == 0
+    const bool tt_wg = (p_in_seg == 0 && pt == 0 && wave == 0);
+#endif
     for (int t = vt0; t < vt1; ++t) {
+#ifdef JLM_TILETRACE
+        const bool tt_on = tt_wg && t == vt0 + 3;
+#endif
+        JLM_TT(1);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool last_c = (c == NC - 1);
@@ -281,10 +314,17 @@ __device__ __forceinline__ void lse_split_body(
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], thi[st], acc[mt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                JLM_TT(10 + st);
             }
             if (!BG && last_c) bias_stage(t + 1);
             JLM_PROF_MARK(p_x);
+            JLM_TT(2);
+#ifdef JLM_TILETRACE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the next chunk's DMA has landed ...
+            JLM_TT(5);                                                      // ... the rest of the wait is the other waves
+#endif
             __syncthreads();
+            JLM_TT(3);
             JLM_PROF_ADD(p_bar, p_x);
             buf ^= 1;
         }
@@ -343,6 +383,7 @@ __device__ __forceinline__ void lse_split_body(
             m = mn;
         }
         JLM_PROF_ADD(p_fold, p_x);
+        JLM_TT(4);
     }
     JLM_PROF_FLUSH();
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
