@@ -45,8 +45,9 @@ class Evaluator:
             raise NotImplementedError("char-RNN models are outside the scope of this build (SURVEY.md 8f)")
         self.vocab = Vocab(self.config['vocab_size'])
         self.w2i = self.vocab.w2i
-        if args.use_ngram:
-            raise NotImplementedError("the n-gram baseline decoder is outside the scope of this build (SURVEY.md 8f)")
+        if args.use_ngram:            # the CPU baseline (eval.py:41-42)
+            from .decoder_ngram import NGramDecoder
+            self.decoder = NGramDecoder(experiment_id=args.experiment_id, ngram_order=args.ngram_order)
         elif args.dynamic_decoding:
             from .decoder_dynamic import DynamicDecoder
             self.decoder = DynamicDecoder(experiment_id=args.experiment_id, comp=args.comp)
@@ -57,7 +58,7 @@ class Evaluator:
     def log_name(self):
         a = self.args
         return 'eval/eval_log_{}_e_{}_dynamic_{}_size_{}_b_{}_comp_{}_vocab_sel_{}_samples_{}_top_{}_random_{}.txt'.format(
-            "neural", a.experiment_id, a.dynamic_decoding, a.eval_size, a.beam_size, a.comp, a.vocab_select, a.samples,
+            "ngram_{}".format(a.ngram_order) if a.use_ngram else "neural", a.experiment_id, a.dynamic_decoding, a.eval_size, a.beam_size, a.comp, a.vocab_select, a.samples,
             a.top_sampling, a.random_sampling)
 
     def evaluate(self):
@@ -93,16 +94,18 @@ class Evaluator:
                 best_hit, n_best_hit, a.eval_size - best_hit - n_best_hit, a.eval_size)
             f.write(summary)
             d = self.decoder
-            lines = ["--- %f seconds lstm per step ---" % (np.mean(d.perf_log_lstm)),
-                     "--- %f seconds softmax per step ---" % (np.mean(d.perf_log_softmax)),
-                     "--- %f seconds per sent.---" % (np.sum(d.perf_log_lstm + d.perf_log_softmax) / d.perf_sen)]
+            lines = []
+            if not a.use_ngram:       # eval.py:104-107
+                lines = ["--- %f seconds lstm per step ---" % (np.mean(d.perf_log_lstm)),
+                         "--- %f seconds softmax per step ---" % (np.mean(d.perf_log_softmax)),
+                         "--- %f seconds per sent.---" % (np.sum(d.perf_log_lstm + d.perf_log_softmax) / d.perf_sen)]
             for ln in lines:
                 f.write(ln)
             f.write("--- %s seconds ---" % (time.time() - start_time))
             print(summary)
             for ln in lines:
                 print(ln)
-            if a.dynamic_decoding:
+            if a.dynamic_decoding and not a.use_ngram:
                 print("--- %f seconds per step for vocab fix.---" % np.mean(d.perf_log_fix_vocab))
                 print("--- %f seconds per step for lattice path fix.---" % np.mean(d.perf_log_fix_lattice_path_prob))
             print("--- %s seconds ---" % (time.time() - start_time))

@@ -182,6 +182,42 @@ def small_segs(V):
     return [(32, 0, V // 4), (16, V // 4, (3 * V) // 5), (8, (3 * V) // 5, None)]
 
 
+def write_arpa(root, lexicon, vocab_size, seed=77, name="lm3"):
+    """A synthetic back-off n-gram file ``data/lm3`` in the layout the reference's parser reads
+    (decoder/model_ngram.py:30-52: tab-separated ``log10 prob <TAB> w1 w2 .. [<TAB> log10 backoff]``, every other line
+    ignored; ``<s>`` / ``</s>`` stand for ``<eos>``).  Unigrams for ~80 % of the in-vocabulary words (the rest fall
+    to the 100.0 floor), bigrams and trigrams over random word pairs / triples, some anchored at the sentence start."""
+    rng = np.random.RandomState(seed)
+    words = [w for w, _f in lexicon[1:vocab_size - 1]]
+    n = len(words)
+    fmt = lambda x: "%.4f" % x
+    lines = ["", "\\data\\", "ngram 1=0", "ngram 2=0", "ngram 3=0", "", "\\1-grams:"]
+    lines.append("%s\t</s>" % fmt(-1.2))
+    lines.append("%s\t<s>\t%s" % (fmt(-99.0), fmt(-0.3)))
+    keep = rng.rand(n) < 0.8
+    lp = -1.0 - 4.0 * rng.rand(n)
+    bo = -0.1 - 0.8 * rng.rand(n)
+    for i in range(n):
+        if keep[i]:
+            lines.append("%s\t%s\t%s" % (fmt(lp[i]), words[i], fmt(bo[i])))
+    lines += ["", "\\2-grams:"]
+    for _ in range(4 * n):
+        a, b = rng.randint(0, n, size=2)
+        first = "<s>" if rng.rand() < 0.1 else words[a]
+        last = "</s>" if rng.rand() < 0.05 else words[b]
+        lines.append("%s\t%s %s\t%s" % (fmt(-0.3 - 3.0 * rng.rand()), first, last, fmt(-0.1 - 0.5 * rng.rand())))
+    lines += ["", "\\3-grams:"]
+    for _ in range(3 * n):
+        a, b, c = rng.randint(0, n, size=3)
+        first = "<s>" if rng.rand() < 0.1 else words[a]
+        lines.append("%s\t%s %s %s" % (fmt(-0.2 - 2.5 * rng.rand()), first, words[b], words[c]))
+    lines += ["", "\\end\\", ""]
+    d = os.path.join(root, "data")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "w", encoding="utf-8") as f:
+        f.write("\n".join(lines))
+
+
 def build_fixture(root, name, exp_id=1):
     """Materialise one named fixture under ``root``; returns (cfg, lexicon,
     reading_dict, alphabet).  The small fixtures use a 12-kana alphabet so
@@ -207,6 +243,8 @@ def build_fixture(root, name, exp_id=1):
     cfg = make_config(V, H, E, mode, segs, self_norm)
     lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet)
     write_experiment(root, exp_id, cfg, scale=scale)
+    if size == "small":
+        write_arpa(root, lexicon, V)      # the n-gram baseline's model file (decoder/model_ngram.py reads data/lm3)
     return cfg, lexicon, reading_dict, alphabet
 
 

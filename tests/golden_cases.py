@@ -71,4 +71,22 @@ EVAL_CASES = [
     ("small-tied/eval-static", "small-tied", ["-e", "1", "-es", "20", "-b", "10"]),
     ("small-tied/eval-dynamic", "small-tied", ["-e", "1", "-es", "12", "-b", "10", "-vs", "True", "-dd", "True"]),
 ]
+# n-gram baseline decoder (reference decoder/decoder_ngram.py, model data/lm3 written by synth.write_arpa):
+# (name, fixture, ngram order, decode kwargs, sentence spec)
+NGRAM_CASES = [
+    ("small-tied/ngram-o3", "small-tied", 3, dict(beam_width=10), ("ragged", 12, 1, 20, 3)),
+    ("small-tied/ngram-o2-b3", "small-tied", 2, dict(beam_width=3, topN=5), ("ragged", 8, 1, 16, 4)),
+    ("small-tied/ngram-unpruned", "small-tied", 3, dict(beam_width=None, topN=10), ("ragged", 6, 1, 5, 5)),
+]
+NGRAM_UNCOVERED = "\u30f7"          # a kana no lexicon reading contains: this decoder has no <unk> fallback -> no path
+
+
+def ngram_sentences(spec, alphabet, first_case):
+    sents = case_sentences(spec, alphabet)
+    if first_case:
+        sents = sents + [sents[0][:3] + NGRAM_UNCOVERED + sents[0][3:]]
+    return sents
+
+
+NGRAM_EVAL_CASE = ("small-tied/eval-ngram", "small-tied", ["-e", "1", "-es", "20", "-b", "10", "-ng", "True", "-o", "3"])
 EVAL_CORPUS = dict(n=30, words_per_sentence=5, seed=5, oov_every=6)

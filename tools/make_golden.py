@@ -9,8 +9,9 @@ jlm_amd/synth.py), expected outputs go to tests/golden/:
   decode.json       Decoder.decode / DynamicDecoder.decode n-best lists (+ per
                     frame beams, read from the reference's Path objects)
   eval.json         decoder/eval.py run unchanged via runpy: hit counts and log
+  ngram.json        NGramDecoder.decode n-best lists, NGramModel.evaluate, eval.py -ng
 
-Usage:  python tools/make_golden.py [--only lm|decode|eval] [--filter substr]
+Usage:  python tools/make_golden.py [--only lm|decode|eval|ngram] [--filter substr]
 """
 import argparse
 import contextlib
@@ -191,6 +192,61 @@ def gen_eval():
         json.dump(results, f, ensure_ascii=False, indent=0)
 
 
+def _run_reference_eval(root, argv):
+    work = tempfile.mkdtemp()
+    os.makedirs(os.path.join(work, "eval"))
+    cwd = os.getcwd()
+    os.chdir(work)
+    old_argv = sys.argv
+    sys.argv = ["eval.py"] + argv
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            runpy.run_path(os.path.join(REF, "decoder", "eval.py"), run_name="__main__")
+    finally:
+        sys.argv = old_argv
+        os.chdir(cwd)
+    logs = os.listdir(os.path.join(work, "eval"))
+    assert len(logs) == 1
+    with open(os.path.join(work, "eval", logs[0]), "r", encoding="utf-8") as f:
+        body = f.read()
+    cut = body.index("--- ") if "--- " in body else len(body)
+    hits = [ln for ln in buf.getvalue().splitlines() if ln.startswith("best_hit")]
+    return {"log_name": logs[0], "log_body": body[:cut], "stdout_hits": hits}
+
+
+def gen_ngram():
+    """The n-gram baseline (reference decoder/decoder_ngram.py + model_ngram.py) on data/lm3 of the fixture."""
+    results = {}
+    for name, fx, order, kwargs, spec in gc.NGRAM_CASES:
+        root = fixture_root(fx)
+        import_reference(root)
+        sys.modules.pop("decoder_ngram", None)
+        sys.modules.pop("model_ngram", None)
+        with contextlib.redirect_stdout(io.StringIO()):
+            import decoder_ngram
+            dec = decoder_ngram.NGramDecoder(1, ngram_order=order)
+        sents = gc.ngram_sentences(spec, _alpha[fx], name == gc.NGRAM_CASES[0][0])
+        out = []
+        for s in sents:
+            nbest = dec.decode(s, **kwargs)
+            item = {"input": s, "nbest": [[float(a), list(b)] for a, b in nbest]}
+            if nbest:
+                item["evaluate_best"] = float(dec.model.evaluate(list(nbest[0][1])))
+            out.append(item)
+        results[name] = out
+        print("ngram", name, len(out), "sentences;", sum(1 for o in out if not o["nbest"]), "without a path")
+    name, fx, argv = gc.NGRAM_EVAL_CASE
+    root = fixture_root(fx)
+    cfg, lexicon, _rd, _al = synth.build_fixture(root, fx)
+    synth.write_test_corpus(root, lexicon, cfg["vocab_size"], **gc.EVAL_CORPUS)
+    import_reference(root)
+    results[name] = _run_reference_eval(root, argv)
+    print("ngram eval", results[name]["stdout_hits"])
+    with open(os.path.join(GOLD, "ngram.json"), "w", encoding="utf-8") as f:
+        json.dump(results, f, ensure_ascii=False, indent=0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -203,3 +259,5 @@ if __name__ == "__main__":
         gen_decode(a.filter)
     if a.only in (None, "eval"):
         gen_eval()
+    if a.only in (None, "ngram"):
+        gen_ngram()
