@@ -69,3 +69,23 @@ def test_eval_harness_with_the_ngram_decoder(fx, golden_ngram, monkeypatch, tmp_
     with open(os.path.join("eval", gold["log_name"]), "r", encoding="utf-8") as fh:
         body = fh.read()
     assert body[:body.index("--- ")] == gold["log_body"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/decoder/eval.py"), reason="the reference is only present in the build container")
+def test_reference_eval_py_with_ng_runs_unchanged_over_compat(fx, golden_ngram, monkeypatch, tmp_path):
+    """The reference's own eval.py -ng True, its NGramDecoder import resolved by compat/decoder_ngram.py."""
+    name, fixture, argv = gc.NGRAM_EVAL_CASE
+    f = fx(fixture)
+    synth.write_test_corpus(f["root"], f["lexicon"], f["cfg"]["vocab_size"], **gc.EVAL_CORPUS)
+    jconfig.set_root(f["root"])
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("eval")
+    from tools import run_reference_eval
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        run_reference_eval.run("/root/reference/decoder/eval.py", argv)
+    gold = golden_ngram[name]
+    assert [ln for ln in buf.getvalue().splitlines() if ln.startswith("best_hit")] == gold["stdout_hits"]
+    with open(os.path.join("eval", gold["log_name"]), "r", encoding="utf-8") as fh:
+        body = fh.read()
+    assert body[:body.index("--- ")] == gold["log_body"]
