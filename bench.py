@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--end-to-end", action="store_true", help="time the host-inclusive path as the step")
     ap.add_argument("--decoder", default="static", choices=["static", "static-vs", "dynamic"],
                     help="static = Decoder full vocabulary (headline); static-vs = vocab_select; dynamic = DynamicDecoder (configs[3])")
+    # debugging the N > 1 control flow on a one-GPU box: every rank on device 0, control-plane collectives over gloo
+    ap.add_argument("--debug-shared-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import numpy as np
@@ -65,8 +67,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.debug_shared_gpu:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
     else:
         torch.cuda.set_device(0)
@@ -149,10 +155,11 @@ def main():
     dt_eager = time.perf_counter() - t0e
     eng.recorder = None
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        cdev = "cpu" if args.debug_shared_gpu else "cuda"
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(chars_per_step)], device="cuda", dtype=torch.float64)
+        c = torch.tensor([float(chars_per_step)], device=cdev, dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_chars_per_step = float(c.item())
     else:
