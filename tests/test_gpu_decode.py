@@ -6,6 +6,8 @@ at BASELINE.json's full batch sizes.
 Bars (BASELINE.json north_star): step logits <= 1e-4 relative, identical 1-best
 decode strings.  Path scores are sums of ~20 float32-derived terms of size ~10,
 so they are compared at 1e-5 relative / 1e-3 absolute."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,8 @@ def test_decode_matches_reference_golden(case, fast, fx, golden_decode):
 def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
     """JLM_PRECISION=f32 keeps the whole decode on the f32 matrix pipe (the round's first
     kernels); it must give the same n-best as the default split-f16 decode."""
+    if os.environ.get("JLM_PRECISION", "f16x3") != "f16x3":
+        pytest.skip("the suite is running with JLM_PRECISION=f32: there is no split path to compare with")
     f = fx(fixture)
     jconfig.set_root(f["root"])
     from jlm_amd.decoder import Decoder
@@ -128,6 +132,8 @@ def test_native_frame_loop_equals_call_by_call_loop(fixture, kind, kw, fx):
     dec = _decoder(f, kind)
     eng = dec._engine
     sents = synth.make_ragged_sentences(14, 1, 17, seed=91, alphabet=f["alphabet"])
+    if os.environ.get("JLM_NATIVE_LOOP", "1") == "0":
+        pytest.skip("the suite is running with JLM_NATIVE_LOOP=0")
     assert eng.native_loop
     a = dec.decode_batch(sents, beam_width=6, **kw)
     eng.native_loop = False

@@ -1,6 +1,8 @@
 """GPU: edge cases of the decoders against the oracle -- beam 1, beam larger than the
 candidate count, one-kana and long sentences, raw-symbol (<unk>) fallbacks, empty
 batch, a vocabulary whose size is not a multiple of any tile, LSTM_Model helpers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -167,7 +169,8 @@ def test_operand_ranges_of_the_split_kernels(name, edit, tag, tmp_path):
     the decode must stay on the oracle whatever those ranges are."""
     f = _rescaled_fixture(tmp_path, name, edit)
     d, o = _pair(f, "static")
-    assert d.model.dev.split_array is not None
+    if os.environ.get("JLM_PRECISION", "f16x3") == "f16x3":      # (the suite also runs under JLM_PRECISION=f32)
+        assert d.model.dev.split_array is not None
     sents = synth.make_ragged_sentences(6, 3, 15, seed=123, alphabet=f["alphabet"])
     got = d.decode_batch(sents, beam_width=6)
     for s, g in zip(sents, got):
