@@ -139,6 +139,7 @@ class _Plan:
                                   self.edge.data_ptr(), self.live_base.data_ptr(), None, 0, 0)
         self.graph = None
         self.warm = False
+        self.nbytes = sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor) and t.device == dev)
         # jlm_decode_plan: the same buffers for the native frame loop (jlm_decode_frames)
         ptr = lambda t: t.data_ptr() if t is not None else None
         d = self.desc = _lib.DecodePlan()
@@ -165,7 +166,9 @@ class _Plan:
 
 
 class DecodeEngine:
-    MAX_PLANS = 4
+    MAX_PLANS = 4                  # plans kept regardless of their size (two or three are in flight at a time)
+    MAX_PLANS_SMALL = 48           # ... and as many more as fit PLAN_BYTES of device memory
+    PLAN_BYTES = 4 << 30
 
     def __init__(self, dev_model):
         self.m = dev_model
@@ -204,10 +207,17 @@ class DecodeEngine:
         caps = {k: _round_up(int(v * 1.25) + 64, 1024) for k, v in need.items()}
         caps["cands"] = max(_round_up(need["cands"], 256), 1024)
         self.plans = [p for p in self.plans if p.busy or p.key != key or p.fits(need)]
-        idle = [p for p in self.plans if not p.busy]
-        while len(self.plans) >= self.MAX_PLANS and idle:
-            self.plans.remove(idle.pop(0))
         p = _Plan(self, key, caps)
+        # Least recently used idle plans go when the set outgrows its budget: a count for the big batch plans (hundreds
+        # of MB each), bytes for the small ones -- sentence-at-a-time callers (eval.py) meet a new (length bucket, list
+        # size) shape every few calls, and re-allocating a plan costs more than the decode it serves.
+        idle = [q for q in self.plans if not q.busy]
+        total = sum(q.nbytes for q in self.plans) + p.nbytes
+        while idle and (len(self.plans) >= self.MAX_PLANS_SMALL or
+                        (total > self.PLAN_BYTES and len(self.plans) >= self.MAX_PLANS)):
+            q = idle.pop(0)
+            self.plans.remove(q)
+            total -= q.nbytes
         self.plans.append(p)
         return p
 

@@ -11,6 +11,8 @@ root = os.path.join(tempfile.gettempdir(), "jlm_dbg")
 cfg, _l, _r, al = synth.build_fixture(root, fixture)
 jconfig.set_root(root)
 sents = synth.make_sentences(64, 20, seed=4242, alphabet=al)
+if os.environ.get('SS_RAGGED'):
+    sents = synth.make_ragged_sentences(200, 3, 45, seed=7, alphabet=al)      # every length bucket, every list-size class
 for cls, kw in ((Decoder, {}), (Decoder, dict(vocab_select=True)), (DynamicDecoder, dict(vocab_select=True))):
     dec = cls(1)
     for timing in (True, False):
@@ -19,4 +21,4 @@ for cls, kw in ((Decoder, {}), (Decoder, dict(vocab_select=True)), (DynamicDecod
         torch.cuda.synchronize(); t = time.perf_counter()
         for s in sents: dec.decode(s, **kw)
         dt = (time.perf_counter() - t) / len(sents)
-        print("%-15s %-22s perf_timing=%-5s  %.2f ms per sentence  %.0f chars/s" % (cls.__name__, kw, timing, dt * 1e3, 20 / dt))
+        print("%-15s %-22s perf_timing=%-5s  %.2f ms per sentence  %.0f chars/s" % (cls.__name__, kw, timing, dt * 1e3, sum(len(x) for x in sents) / len(sents) / dt))
