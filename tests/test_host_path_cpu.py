@@ -3,6 +3,8 @@ sequence, read-out, reference-compatible classes) driven end to end with the
 numpy test double of the C ABI (tests/fake_hip.py), checked against the golden
 vectors captured from the reference.  The kernels themselves are checked on the
 GPU box (tests/test_gpu_*.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -158,3 +160,14 @@ def test_module_helpers_match_the_oracle_and_smoke_main_runs(fx, fake, capsys):
     out = capsys.readouterr().out
     assert "--- generated sentence" in out and "--- random sentence" in out
     assert np.isfinite(a) and np.isfinite(b) and a > 0 and b > 0
+
+
+def test_usable_cpus_follows_quota_and_local_world_size(monkeypatch):
+    import jlm_amd
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    base = jlm_amd.usable_cpus()
+    assert 1 <= base <= (os.cpu_count() or 1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert jlm_amd.usable_cpus() == max(1, base // 4)           # the ranks of a node share the quota
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
+    assert jlm_amd.usable_cpus() == base
