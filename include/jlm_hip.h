@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 3
+#define JLM_ABI_VERSION 4
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
 int jlm_device_arch(int dev, char *buf, int buflen);
@@ -152,6 +152,21 @@ int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void 
                         const void *emb, int ld_emb, const void *wt, const float *bias,
                         int kpad, int H, int E, float descale, float h_scale, const float *xgate,
                         int n_rows_max, const int *n_dev, void *stream);
+
+/* ABI 4: the decode's LSTM step (K1+K2+K3+K9; decoder/model.py:125-139 with the state gather / scatter of
+ * Decoder._batch_predict, decoder/decoder.py:206-218), table form, one 160-row x 128-gate-column tile per CU.
+ * Same row semantics as jlm_lstm_step.  Operands:
+ *   h_in / h_out   split rows of the state scaled by h_scale (|h| < 1, h_scale a power of two <= 2^14);
+ *   wt8            split rows [4H, H] of the state half of the gate matrix scaled by 1 / (descale * h_scale),
+ *                  in the gate-interleave-8 row order  n = (u / 8) * 32 + gate * 8 + (u % 8), gate order i,f,o,g
+ *                  (a 32-row MFMA block = four gates of eight units: the cell update needs no transposition);
+ *   xgate8         f32 [V, 4H], same column order: (emb[w] . W_x^T + bias) / descale for every vocabulary word
+ *                  (model.py:125-131 computes x.IM_g + h.HM_g + b_g; the table is the x.IM_g + b_g part);
+ *   c stays f32.   H % 32 == 0, ld_state % 16 == 0. */
+int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
+                     const int *rows, const int *prev, const int *word,
+                     const void *wt8, const float *xgate8, int H, float descale, float h_scale,
+                     int n_rows_max, const int *n_dev, void *stream);
 
 /* jlm_gemm_nt on split rows: C = descale * (A . B^T) + bias, C plain f32. */
 int jlm_gemm_nt_split(const void *A, int lda, const int *a_rows, const void *B, int ldb, const int *b_rows,
@@ -295,7 +310,7 @@ int jlm_softmax_rows(const float *y, float *pred, int ld, int n_rows, int n_cols
  * whole launch sequence of a batch -- per frame
  *   [incremental: merge the frame's new words into all older rows]  jlm_wordlist_merge_split | jlm_wordlist_lse(merge)
  *   jlm_beam_step                (folds the previous frame's normaliser slices)
- *   jlm_lstm_step(_split), jlm_gemm_nt(_split) (T projection)
+ *   jlm_lstm_step_xg | jlm_lstm_step(_split), jlm_gemm_nt(_split) (T projection)
  *   jlm_edge_logits              (on `side_stream` when given, forked after T and joined before the next beam step)
  *   jlm_vocab_lse_split | _stationary | jlm_wordlist_lse(_split)
  * and jlm_backtrace at the end -- exactly the calls a host would make one by
@@ -315,6 +330,8 @@ typedef struct {
     const float *emb; int ld_emb; const float *wt; const float *gate_bias; int kpad, E;
     /* jlm_lstm_step_split operands (split_lstm == 1; input side = xgate table) */
     const void *wt_split; int kpad_split; float gate_descale, h_scale; const float *xgate;
+    /* jlm_lstm_step_xg operands (ABI 4; used instead of the line above when wt8 != NULL) */
+    const void *wt8; const float *xgate8;
     /* T projection: [n_t, H] panel, plain or split rows */
     const float *pmt; const void *pmt_split; int n_t; float t_descale;
     /* full-vocabulary normaliser: split segments (NULL: f32 rows-stationary form) */

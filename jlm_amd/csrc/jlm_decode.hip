@@ -89,7 +89,10 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         if (f == F - 1) break;
         const int *rows = st.live + (size_t)f * rmax;
         const int *ndev = st.n_live + f;
-        if (m->split_lstm)
+        if (m->split_lstm && m->wt8)
+            JLM_TRY(jlm_lstm_step_xg(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, m->wt8, m->xgate8, m->H,
+                                     m->gate_descale, m->h_scale, rmax, ndev, stream));
+        else if (m->split_lstm)
             JLM_TRY(jlm_lstm_step_split(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, nullptr, 0, m->wt_split, nullptr,
                                         m->kpad_split, m->H, 0, m->gate_descale, m->h_scale, m->xgate, rmax, ndev, stream));
         else

@@ -352,13 +352,28 @@ class DeviceModel:
             # GEMM then contracts over the state only (a third less staging traffic, which is what it is
             # bound by) and the epilogue adds one gathered row per hypothesis
             S = 14 + pow2_below(2.0 ** 14, wh)
-            wx = self.wt[:, H:H + self.Epad].double()
-            self.xgate = (self.emb.double() @ wx.T + self.gate_bias.double()).float().contiguous()
-            del wx
+            # gate-interleave-8 row order of jlm_lstm_step_xg: a 32-row MFMA block = the four gates of eight units
+            u = np.arange(H)
+            perm8 = np.empty(4 * H, dtype=np.int64)
+            for gi in range(4):
+                perm8[(u // 8) * 32 + gi * 8 + (u % 8)] = (u // 16) * 64 + gi * 16 + (u % 16)
+            wt_host = self.wt.cpu().numpy()
+            # float64 product on the host (the reference's own arithmetic, np.dot), rounded once, pre-multiplied by
+            # 2^S = 1 / descale so that a table row is the accumulators' start value
+            wx = wt_host[perm8, H:H + self.Epad].astype(np.float64)
+            xg = self.emb.cpu().numpy().astype(np.float64) @ wx.T
+            xg += self.gate_bias.cpu().numpy().astype(np.float64)[perm8]
+            xg *= 2.0 ** S
+            self.xgate8 = torch.from_numpy(xg.astype(np.float32)).to(self.device)
+            del xg, wx
             self.kpad_split = H
-            self.wt_split = torch.zeros((4 * H, self.kpad_split), dtype=torch.float32, device=self.device)
-            _lib.check(L.jlm_pack_split_f16(self.wt.data_ptr(), 4 * H, H, self.kpad, float(2.0 ** (S - 14)),
-                                            self.wt_split.data_ptr(), self.kpad_split, st), "jlm_pack_split_f16(W_h)")
+            wt8 = torch.from_numpy(np.ascontiguousarray(wt_host[perm8, :H])).to(self.device)
+            self.wt8 = torch.zeros((4 * H, H), dtype=torch.float32, device=self.device)
+            _lib.check(L.jlm_pack_split_f16(wt8.data_ptr(), 4 * H, H, H, float(2.0 ** (S - 14)),
+                                            self.wt8.data_ptr(), H, st), "jlm_pack_split_f16(W_h)")
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)      # wt8's source goes out of scope
+            del wt8
             self.gate_descale = 2.0 ** -S
             eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
             self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
@@ -381,8 +396,8 @@ class DeviceModel:
             d.emb, d.ld_emb, d.wt, d.gate_bias = self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr()
             d.kpad, d.E = self.kpad, self.Epad
             if self.split_lstm:
-                d.wt_split, d.kpad_split = self.wt_split.data_ptr(), self.kpad_split
-                d.gate_descale, d.h_scale, d.xgate = self.gate_descale, self.h_scale, self.xgate.data_ptr()
+                d.wt8, d.xgate8, d.kpad_split = self.wt8.data_ptr(), self.xgate8.data_ptr(), self.kpad_split
+                d.gate_descale, d.h_scale = self.gate_descale, self.h_scale
                 d.pmt_split, d.t_descale = self.pmt_split.data_ptr(), self.t_descale
             d.pmt, d.n_t = ptr(self.pmt), (self.pmt.shape[0] if self.pmt is not None else 0)
             if self.split_array is not None:
@@ -404,10 +419,9 @@ class DeviceModel:
         if rec is not None:
             rec.begin("gate_gemm")
         if split:
-            _lib.check(L.jlm_lstm_step_split(h_in, c_in, ld, h_out, c_out, rows, prev, word, None, 0,
-                                             self.wt_split.data_ptr(), None, self.kpad_split, self.H, 0,
-                                             self.gate_descale, self.h_scale, self.xgate.data_ptr(), n_rows_max, n_dev, stream),
-                       "jlm_lstm_step_split")
+            _lib.check(L.jlm_lstm_step_xg(h_in, c_in, ld, h_out, c_out, rows, prev, word, self.wt8.data_ptr(),
+                                          self.xgate8.data_ptr(), self.H, self.gate_descale, self.h_scale, n_rows_max, n_dev,
+                                          stream), "jlm_lstm_step_xg")
         else:
             _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
                                        self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),

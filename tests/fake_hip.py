@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 3
+        return 4
 
     # ------------------------------------------------------- the frame loop (ABI 3)
     def jlm_decode_frames(self, m, p, lat, st, stream, side_stream):
@@ -90,7 +90,10 @@ class FakeLib:
             if f == F - 1:
                 break
             rows, ndev = off(st.live, f * rmax), off(st.n_live, f)
-            if m.split_lstm:
+            if m.split_lstm and m.wt8:
+                r = self.jlm_lstm_step_xg(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, m.wt8, m.xgate8, m.H,
+                                          m.gate_descale, m.h_scale, rmax, ndev, stream)
+            elif m.split_lstm:
                 r = self.jlm_lstm_step_split(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, None, 0, m.wt_split, None,
                                              m.kpad_split, m.H, 0, m.gate_descale, m.h_scale, m.xgate, rmax, ndev, stream)
             else:
@@ -221,6 +224,39 @@ class FakeLib:
         z = ((x @ W.T) * float(descale)).astype(np.float32) + add
         u = np.arange(H)
         zi, zf, zo, zg = (z[:, (u // 16) * 64 + k * 16 + (u % 16)] for k in range(4))
+        sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
+        cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
+        hn = (np.tanh(cn) * sig(zo)).astype(np.float32)
+        self._split_write(h_out, gmax, ld, g, hn * np.float32(h_scale))
+        cout = view(c_out, gmax * ld, np.float32).reshape(gmax, ld)
+        cout[g, :H] = cn
+        return 0
+
+    def jlm_lstm_step_xg(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, wt8, xgate8, H, descale, h_scale,
+                         n_rows_max, n_dev, stream):
+        """table form, gate-interleave-8 order: n = (u / 8) * 32 + gate * 8 + u % 8; xgate8 pre-multiplied by 1 / descale"""
+        if H <= 0 or H % 32 or ld % 16 or ld < H:
+            return -1
+        n = _n(n_rows_max, n_dev)
+        if n <= 0:
+            return 0
+        g = _rows(rows, n)
+        gmax = int(g.max()) + 1
+        p = view(prev, gmax, np.int32)[g].astype(np.int64)
+        w = view(word, gmax, np.int32)[g].astype(np.int64)
+        hmax = max(gmax, int(p.max()) + 1)
+        hin = self._split_read(h_in, hmax, ld)
+        cin = view(c_in, hmax * ld, np.float32).reshape(hmax, ld)
+        ok = p >= 0
+        x = np.zeros((n, H), dtype=np.float64)
+        x[ok] = hin[p[ok], :H]
+        cp = np.zeros((n, H), dtype=np.float32)
+        cp[ok] = cin[p[ok], :H]
+        W = self._split_read(wt8, 4 * H, H)
+        add = view(xgate8, (int(w.max()) + 1) * 4 * H, np.float32).reshape(-1, 4 * H)[w].astype(np.float64)
+        z = ((x @ W.T + add) * float(descale)).astype(np.float32)
+        u = np.arange(H)
+        zi, zf, zo, zg = (z[:, (u // 8) * 32 + k * 8 + (u % 8)] for k in range(4))
         sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
         cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
         hn = (np.tanh(cn) * sig(zo)).astype(np.float32)

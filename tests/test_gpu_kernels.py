@@ -202,6 +202,75 @@ def test_lstm_step_split(L, H, E, R, use_rows):
     np.testing.assert_allclose(cog2.cpu().numpy()[sel], co.numpy()[sel], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("H,R,use_rows", [(64, 10, False), (64, 200, True), (512, 700, True), (512, 2560, True), (128, 161, True),
+                                         (512, 159, False)])
+def test_lstm_step_xg(L, H, R, use_rows):
+    """jlm_lstm_step_xg (one 160 x 128 tile per CU, gate-interleave-8 order, table rows as accumulator start values)
+    against the f64 restatement on the ORIGINAL f32 operands and against the numpy double fed the same split rows;
+    in-place state arrays, gathered rows, a device-side row count one short of the bound"""
+    rng = np.random.default_rng(7 * H + R)
+    V, G = 300, R * 3 + 7
+    h_np = np.tanh(rng.standard_normal((G, H))).astype(np.float32)
+    c_np = (rng.standard_normal((G, H)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((4 * H, H)) * 0.08).astype(np.float32)             # rows in gate-interleave-8 order
+    xg = (rng.standard_normal((V, 4 * H)) * 0.6).astype(np.float32)             # emb . W_x^T + b, same order
+    word_np = rng.integers(0, V, size=G).astype(np.int32)
+    S = 20
+    if use_rows:
+        rows_np = (G - 1 - rng.permutation(R)).astype(np.int32)
+        prev_np = rng.integers(-1, G - R, size=G).astype(np.int32)
+        n_live = R - 1
+    else:
+        rows_np = None
+        prev_np = np.concatenate([np.full(R, -1), np.arange(G - R)]).astype(np.int32)   # rows 0..R-1 <- zero state / R.. <- earlier
+        prev_np = np.where(np.arange(G) < R, np.where(np.arange(G) % 3 == 0, -1, R + np.arange(G) % (G - R)), 0).astype(np.int32)
+        n_live = R
+    sel = rows_np[:n_live] if use_rows else np.arange(R)
+    # f64 restatement
+    p = prev_np[sel].astype(np.int64)
+    hin = np.where((p >= 0)[:, None], h_np[np.maximum(p, 0)], 0.0).astype(np.float64)
+    cin = np.where((p >= 0)[:, None], c_np[np.maximum(p, 0)], 0.0).astype(np.float64)
+    z = hin @ W.astype(np.float64).T + xg[word_np[sel]].astype(np.float64)
+    u = np.arange(H)
+    zi, zf, zo, zg = (z[:, (u // 8) * 32 + k * 8 + (u % 8)] for k in range(4))
+    sig = lambda t: 1.0 / (np.exp(-t) + 1.0)
+    cn = cin * sig(zf) + np.tanh(zg) * sig(zi)
+    hn = np.tanh(cn) * sig(zo)
+    # device operands
+    hg, cg = torch.as_tensor(h_np).cuda(), torch.as_tensor(c_np.copy()).cuda()
+    hs = _pack(L, hg, H, 2.0 ** 14)
+    ws = _pack(L, torch.as_tensor(W).cuda(), H, 2.0 ** (S - 14))
+    xg8 = torch.as_tensor(xg * np.float32(2.0 ** S)).cuda()
+    wordg, prevg = torch.as_tensor(word_np).cuda(), torch.as_tensor(prev_np).cuda()
+    rowsg = torch.as_tensor(rows_np).cuda() if use_rows else None
+    ndg = torch.as_tensor(np.array([n_live], dtype=np.int32)).cuda() if use_rows else None
+    torch.cuda.synchronize()
+    hs_c, cc = hs.cpu(), torch.as_tensor(c_np.copy())
+    args = (H, 2.0 ** -S, 2.0 ** 14, R)
+    assert L.jlm_lstm_step_xg(hs.data_ptr(), cg.data_ptr(), H, hs.data_ptr(), cg.data_ptr(), rowsg.data_ptr() if use_rows else None,
+                              prevg.data_ptr(), wordg.data_ptr(), ws.data_ptr(), xg8.data_ptr(), *args,
+                              ndg.data_ptr() if use_rows else None, _st()) == 0
+    torch.cuda.synchronize()
+    h_gpu = _unsplit(hs) / 2.0 ** 14
+    c_gpu = cg.cpu().numpy()
+    np.testing.assert_allclose(h_gpu[sel], hn, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(c_gpu[sel], cn, rtol=2e-5, atol=2e-6)
+    # rows that were not stepped are untouched
+    mask = np.ones(G, dtype=bool)
+    mask[sel] = False
+    np.testing.assert_array_equal(c_gpu[mask], c_np[mask])
+    # the numpy double on the same split rows
+    ws_c, xg_c = ws.cpu(), xg8.cpu()
+    rows_c = torch.as_tensor(rows_np) if use_rows else None
+    nd_c = torch.as_tensor(np.array([n_live], dtype=np.int32)) if use_rows else None
+    word_c, prev_c = torch.as_tensor(word_np), torch.as_tensor(prev_np)
+    assert FK.jlm_lstm_step_xg(hs_c.data_ptr(), cc.data_ptr(), H, hs_c.data_ptr(), cc.data_ptr(),
+                               rows_c.data_ptr() if use_rows else None, prev_c.data_ptr(), word_c.data_ptr(), ws_c.data_ptr(),
+                               xg_c.data_ptr(), *args, nd_c.data_ptr() if use_rows else None, 0) == 0
+    np.testing.assert_allclose(h_gpu[sel], (_unsplit(hs_c) / 2.0 ** 14)[sel], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(c_gpu[sel], cc.numpy()[sel], rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("M,N,K,maps", [(70, 40, 32, False), (300, 352, 512, True), (2560, 352, 512, True), (1, 8, 16, False)])
 def test_gemm_nt_split(L, M, N, K, maps):
     rng = np.random.default_rng(M + N + K)

@@ -174,6 +174,30 @@ def bench_gate_split(H, E, R):
     report("lstm_step_split+xgate-table H=%d E=%d R=%d" % (H, E, R), 2.0 * (H + E) * 4 * H * R, timeit(f2))
 
 
+def bench_gate_xg(H, R):
+    if flt and flt not in "gate":
+        return
+    V, G = 50000, 3 * R
+    hf, c = torch.tanh(rnd(G, H)), rnd(G, H)
+    wtf = rnd(4 * H, H, scale=0.05)
+    h, wt = torch.zeros_like(hf), torch.zeros_like(wtf)
+    assert L.jlm_pack_split_f16(hf.data_ptr(), G, H, H, 2.0 ** 14, h.data_ptr(), H, st) == 0
+    assert L.jlm_pack_split_f16(wtf.data_ptr(), 4 * H, H, H, 2.0 ** 6, wt.data_ptr(), H, st) == 0
+    xg = rnd(V, 4 * H, scale=2.0 ** 20)
+    rows = (torch.arange(R, device=dev, dtype=torch.int32) + 2 * R).contiguous()
+    prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
+    word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    f = lambda: L.jlm_lstm_step_xg(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
+                                   word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, R, nd.data_ptr(), st)
+    assert f() == 0
+    med, mn = timeit(f)
+    ex = 3 * 2.0 * H * 4 * H * R
+    print("lstm_step_xg H=%d R=%d                        median %8.1f us  min %8.1f us  executed %6.1f TF/s = %4.1f%% of dense f16 peak "
+          "(counted 2(H+200)4H: %5.1f TF)" % (H, R, med * 1e3, mn * 1e3, ex / (med * 1e-3) / 1e12,
+                                               100 * ex / (med * 1e-3) / 1e12 / 2516.6, 2.0 * (H + 200) * 4 * H * R / (med * 1e-3) / 1e12))
+
+
 def bench_gemm_split(M, N, K, tag):
     if flt and flt not in "gemm":
         return
@@ -200,6 +224,7 @@ if __name__ == "__main__":
     for R in (2560,):
         bench_gate(512, 200, R)
         bench_gate_split(512, 200, R)
+        bench_gate_xg(512, R)
         bench_gate(512, 256, R)
         bench_gate_split(512, 256, R)
         bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
@@ -216,6 +241,9 @@ if __name__ == "__main__":
         bench_gemm(R, 200, 512, "PM")
         bench_gemm(R, 100, 200, "VT1")
         bench_gemm(R, 52, 200, "VT2")
+    bench_gate_xg(512, 5120)
+    bench_gate_xg(512, 10240)
+    bench_gate_xg(512, 20480)
     bench_gate(512, 256, 20480)
     bench_lse(100000, 256, 20480, "tied100k-b20")
     bench_lse_stat(100000, [256], 20480, "tied100k-b20")
