@@ -1,2 +1,8 @@
-"""reference decoder/decoder.py -> jlm_amd.decoder"""
-from jlm_amd.decoder import Decoder, CharRNNDecoder, Node  # noqa: F401
+"""reference decoder/decoder.py -> jlm_amd.decoder (per-frame timing on: the reference's eval.py prints perf_log_*)"""
+from jlm_amd.decoder import Decoder as _Decoder, CharRNNDecoder, Node  # noqa: F401
+
+
+class Decoder(_Decoder):
+    def __init__(self, *a, **k):
+        super(Decoder, self).__init__(*a, **k)
+        self.perf_timing = True

@@ -3,27 +3,31 @@
 //   z[g][n] = sum_k h[prev[g]][k] * W_h[n][k]  +  xgate[word[g]][n]          (decoder/model.py:125-131)
 //   c[g] = c[prev[g]] * sig(z_f) + tanh(z_g) * sig(z_i);  h[g] = tanh(c[g]) * sig(z_o)   (model.py:133-139)
 //
-// What bounds this GEMM at the decode's shapes (R = 2 560 rows x 4H = 2 048 gate columns x K = H = 512,
-// 16 GFLOP-passes) is not the matrix pipe (6.4 us) but getting operand bytes from L2 into LDS: every
-// output tile needs (rows + columns) x 2 KB of split rows.  The tile form it replaces (128 x 64 tiles,
-// 640 workgroups) staged 245 MB per launch.  Here:
+// Shape at the decode: R = 2 560 rows x 4H = 2 048 gate columns x K = H = 512: 16 GFLOP-passes (6.4 us of the matrix
+// pipe at its nominal rate, 7.9 us at the ~2.0 GHz the chip sustains under MFMAs).  Every output tile needs
+// (rows + columns) x 2 KB of split rows from L2; the tile form it replaces (128 x 64 tiles, 640 workgroups) staged 245 MB
+// per launch.  Here:
 //   * ONE 160-hypothesis x 128-gate-column tile per CU (16 x 16 = 256 workgroups at R = 2 560, H = 512):
 //     (160 + 128) x 2 KB = 576 KB per CU, 147 MB per launch -- the minimum of (m + n) at m n = 20 480;
-//   * 8 waves = two per SIMD: wave w owns gate block w & 3 (32 gate columns) and hypothesis blocks
-//     0..2 (w < 4) or 3..4 (w >= 4), so each SIMD has 5 blocks of MFMA work and its two waves cover each
-//     other's LDS-DMA issue and fragment-read latencies;
-//   * a 4-stage LDS ring (36 KB per 32-value k-step) filled by global_load_lds_dwordx4 with counted
-//     s_waitcnt vmcnt: two to three stages (72-108 KB per CU) stay in flight across the one raw
-//     s_barrier per k-step;
-//   * SWAPPED orientation: the gate matrix is the MFMA A operand (D rows = gate columns), the
-//     hypotheses are the B operand (D columns), and the gate matrix is packed in the row order
+//   * 8 waves = two per SIMD: wave w owns gate block w & 3 (32 gate columns) and hypothesis blocks 0..2 (w < 4) or
+//     3..4 (w >= 4), so each SIMD has 5 blocks of MFMA work and its two waves cover each other;
+//   * a 4-stage LDS ring (36 KB per 32-value k-step) filled by global_load_lds_dwordx4, three stages (108 KB per CU) in
+//     flight across the one raw s_barrier per k-step, counted s_waitcnt vmcnt;
+//   * a software pipeline at HALF k-step granularity with the fragments double-buffered in registers: fragment reads and
+//     LDS-DMA issue run under MFMAs, not in front of them;
+//   * SWAPPED orientation: the gate matrix is the MFMA A operand (D rows = gate columns), the hypotheses are the B
+//     operand (D columns), and the gate matrix is packed in the row order
 //         n = (u / 8) * 32 + gate * 8 + (u % 8)          gate order i, f, o, g
 //     so that a lane's 16 accumulator registers of a 32 x 32 block are the FOUR gates of FOUR units
-//     (acc[4 gate + e] = gate of unit 8 (n / 32) + 4 (lane >> 5) + e) of ONE hypothesis (lane & 31):
-//     the LSTM cell update runs in registers, no transposition through LDS, no second barrier phase;
-//   * the input side xgate[word] (table, packed in the same order, pre-multiplied by 1 / descale) is
-//     the accumulators' INITIAL value, gathered by 16-byte loads at kernel start together with the old
-//     cell state: both round trips are hidden under the mainloop.
+//     (acc[4 gate + e] = gate of unit 8 (n / 32) + 4 (lane >> 5) + e) of ONE hypothesis (lane & 31): the LSTM cell update
+//     runs in registers -- no transposition through LDS, no second barrier phase;
+//   * the input side xgate[word] (table in the same column order, pre-multiplied by 1 / descale) and the old cell state
+//     are requested at the start of the LAST four k-steps and added in the epilogue: their HBM round trip (the table is
+//     hundreds of MB, rows are random) hides under those k-steps, and -- the vmcnt counter being in order -- does not sit
+//     in front of the ring's first stage as it would if they were requested at kernel start.
+// Measured and rejected (tools/probes/gate_xg_profile.py, gate_loop.hip): warming L2 with one load per operand
+// line at kernel start (+5 us: the loop is not bound by L2 misses -- with every operand L2-resident and no DMA at all a
+// k-step still takes 0.8 us); a whole-k-step register double buffer (spills at 3 hypothesis blocks).
 #include "jlm_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -32,8 +36,9 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
-// Per-workgroup timeline (-DJLM_PROFILE builds only, tools/probes/gate_xg_profile.py): wave 0 and wave 4 of a workgroup stamp
-// the 100 MHz wall clock at kernel start, after the index chains, when the first stage has landed, after the mainloop, at the end.
+// Per-workgroup timeline (-DJLM_PROFILE builds only, tools/probes/gate_xg_profile.py): waves 0 and 4 of a workgroup stamp the
+// 100 MHz wall clock at kernel start, after the index chains, when the first stage has landed, after the steady-state
+// k-steps, after the mainloop, at the end.
 #ifdef JLM_PROFILE
 static __device__ unsigned long long jlm_gate_time[2048][2][6];
 #define JLM_GT_T(i) do { if ((threadIdx.x & 255) == 0) jlm_gate_time[blockIdx.x & 2047][threadIdx.x >> 8][i] = wall_clock64(); } while (0)
@@ -61,12 +66,12 @@ struct GateXgArgs {
     int H; float descale, h_scale;
     int nrows; const int *ndev;
     int tiles_m, tiles_n;
-    int ablate;                                          // -DJLM_PROFILE builds: 1 = no MFMAs, 2 = no LDS-DMA in the loop, 4 = no fragment reads
-    int touch;                                           // warm L2 with the tile's operand lines at kernel start
 };
 
+template <int N> using IC = std::integral_constant<int, N>;
+
 // NB hypothesis blocks of MFMA work, NP LDS-DMA pieces (8 rows x 128 B each) per stage for this wave.
-template <int NB, int NP, bool PIPE>
+template <int NB, int NP>
 __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, const int n0, const int M, const int wave,
                                              const int lane, float *smem) {
     const int gb = wave & 3;                             // gate block of this wave
@@ -74,6 +79,7 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
     const int li = lane & 31, hf = lane >> 5;
     const int H = a.H, ld = a.ld;
     const int u0 = (n0 >> 2) + 8 * gb + 4 * hf;          // the lane's four hidden units
+    constexpr int NXG = 5 * NB;                          // loads of the epilogue operands: 4 table quads + 1 cell quad per block
 
     JLM_GT_T(0);
     // ---- index chains first, all of them together (two dependent round trips, not two per consumer):
@@ -106,27 +112,19 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
     }
 #pragma unroll
     for (int i = 0; i < NP - 2; ++i) pp[i] = a.prev[pp[i]];
-
+    // the indices are "used" here, before the first LDS-DMA goes out: with pieces in flight hipcc waits vmcnt(0) at the
+    // first use of an ordinary load's result, and the first use of ew / ep is the request of the epilogue operands in the
+    // middle of the mainloop -- it would drain the ring there.  They arrive with pp (same round trip), which the source
+    // addresses below need anyway.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        asm volatile("" : "+v"(ew[nb]));
+        asm volatile("" : "+v"(ep[nb]));
+    }
 #ifdef JLM_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     JLM_GT_T(1);
 #endif
-    // ---- table rows (= accumulator start values) and old cell state: two more round trips, hidden under the ring's fill
-    f32x16 acc[NB];
-    f32x4 cp[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const float *xr = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * gb + 4 * hf;
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 8 * gate);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[nb][4 * gate + e] = v[e];      // rows past M: never stored, left unmasked
-        }
-        const int p = ep[nb];
-        cp[nb] = *reinterpret_cast<const f32x4 *>(a.c_in + (size_t)(p >= 0 ? p : 0) * ld + u0);    // masked in the epilogue
-        if (!eok[nb]) eg[nb] = -1;
-    }
 
     // ---- LDS-DMA pieces of this wave: 2 of the gate matrix, NP - 2 of the gathered state rows.
     //      lane = (row lane >> 3 of the piece's 8 rows, 16-byte slot lane & 7); the source granule is
@@ -153,24 +151,6 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
             dst[i] = (GT_BN + prow[i - 2]) * 32;
         }
     }
-    // ---- L2 warm-up: every 128-byte line of the rows this wave will stage, requested NOW (one dword per line and lane,
-    //      results never read).  A third of the tile's lines miss the XCD's L2 (state rows written by other XCDs, the gate
-    //      matrix evicted by the vocabulary kernel) and come over the fabric in 2-4 us; the vmcnt counter is in order, so
-    //      in the ring a single late piece holds up the k-step.  All misses in flight at once at the start, the ring then
-    //      streams from L2.  Hidden from hipcc (inline asm): it would wait for these loads; the destination registers stay
-    //      reserved until the first stage's wait below, which (in order) is behind them.
-    int warm = 0;
-    if (a.touch) {
-        const int lines = H / 32;                        // 128-byte lines per row
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = (i < 2 ? 8 * (2 * wave + i) : prow[i - 2]) + lrow;
-            const char *rowp = src[i] - (lslot ^ ((row >> 1) & 7)) * 16;
-            if (inc[i])                                  // (not the zero page)
-                for (int l = lslot; l < lines; l += 8)
-                    asm volatile("global_load_dword %0, %1, off" : "+v"(warm) : "v"(rowp + l * 128) : "memory");
-        }
-    }
     auto issue = [&](int stg) {
         float *base = smem + stg * GT_STAGE_FLOATS;
 #pragma unroll
@@ -178,6 +158,34 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
             GLDS16(src[i], base + dst[i]);
             src[i] += inc[i];
         }
+    };
+
+    // epilogue operands: the word's table row (the four gates of the lane's four units) and the old cell state.
+    // Requested by INLINE-ASM loads, hidden from hipcc: in front of a load it can see, with LDS-DMA pieces in flight, it
+    // drains the queue (s_waitcnt vmcnt(0) before the load is even issued).  The destinations are plain asm outputs:
+    // nothing reads them until the asm wait in front of the epilogue, which takes every one of them as an in/out operand.
+    f32x4 xg[NB][4], cp[NB];
+    const float *xrp[NB], *cpp[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        xrp[nb] = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * gb + 4 * hf;
+        cpp[nb] = a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+    }
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                         "global_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\t"
+                         "global_load_dwordx4 %3, %4, off offset:96"
+                         : "=&v"(xg[nb][0]), "=&v"(xg[nb][1]), "=&v"(xg[nb][2]), "=&v"(xg[nb][3]) : "v"(xrp[nb]) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cp[nb]) : "v"(cpp[nb]) : "memory");    // masked in the epilogue
+        }
+    };
+    auto wait_epilogue_operands = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xg[nb][0]), "+v"(xg[nb][1]), "+v"(xg[nb][2]), "+v"(xg[nb][3]), "+v"(cp[nb])::"memory");
     };
 
     // fragment offsets (floats) inside a stage: granule (4 step + 2 half + plane) of row li, swizzled
@@ -189,185 +197,119 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
     const int w_off = gb * 32 * 32;                      // this wave's gate block inside the stage
     const int h_off = (GT_BN + hb0 * 32) * 32;           // its first hypothesis block
 
-    const int nk = H / 32;
-    // The ring's first stages, and the first use of the table rows / old cell state in STRAIGHT-LINE code: here hipcc counts
-    // the younger LDS-DMA pieces behind them (s_waitcnt vmcnt(pieces)); left to the loop it cannot tell on the back edge
-    // whether they are still pending and puts vmcnt(0) in front of the MFMAs of every k-step, draining the ring.  The counter
-    // is in order, so this waits for nothing the first stage's own wait would not wait for.
-    constexpr int NPRE = PIPE ? GT_STAGES : GT_STAGES - 1;
-    if (nk >= NPRE) {
+    f32x16 acc[NB];
 #pragma unroll
-        for (int q = 0; q < NPRE; ++q) issue(q);
-    } else {
-        for (int q = 0; q < nk; ++q) issue(q);
-    }
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        asm volatile("" : "+v"(acc[nb]));
-        asm volatile("" : "+v"(cp[nb]));
-    }
-#ifdef JLM_PROFILE
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-    JLM_GT_T(2);
-#endif
-    if constexpr (!PIPE) {
-        int stg = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // stage kt has landed (this wave's pieces; the barrier makes it everybody's); stages kt+1, kt+2 stay in flight
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
-            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            // everybody has finished reading stage kt-1: its slot takes stage kt+3
-#ifdef JLM_PROFILE
-            if (kt + GT_STAGES - 1 < nk && !(a.ablate & 2)) issue(stg == 0 ? GT_STAGES - 1 : stg - 1);
-#else
-            if (kt + GT_STAGES - 1 < nk) issue(stg == 0 ? GT_STAGES - 1 : stg - 1);
-#endif
-            const float *ws = smem + stg * GT_STAGE_FLOATS + w_off;
-            const float *hs = smem + stg * GT_STAGE_FLOATS + h_off;
-            f16x8 aw[2][2], bh[2][NB][2];
-#ifdef JLM_PROFILE
-            if (a.ablate & 4) {
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    struct Frag { f16x8 aw[2]; f16x8 bh[NB][2]; };
+    auto read_half = [&](int stage, int st, Frag &f) {
+        const float *ws = smem + (stage & 3) * GT_STAGE_FLOATS + w_off;
+        const float *hs = smem + (stage & 3) * GT_STAGE_FLOATS + h_off;
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
+        for (int p = 0; p < 2; ++p) {
+            f.aw[p] = *reinterpret_cast<const f16x8 *>(ws + goff[st][p]);
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        aw[st][p] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) bh[st][nb][p] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
-                    }
-            } else
-#endif
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    aw[st][p] = *reinterpret_cast<const f16x8 *>(ws + goff[st][p]);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bh[st][nb][p] = *reinterpret_cast<const f16x8 *>(hs + nb * 1024 + goff[st][p]);
-                }
-            __builtin_amdgcn_sched_barrier(0);           // all fragment reads of the k-step in flight before the first MFMA
-#ifdef JLM_PROFILE
-            if (a.ablate & 1) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        asm volatile("" ::"v"(aw[st][p]));
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(bh[st][nb][p]));
-                    }
-            } else
-#endif
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int pr = 0; pr < 3; ++pr)           // lo.hi, hi.lo, hi.hi; blocks inner: no two consecutive MFMAs share an accumulator
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[st][pr == 0 ? 1 : 0], bh[st][nb][pr == 1 ? 1 : 0],
-                                                                         acc[nb], 0, 0, 0);
-            stg = stg == GT_STAGES - 1 ? 0 : stg + 1;
+            for (int nb = 0; nb < NB; ++nb) f.bh[nb][p] = *reinterpret_cast<const f16x8 *>(hs + nb * 1024 + goff[st][p]);
         }
-    } else {
-        // Software pipeline at HALF k-step granularity (one 16-value MFMA step = 3 NB MFMAs), fragments double-buffered in
-        // registers (2 x (2 + 2 NB) x 4 VGPRs):
-        //   k-step kt:   read(kt, step 1) -> B ; MFMAs(kt, step 0) from A ; [B has returned]
-        //                wait(stage kt+1 landed) ; barrier ; [request stage kt+4 into the slot of stage kt]
-        //                read(kt+1, step 0) -> A ; MFMAs(kt, step 1) from B ; [A has returned] ; [request stage kt+4]
-        // Fragment reads and LDS-DMA issue run under MFMAs instead of in front of them, and three stages (108 KB per CU)
-        // are in flight across the barrier.  Every wave has its reads of stage kt back before it arrives at the barrier of
-        // k-step kt, so the slot is free behind it.  The two waves of a SIMD are staggered: waves 0-3 (9 MFMAs per half
-        // step) request right after the barrier, waves 4-7 (6 MFMAs) after their MFMAs, so one is on the matrix pipe while
-        // the other pays the DMA issue cost.
-        constexpr bool DMA_FIRST = (NP == 4);
-        struct Frag { f16x8 aw[2]; f16x8 bh[NB][2]; };
-        auto read_half = [&](int stage, int st, Frag &f) {
-            const float *ws = smem + (stage & 3) * GT_STAGE_FLOATS + w_off;
-            const float *hs = smem + (stage & 3) * GT_STAGE_FLOATS + h_off;
+    };
+    auto mfmas = [&](const Frag &f) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                f.aw[p] = *reinterpret_cast<const f16x8 *>(ws + goff[st][p]);
+        for (int pr = 0; pr < 3; ++pr)                   // lo.hi, hi.lo, hi.hi; blocks inner: no two consecutive MFMAs share an accumulator
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) f.bh[nb][p] = *reinterpret_cast<const f16x8 *>(hs + nb * 1024 + goff[st][p]);
-            }
-        };
-        auto mfmas = [&](const Frag &f) {
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.aw[pr == 0 ? 1 : 0], f.bh[nb][pr == 1 ? 1 : 0], acc[nb], 0, 0, 0);
+    };
+    auto touch = [&](Frag &f) {
+        // "use" the fragments HERE: hipcc puts the wait for a ds_read in front of its first use and merges the pending
+        // state of all paths into a block, so without this it waits lgkmcnt(0) in front of the next MFMA group -- right
+        // after that group's own reads were issued.  Behind the MFMAs the reads have long returned.
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr)               // lo.hi, hi.lo, hi.hi; blocks inner: no two consecutive MFMAs share an accumulator
+        for (int p = 0; p < 2; ++p) {
+            asm volatile("" : "+v"(f.aw[p]));
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.aw[pr == 0 ? 1 : 0], f.bh[nb][pr == 1 ? 1 : 0], acc[nb], 0, 0, 0);
-        };
-        auto touch = [&](Frag &f) {
-            // "use" the fragments HERE: hipcc puts the wait for a ds_read in front of its first use and merges the pending
-            // state of all paths into a block, so without this it waits lgkmcnt(0) in front of the next MFMA group -- right
-            // after that group's own reads were issued.  Behind the MFMAs the reads have long returned.
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(f.bh[nb][p]));
+        }
+    };
+    // One k-step of the software pipeline (fa holds step 0 of stage kt on entry):
+    //     read(kt, step 1) -> fb ; MFMAs(kt, step 0) from fa ; [fb has returned]
+    //     wait(stage kt+1 landed, VM younger operations may stay in flight) ; barrier ; [request stage kt+4 into the slot of stage kt]
+    //     read(kt+1, step 0) -> fa ; MFMAs(kt, step 1) from fb ; [request stage kt+4] ; [fa has returned]
+    // Every wave has its reads of stage kt back before it arrives at the barrier of k-step kt, so the slot is free behind
+    // it.  The two waves of a SIMD are staggered: waves 0-3 (9 MFMAs per half step) request right after the barrier,
+    // waves 4-7 (6 MFMAs) after their MFMAs, so one is on the matrix pipe while the other pays the DMA issue cost.
+    constexpr bool DMA_FIRST = (NP == 4);
+    Frag fa, fb;
+    auto kstep = [&](auto has_next, auto vm, auto do_issue, int kt) {
+        read_half(kt, 1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        touch(fb);
+        if constexpr (decltype(has_next)::value) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(decltype(vm)::value) : "memory");
+            if constexpr (DMA_FIRST && decltype(do_issue)::value) issue(kt & 3);
+            read_half(kt + 1, 0, fa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fb);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!DMA_FIRST && decltype(do_issue)::value) issue(kt & 3);
+        if constexpr (decltype(has_next)::value) touch(fa);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    const int nk = H / 32;
+    if (nk >= GT_STAGES) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                asm volatile("" : "+v"(f.aw[p]));
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(f.bh[nb][p]));
-            }
-        };
-        auto wait_barrier = [&](int stages_in_flight) {  // stages allowed to stay in flight behind the one waited for
-            switch (stages_in_flight) {
-                case 3: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NP) : "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
-            }
-        };
-        Frag fa, fb;
-        wait_barrier(nk > 3 ? 3 : nk - 1);
+        for (int q = 0; q < GT_STAGES; ++q) issue(q);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NP) : "memory");
+        JLM_GT_T(2);
         read_half(0, 0, fa);
         touch(fa);
         int kt = 0;
-        for (; kt + 4 < nk; ++kt) {                      // steady state: stages kt+1 .. kt+4 exist
+        for (; kt + 4 < nk; ++kt) kstep(T{}, IC<2 * NP>{}, T{}, kt);       // steady state: stages kt+1 .. kt+4 exist
+        JLM_GT_T(5);
+        // the last four k-steps: nothing left to request for the ring; the epilogue's operands go out now, younger than
+        // the two stages still in flight, so the waits below let them (NXG loads) stay in flight as well
+        load_epilogue_operands();
+        kstep(T{}, IC<2 * NP + NXG>{}, F{}, kt);
+        kstep(T{}, IC<NP + NXG>{}, F{}, kt + 1);
+        kstep(T{}, IC<NXG>{}, F{}, kt + 2);
+        kstep(F{}, IC<0>{}, F{}, kt + 3);
+    } else {
+        // short contractions (H < 128): everything requested up front, plain waits
+        load_epilogue_operands();
+        for (int q = 0; q < nk; ++q) issue(q);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        JLM_GT_T(2);
+        read_half(0, 0, fa);
+        touch(fa);
+        JLM_GT_T(5);
+        for (int kt = 0; kt < nk; ++kt) {
             read_half(kt, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
             mfmas(fa);
-            __builtin_amdgcn_sched_barrier(0);
-            touch(fb);
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
-            if (DMA_FIRST) issue(kt & 3);
-            read_half(kt + 1, 0, fa);
-            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) read_half(kt + 1, 0, fa);
             mfmas(fb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!DMA_FIRST) issue(kt & 3);
-            touch(fa);
-        }
-        for (; kt < nk; ++kt) {                          // the last (up to) four k-steps: nothing left to request
-            read_half(kt, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(fa);
-            __builtin_amdgcn_sched_barrier(0);
-            touch(fb);
-            if (kt + 1 < nk) {
-                wait_barrier(nk - 2 - kt < 2 ? nk - 2 - kt : 2);
-                read_half(kt + 1, 0, fa);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(fb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) touch(fa);
         }
     }
-    asm volatile("" ::"v"(warm));                        // (the warm-up loads' destination stays reserved up to here)
     JLM_GT_T(3);
+    wait_epilogue_operands();
 
-    // ---- cell update in registers: acc[4 gate + e] = pre-activation of gate `gate`, unit u0 + e, hypothesis li
+    // ---- cell update in registers: acc[4 gate + e] + table = pre-activation (x 1 / descale) of gate `gate`, unit u0 + e,
+    //      hypothesis li
     const float ds = a.descale;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int g = eg[nb];
+        const int g = eok[nb] ? eg[nb] : -1;
         if (g < 0) continue;
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid(acc[nb][e] * ds), gf = jlm_sigmoid(acc[nb][4 + e] * ds);
-            const float go = jlm_sigmoid(acc[nb][8 + e] * ds), gg = jlm_tanh(acc[nb][12 + e] * ds);
+            const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
+            const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
             cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
             hn[e] = jlm_tanh(cn[e]) * go;
         }
@@ -386,7 +328,6 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
 #endif
 }
 
-template <bool PIPE>
 __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware tile order (block b runs on XCD b % 8, observed; speed only): when the gate tiles divide over the 8
@@ -407,8 +348,8 @@ __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
     if (m0 >= M) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (wave < 4) gate_xg_body<3, 4, PIPE>(a, m0, n0, M, wave, lane, smem);
-    else gate_xg_body<2, 5, PIPE>(a, m0, n0, M, wave, lane, smem);
+    if (wave < 4) gate_xg_body<3, 4>(a, m0, n0, M, wave, lane, smem);
+    else gate_xg_body<2, 5>(a, m0, n0, M, wave, lane, smem);
 }
 
 }  // namespace
@@ -419,14 +360,10 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     if (H <= 0 || H % 32 != 0 || ld_state % 16 != 0 || ld_state < H) return -1;
     if (n_rows_max <= 0) return 0;
     static bool attr_done = false;
-    static int pipe = 0, touch = 1;
     if (!attr_done) {
-        for (const void *k : {reinterpret_cast<const void *>(gate_xg_kernel<false>), reinterpret_cast<const void *>(gate_xg_kernel<true>)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-        }
-        if (const char *e = getenv("JLM_GATE_PIPE")) pipe = atoi(e);      // developer A/B switches (tools/kbench.py)
-        if (const char *e = getenv("JLM_GATE_TOUCH")) touch = atoi(e);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gate_xg_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     GateXgArgs a;
@@ -436,13 +373,7 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     a.nrows = n_rows_max; a.ndev = n_dev;
     a.tiles_m = (n_rows_max + GT_BM - 1) / GT_BM;
     a.tiles_n = 4 * H / GT_BN;
-    a.touch = touch;
-    a.ablate = 0;
-#ifdef JLM_PROFILE
-    if (const char *e = getenv("JLM_GATE_ABLATE")) a.ablate = atoi(e);
-#endif
-    if (pipe) hipLaunchKernelGGL(gate_xg_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(512), GT_LDS_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gate_xg_kernel<false>, dim3(a.tiles_m * a.tiles_n), dim3(512), GT_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gate_xg_kernel, dim3(a.tiles_m * a.tiles_n), dim3(512), GT_LDS_BYTES, (hipStream_t)stream, a);
     JLM_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,13 @@ plus ``decode_batch(list_of_inputs, ...)`` (the reference decodes one sentence
 at a time; batching sentences is what fills the GPU).  ``decode`` is
 ``decode_batch`` of one sentence.
 
+``perf_timing`` (default False): with True every frame is bracketed by HIP events
+(per-call lists ``perf_log_lstm`` / ``perf_log_softmax`` as the reference fills
+them, decoder.py:206-218) and the launches are enqueued one by one from Python on
+one stream; the default keeps the native frame loop and the two alternating
+streams.  ``jlm_amd.eval`` and the ``compat/`` shims for the reference's
+``eval.py`` (which prints those lists) switch it on.
+
 Deliberate differences (DESIGN.md "Reference quirks"):
   * ``beam_width=None`` (no pruning, exponential) is rejected;
   * a stale ``lattice_vocab`` from an earlier ``vocab_select=True`` call is not
@@ -68,7 +75,7 @@ class Decoder():
         self.perf_sen = 0
         self.perf_log_lstm = []
         self.perf_log_softmax = []
-        self.perf_timing = True          # per-frame HIP-event timings into perf_log_* (eval.py reads them)
+        self.perf_timing = False         # True: per-frame HIP-event timings into perf_log_* (eval.py reads them), slower path
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
         self._pool = None                # worker threads that build the lattices of upcoming chunks
@@ -111,10 +118,17 @@ class Decoder():
         if not 1 <= int(beam_width) <= 64:
             raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
         inputs = list(inputs)
-        if any(len(x) == 0 for x in inputs):
-            raise ValueError("empty input string")
         if not inputs:
             return []
+        if any(len(x) == 0 for x in inputs):
+            # the reference's loop over an empty input leaves the <eos> path alone: [(0.0, [])] (decoder.py:220-241)
+            keep = [i for i, x in enumerate(inputs) if len(x)]
+            sub = self.decode_batch([inputs[i] for i in keep], topN, beam_width, vocab_select, samples, top_sampling,
+                                    random_sampling) if keep else []
+            out = [[(0.0, [])] for _ in inputs]
+            for i, r in zip(keep, sub):
+                out[i] = r
+            return out
         def prepare(i):
             """host side of chunk i: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
@@ -173,8 +187,10 @@ class Decoder():
     def decode(self, input, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
                random_sampling=False):
         out = self.decode_batch([input], topN, beam_width, vocab_select, samples, top_sampling, random_sampling)[0]
-        self.backward_lookup = self.last_lattice.backward_lookup(0)
-        self.perf_sen += 0
+        if len(input):
+            # the reference's shape: dict frame -> [Node] (decoder.py:79-135), what _build_lattice returns
+            self.backward_lookup = {f: [Node(st, ln, w, word) for (st, ln, w, word) in nodes]
+                                    for f, nodes in enumerate(self.last_lattice.backward_lookup(0))}
         return out
 
 

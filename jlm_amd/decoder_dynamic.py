@@ -37,20 +37,27 @@ class DynamicDecoder(Decoder):
         if not vocab_select:
             raise TypeError("'NoneType' object is not subscriptable")      # decoder_dynamic.py:114
         inputs = list(inputs)
-        if any(len(x) == 0 for x in inputs):
-            raise ValueError("empty input string")
         if not inputs:
             return []
+        if any(len(x) == 0 for x in inputs):
+            keep = [i for i, x in enumerate(inputs) if len(x)]
+            sub = self.decode_batch([inputs[i] for i in keep], topN, beam_width, vocab_select, samples, top_sampling,
+                                    random_sampling) if keep else []
+            res = [[(0.0, [])] for _ in inputs]
+            for i, r in zip(keep, sub):
+                res[i] = r
+            return res
         out, inflight = [], deque()
 
         def finish(ticket):
             out.extend(self._engine.collect(ticket))
             self._log_perf()
-            # the vocabulary fix-up and the path re-scoring are fused into the frame's
-            # kernels; their cost is inside perf_log_softmax.  eval.py takes np.mean of these.
-            n = len(self._engine.last_timing or [])
-            self.perf_log_fix_vocab.extend([0.0] * max(n, 1))
-            self.perf_log_fix_lattice_path_prob.extend([0.0] * max(n, 1))
+            # perf_timing: HIP events around the merge of a frame's new words into the older rows (the reference's
+            # "vocab fix", decoder_dynamic.py:112-148) and around the re-scoring beam step ("lattice path fix", :150-175)
+            if self.perf_timing and self._engine.last_fix_timing:
+                for t_vocab, t_path in self._engine.last_fix_timing:
+                    self.perf_log_fix_vocab.append(t_vocab)
+                    self.perf_log_fix_lattice_path_prob.append(t_path)
 
         def prepare(i):
             lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)

@@ -175,6 +175,7 @@ class DecodeEngine:
         self.torch = dev_model.torch
         self.device = dev_model.device
         self.last_timing = None
+        self.last_fix_timing = None     # dynamic decoder under timing: (vocab fix, path fix) seconds per frame
         self.last_state = None
         self.recorder = None            # optional model.KernelRecorder (bench.py): forces eager launches
         self.last_n_live = None
@@ -264,6 +265,7 @@ class DecodeEngine:
         p.cnt.zero_()
         p.n_live.zero_()
         ev = []
+        self._fix_ev = []
         join = None
         pending_parts = 0
         wl_split = getattr(m, "split_array", None) is not None and nsegs == 1 and beam <= 32
@@ -288,6 +290,9 @@ class DecodeEngine:
             if join is not None:
                 main.wait_event(join)
                 join = None
+            if timing and dynamic:
+                f0, f1, f2 = (_Stamp(torch, self.device) for _ in range(3))
+                f0.record()
             if dynamic and not self_norm and f >= 2:
                 # K11: older frames learn the words that first appear at frame f
                 r = -2
@@ -304,7 +309,12 @@ class DecodeEngine:
             # the full-vocabulary normaliser of frame f-1 left partial slices: beam_step folds them itself
             p.stS.lse_part = p.part.data_ptr() if pending_parts else None
             p.stS.ld_part, p.stS.n_parts = rmax, pending_parts
+            if timing and dynamic:
+                f1.record()
             _lib.check(L.jlm_beam_step(p.latS, p.stS, f, mode, cands, st), "jlm_beam_step")
+            if timing and dynamic:
+                f2.record()
+                self._fix_ev.append((f0, f1, f2))
             pending_parts = 0
             if f == F - 1:
                 break
@@ -434,17 +444,18 @@ class DecodeEngine:
         if self.device.type == "cuda":
             done = torch.cuda.Event()
             done.record()
-        return (p, lat, topN, ev, timing, done)
+        return (p, lat, topN, ev, timing, done, list(getattr(self, "_fix_ev", [])) if timing else [])
 
     def collect(self, ticket):
         """Wait for a submitted batch and build its n-best lists."""
-        p, lat, topN, ev, timing, done = ticket
+        p, lat, topN, ev, timing, done, fix_ev = ticket
         if done is not None:
             done.synchronize()
         if self.recorder is not None:
             self.last_n_live = p.h_nlive.numpy()[:p.latS.n_frames].copy()
         if timing:
             self.last_timing = [(a.seconds_to(b), b.seconds_to(c2)) for a, b, c2 in ev]
+            self.last_fix_timing = [(a.seconds_to(b), b.seconds_to(c2)) for a, b, c2 in fix_ev]
         self.last_state = p
         out = self._read_out(lat, p.h_nodes.numpy(), p.h_len.numpy(), p.h_score.numpy(), topN)
         p.busy = False

@@ -63,6 +63,8 @@ class Evaluator:
         self.vocab = Vocab(self.config['vocab_size'])
         self.w2i = self.vocab.w2i
         self.decoder = self._make_decoder()
+        if hasattr(self.decoder, "perf_timing"):
+            self.decoder.perf_timing = True       # the log's per-step times (eval.py:104-121) need the per-frame events
 
     def _make_decoder(self):
         a = self.args                 # selection order of eval.py:41-48
@@ -127,8 +129,9 @@ class Evaluator:
                 print(ln)
             if a.dynamic_decoding and not a.use_ngram:
                 d = self.decoder
-                print("--- %f seconds per step for vocab fix.---" % np.mean(d.perf_log_fix_vocab))
-                print("--- %f seconds per step for lattice path fix.---" % np.mean(d.perf_log_fix_lattice_path_prob))
+                fix = lambda v: ("%f" % np.mean(v)) if len(v) else "n/a"
+                print("--- %s seconds per step for vocab fix.---" % fix(d.perf_log_fix_vocab))
+                print("--- %s seconds per step for lattice path fix.---" % fix(d.perf_log_fix_lattice_path_prob))
             print("--- %s seconds ---" % (time.time() - t_start))
         return best, nbest_hits
 

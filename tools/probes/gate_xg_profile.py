@@ -20,8 +20,14 @@ assert L.jlm_pack_split_f16(hf.data_ptr(), G, H, H, 2.0 ** 14, h.data_ptr(), H, 
 assert L.jlm_pack_split_f16(wtf.data_ptr(), 4 * H, H, H, 2.0 ** 6, wt.data_ptr(), H, None) == 0
 xg = rnd(V, 4 * H, scale=2.0 ** 20)
 rows = (torch.arange(R, device=dev, dtype=torch.int32) + 2 * R).contiguous()
-prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
 word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
+prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
+mode = os.environ.get("GATE_PREV", "random")
+if mode == "hot":          # every tile gathers the same 160 state rows, one table row, one cell row: everything L2-resident
+    prev = (torch.arange(G, device=dev, dtype=torch.int32) % 160).contiguous()
+    word = torch.zeros(G, device=dev, dtype=torch.int32)
+elif mode == "ident":      # contiguous state rows instead of a gather
+    prev = (torch.arange(G, device=dev, dtype=torch.int32) - 2 * R).clamp(min=0).contiguous()
 nd = torch.tensor([R], device=dev, dtype=torch.int32)
 f = lambda: L.jlm_lstm_step_xg(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
                                word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, R, nd.data_ptr(), None)
@@ -48,3 +54,7 @@ for w, name in ((0, "wave 0 (3 blocks, requests first)"), (1, "wave 4 (2 blocks,
     for i, nm in enumerate(("index chains", "table rows + DMA prologue -> first stage landed", "main loop", "epilogue (incl. stores landed)")):
         print("   %-48s mean %6.2f  p10 %6.2f  p90 %6.2f us" % (nm, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
     print("   end            mean %6.2f  max %6.2f us" % (x[:, 4].mean(), x[:, 4].max()))
+    if a[:, w, 5].max() > 0:
+        st = (a[:, w, 5] - a[:, w, 2]) / 100.0
+        print("   of the main loop: steady-state k-steps (all but the last 4) %6.2f us, the last 4 %6.2f us" % (
+            st.mean(), (d[:, 2] - st).mean()))
