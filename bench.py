@@ -1,27 +1,34 @@
 #!/usr/bin/env python
-"""Headline benchmark: decoded kana chars/sec of the batched lattice decode.
+"""Headline benchmark: decoded kana chars/sec of the batched lattice decode (SURVEY.md 8d).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: BASELINE.json configs[1]
-(LSTM h=512, D-softmax* segs (200,100,50) over V=50k, beam=10, 256 synthetic
-20-kana sentences) per GPU; sentences shard across ranks with no collective on
-the data path (weak scaling: every rank decodes its own 256 sentences).  The
-timed region starts with the batch's lattice (CSR) and the weights resident in
-HBM and ends when the n-best back-pointer traces are back on the host; K steps
-are bracketed by barrier + synchronize on both sides and the MAX over ranks is
-reported.  The host-inclusive rate (lattice build from the kana strings, upload,
-string read-out) is reported beside it as "end_to_end_chars_per_s".
+--config 2 (default; BASELINE.json configs[1], the configuration the metric is quoted on for one GPU):
+    LSTM h=512, D-softmax* segs (200,100,50) over V=50k, beam=10, 256 synthetic 20-kana sentences per GPU.
+    A "step" is one pass of the hot path over one such batch, strings in -> n-best strings out:
+    `value` = kana characters / wall time from the first lattice build to the last n-best string
+    (SURVEY.md 8d), through the product entry point `Decoder.decode_batch`, K batches pipelined as the
+    product pipelines its chunks (native lattice build + upload of batch i+1 and string read-out of batch
+    i-1 run while the GPU decodes batch i).  Weights and lexicon are resident before the clock starts; the
+    kana strings are the only input.  Every rank decodes its own 256 sentences (weak scaling, no collective
+    on the data path); K steps are bracketed by barrier + synchronize and the MAX over ranks is reported.
+    The rate with the batch's lattice already resident in HBM is reported beside it
+    (`device_resident_chars_per_s`), and BASELINE configs[4] (below) runs as an extra leg (`config5`).
+
+--config 5 (BASELINE.json configs[4]): ONE seeded set of 8 192 tied-softmax V=50k 20-kana sentences at beam 10,
+    dealt over the ranks by jlm_amd.shard.decode_sharded (length-sorted round robin, no data-path collective):
+    strong scaling, 8 192 / N sentences per GPU in chunks of 1 024.  A step is one pass over the whole set.
 
 One JSON line on rank 0 (contract in the task statement) plus
-  roofline     : dominant kernel (fused vocabulary-projection/log-sum-exp GEMM,
-                 split-f16 MFMA x3) -- algorithmic FLOPs / live HIP-event duration
-  gate_gemm    : the same for the fused LSTM gate GEMM (BASELINE metric, part 2)
-  cpu_baseline : the numpy oracle (a port of the reference path) timed on this
-                 node's host cores on a bounded sample of the same workload
+  roofline     : dominant kernel (fused vocabulary-projection / log-sum-exp, split-f16 MFMA x3):
+                 algorithmic FLOPs / live HIP-event duration on the launching stream
+  gate_gemm    : the fused LSTM step (BASELINE metric, part 2): EXECUTED MFMA FLOPs / dense f16 peak
+  cpu_baseline : the numpy oracle (a port of the reference path) timed on this node's host cores on a
+                 bounded sample of the same workload (rank 0, N = 1)
 """
 import argparse
+import hashlib
 import json
 from collections import deque
 import os
@@ -35,6 +42,16 @@ sys.path.insert(0, REPO)
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2516.6       # v_mfma_f32_32x32x16_f16, dense: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
 SPLIT_PASSES = 3                    # f16x3: hi.hi + hi.lo + lo.hi per f32-grade product
+CONFIG5_SENTENCES = 8192
+
+
+def kernel_source_sha256():
+    """Identity of the kernels the committed PMC traffic figure was measured on (profiles/traffic_latest.json)."""
+    h = hashlib.sha256()
+    for f in ("jlm_split.hip", "jlm_common.h"):
+        with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def main():
@@ -42,18 +59,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="2 = BASELINE configs[1] (headline, weak scaling); 5 = BASELINE configs[4] (8 192 sentences sharded, strong scaling)")
+    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU per step (config 2)")
     ap.add_argument("--length", type=int, default=20, help="kana per sentence")
     ap.add_argument("--beam", type=int, default=10)
-    ap.add_argument("--fixture", default="mid-vtable", help="mid-vtable (configs[1]) | mid-tied | big-tied")
+    ap.add_argument("--fixture", default=None, help="mid-vtable (configs[1]) | mid-tied | big-tied; default by --config")
     ap.add_argument("--cpu-sentences", type=int, default=32, help="bounded CPU-baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--end-to-end", action="store_true", help="time the host-inclusive path as the step")
+    ap.add_argument("--no-config5", action="store_true", help="config 2 only: skip the extra configs[4] leg")
+    ap.add_argument("--config5-passes", type=int, default=3)
     ap.add_argument("--decoder", default="static", choices=["static", "static-vs", "dynamic"],
                     help="static = Decoder full vocabulary (headline); static-vs = vocab_select; dynamic = DynamicDecoder (configs[3])")
     # debugging the N > 1 control flow on a one-GPU box: every rank on device 0, control-plane collectives over gloo
     ap.add_argument("--debug-shared-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.fixture is None:
+        args.fixture = "mid-vtable" if args.config == 2 else "mid-tied"
 
     import numpy as np
     import torch
@@ -78,204 +100,250 @@ def main():
         torch.cuda.set_device(0)
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
 
-    from jlm_amd import config as jconfig, synth
+    from jlm_amd import config as jconfig, shard, synth
     from jlm_amd.decoder import Decoder
     from jlm_amd.decoder_dynamic import DynamicDecoder
     from jlm_amd.lattice import BatchLattice
     from jlm_amd.model import KernelRecorder
-
-    root = os.path.join(tempfile.gettempdir(), "jlm_bench_%d_%s_r%d" % (os.getuid(), args.fixture, rank))
-    cfg, _lex, _rd, alphabet = synth.build_fixture(root, args.fixture)
-    jconfig.set_root(root)
-    dec = DynamicDecoder(1) if args.decoder == "dynamic" else Decoder(1)
-    dec.perf_timing = False
-    dkw = dict(vocab_select=True) if args.decoder != "static" else {}
-    eng, m = dec._engine, dec.model.dev
-    # every rank decodes its own sentences (seeded by rank): sentence sharding, no data-path collective
-    sents = synth.make_sentences(args.batch, args.length, seed=4242 + rank, alphabet=alphabet)
-    chars_per_step = sum(len(s) for s in sents)
-
-    def host_step():
-        return dec.decode_batch(sents, beam_width=args.beam, **dkw)
-
-    lat = BatchLattice(dec._builder, sents, args.beam)
-    ekind, ekw = "static", {}
-    if args.decoder == "static-vs":
-        w_, o_, _l = lat.static_vocab()
-        ekw = dict(vocab=(w_, o_))
-    elif args.decoder == "dynamic":
-        ekind, ekw = "dynamic", dict(dyn_lists=lat.dynamic_vocab()[:4])
-
-    def device_step():
-        return eng.decode(lat, ekind, topN=10, **ekw)
-
-    step = host_step if args.end_to_end else device_step
-
-    def run_steps(n):
-        """n steps; in device mode the host read-out of step i overlaps the GPU work of step i+1."""
-        if args.end_to_end:
-            for _ in range(n):
-                host_step()
-            return
-        inflight = deque()                 # two steps in flight, as Decoder.decode_batch keeps its chunks
-        for _ in range(n):
-            inflight.append(eng.submit(lat, ekind, topN=10, **ekw))
-            if len(inflight) > dec.pipeline_depth:
-                eng.collect(inflight.popleft())
-        while inflight:
-            eng.collect(inflight.popleft())
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: the requested warm-up steps, and at least 12 decode calls in total (plans for both
-    # streams and both pipeline slots exist before the clock starts)
-    for _ in range(args.warmup):
-        step()
-    run_steps(max(2, 12 - args.warmup))
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    # Per-kernel durations: the same steps once more with a HIP event pair around every GEMM launch
-    # (same kernels, same arguments, same stream; kept out of the throughput loop so that the event
-    # records do not perturb `value`).
-    rec = KernelRecorder(torch)
-    eng.recorder = rec
-    n_live_steps = []
-    barrier()
-    t0e = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        n_live_steps.append(eng.last_n_live)
-    barrier()
-    dt_eager = time.perf_counter() - t0e
-    eng.recorder = None
-    if dist is not None:
-        cdev = "cpu" if args.debug_shared_gpu else "cuda"
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+    def max_over_ranks(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], device="cpu" if args.debug_shared_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([float(chars_per_step)], device=cdev, dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_chars_per_step = float(c.item())
-    else:
-        total_chars_per_step = float(chars_per_step)
+        return float(t.item())
 
-    # host-inclusive rate (not `value`): kana strings in -> n-best strings out through the product
-    # entry point; decode_batch pipelines its chunks (native lattice build + upload of chunk i+1 and
-    # string read-out of chunk i-1 run while the GPU decodes chunk i)
-    e2e_steps = max(2, min(24, args.steps))
-    dec.max_batch = args.batch
-    dec.decode_batch(sents * 2, beam_width=args.beam, **dkw)
-    barrier()
-    t1 = time.perf_counter()
-    dec.decode_batch(sents * e2e_steps, beam_width=args.beam, **dkw)
-    barrier()
-    e2e = chars_per_step * e2e_steps / (time.perf_counter() - t1) * world
+    def sum_over_ranks(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], device="cpu" if args.debug_shared_gpu else "cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
-    # diagnostic (not `value`): does this box overlap the two batches in flight?  The same pipelined loop
-    # with one stream and with the engine's two; on most boxes 3.6 vs 2.6 ms, on some the two are equal
-    # (the queues of the two streams are not run side by side there) and `value` is the one-stream rate.
-    overlap = None
-    if not args.end_to_end and eng.n_streams >= 2:
-        def timed_ms(n):
-            barrier()
-            t = time.perf_counter()
-            run_steps(n)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n * 1e3
-        keep = eng.n_streams
-        two = timed_ms(12)
-        eng.n_streams = 1
-        run_steps(3)
-        one = timed_ms(12)
-        eng.n_streams = keep
-        eng._rr = 0
-        overlap = {"one_stream_ms_per_step": round(one, 3), "two_streams_ms_per_step": round(two, 3),
-                   "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
+    def make_decoder(fixture, kind):
+        root = os.path.join(tempfile.gettempdir(), "jlm_bench_%d_%s_r%d" % (os.getuid(), fixture, rank))
+        cfg, _lex, _rd, alphabet = synth.build_fixture(root, fixture)
+        jconfig.set_root(root)
+        dec = DynamicDecoder(1) if kind == "dynamic" else Decoder(1)
+        return root, cfg, alphabet, dec
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+    dkw = dict(vocab_select=True) if args.decoder != "static" else {}
 
-    # ---- per-kernel roofline from the live HIP-event brackets
-    durs = rec.durations_ms()
-    rows = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in n_live_steps])    # live rows per launch
-    H = m.H
+    # ------------------------------------------------------------------------------------------ config 5 leg
+    def run_config5(dec5, alphabet5, passes):
+        """BASELINE configs[4]: 8 192 sentences dealt over the ranks, strong scaling.  -> (seconds, chars, n_mine)"""
+        sents5 = synth.make_sentences(CONFIG5_SENTENCES, args.length, seed=5555, alphabet=alphabet5)   # the same set on every rank
+        dec5.max_batch = 1024
+        idx, _res = shard.decode_sharded(dec5, sents5, rank, world, beam_width=args.beam)             # untimed pass (plans, streams)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            idx, res = shard.decode_sharded(dec5, sents5, rank, world, beam_width=args.beam)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert len(res) == len(idx) and all(len(r) > 0 for r in res)
+        n_all = int(round(sum_over_ranks(float(len(idx)))))
+        assert n_all == CONFIG5_SENTENCES, "the shards must cover the whole set exactly once"
+        return dt, sum(len(s) for s in sents5), len(idx)
 
-    def kernel_stats(name, flops_per_row):
+    def kernel_stats(durs, rows, name, flops_per_row):
         d = np.asarray(durs.get(name, []), dtype=np.float64)
         if d.size == 0:
             return None
         n = min(d.size, rows.size)
         flops = float((rows[:n] * flops_per_row).sum())
         secs = float(d[:n].sum()) * 1e-3
-        return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12,
-                    flops_per_launch=flops / n)
+        return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12, flops_per_launch=flops / n)
 
-    gate = kernel_stats("gate_gemm", 2.0 * (H + m.E_in) * 4 * H)
-    vstat = kernel_stats("vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
-    if vstat and not m.stationary_ok:
-        # tile form: one launch per segment, rows repeat per segment
-        d = np.asarray(durs["vocab_lse"], dtype=np.float64)
-        per_frame = d[: (d.size // m.n_segs) * m.n_segs].reshape(-1, m.n_segs).sum(axis=1)
-        n = min(per_frame.size, rows.size)
-        fl = float((rows[:n] * m.flops_per_row_vocab).sum())
-        vstat = dict(launches=int(n * m.n_segs), avg_ms=float(d.mean()), tflops=fl / (per_frame[:n].sum() * 1e-3) / 1e12,
-                     flops_per_launch=fl / (n * m.n_segs))
-    roofline = None
-    if vstat:
+    def measure_kernels(dec, lat, ekind, ekw, steps):
+        """The same decode once more with a HIP event pair around every GEMM launch (same kernels, same arguments, on the
+        launching stream; kept out of the throughput loops so that the event records do not perturb them)."""
+        eng, m = dec._engine, dec.model.dev
+        rec = KernelRecorder(torch)
+        eng.recorder = rec
+        n_live = []
+        for _ in range(steps):
+            eng.decode(lat, ekind, topN=10, **ekw)
+            n_live.append(eng.last_n_live)
+        torch.cuda.synchronize()
+        eng.recorder = None
+        durs = rec.durations_ms()
+        rows = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in n_live])    # live rows per launch
+        H = m.H
         split = getattr(m, "split_array", None) is not None
-        kname = ("vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
-                 "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
-                 else "gemm_nt_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
-        traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-        if m.stationary_ok and args.fixture == "mid-vtable" and os.path.exists(tpath):
-            with open(tpath) as tf:
-                tj = json.load(tf)
-            if tj.get("kernel", "vocab_lse_stationary_kernel").split("(")[0].strip() in kname:
-                traffic, traffic_note = tj["vocab_lse_hbm_bytes_per_call"], tj["note"]
-        # split-f16 form: every algorithmic multiply-add is executed as 3 f16 MFMA passes, so the
-        # ceiling for ALGORITHMIC flops is the dense f16 peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if split else F32_MFMA_PEAK_TFLOPS
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(vstat["tflops"], 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(vstat["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                    "avg_launch_ms": round(vstat["avg_ms"], 4), "launches": vstat["launches"],
-                    "flops_per_launch": vstat["flops_per_launch"],
-                    "mfma_dtype": ("f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): peak = %.1f dense f16 / %d passes; "
-                                   "executed %.1f TFLOP/s" % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES, SPLIT_PASSES * vstat["tflops"])
-                                   if split else "f32 (v_mfma_f32_32x32x2_f32)"),
-                    "vs_f32_mfma_peak": round(vstat["tflops"] / F32_MFMA_PEAK_TFLOPS, 3),
-                    "measured": "HIP events around every launch of the dominant kernel, in a repeat of the timed steps"}
-    gate_obj = None
-    if gate:
         gsplit = getattr(m, "split_lstm", False)
-        gpeak = F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if gsplit else F32_MFMA_PEAK_TFLOPS
-        gate_obj = {"kernel": ("gemm_split_kernel<128x64,EpiGate> (jlm_lstm_step_split; input side x.W_x+b read from a per-word "
-                               "table, the MFMAs contract over the state only)" if gsplit
-                               else "gemm2_kernel<64x64,EpiGate> (jlm_lstm_step)"),
-                    "achieved": round(gate["tflops"], 2), "peak": round(gpeak, 1), "unit": "TFLOP/s",
-                    "flops_counted": "2*(H+E)*4H per row (the reference's step)",
-                    "mfma_util_pct": round(100.0 * gate["tflops"] / gpeak, 2),
-                    "avg_launch_ms": round(gate["avg_ms"], 4), "launches": gate["launches"]}
-        if gsplit:
-            # context for BASELINE.json's ">= 40 % on the gate GEMM": the f32-pipe kernel (JLM_PRECISION=f32) meets it
-            # (57 % of 157.3 TF, profiles/r01_d) and is 2.4x slower than this one, which the L2 -> LDS path bounds (DESIGN.md 4)
-            gate_obj["vs_f32_mfma_peak"] = round(gate["tflops"] / F32_MFMA_PEAK_TFLOPS, 3)
-            gate_obj["executed_f16_pct_of_dense_peak"] = round(
-                100.0 * gate["tflops"] * (2.0 * H * 4 * H) / (2.0 * (H + m.Epad) * 4 * H) * SPLIT_PASSES / F16_MFMA_PEAK_TFLOPS, 2)
+        # executed MFMA work: 3 passes, contraction padded to whole 16-value steps (+ the bias column where it rides in the GEMM)
+        k16 = lambda sg: (sg["k"] + (1 if sg["k"] % 16 else 0) + 15) // 16 * 16
+        exec_per_row_vocab = SPLIT_PASSES * sum(2.0 * k16(sg) * (sg["v_end"] - sg["v_start"]) for sg in m.segments)
+        v = kernel_stats(durs, rows, "vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
+        roofline = None
+        if v:
+            kname = ("vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
+                     "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
+                     else "gemm2_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
+            peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if split else F32_MFMA_PEAK_TFLOPS
+            traffic, traffic_note = None, "not measured in this run (tools/gpu_traffic.sh + tools/traffic_report.py write profiles/traffic_latest.json)"
+            tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+            if split and os.path.exists(tpath):
+                with open(tpath) as tf:
+                    tj = json.load(tf)
+                if tj.get("source_sha256") == kernel_source_sha256() and tj.get("fixture") == args.fixture:
+                    traffic, traffic_note = tj["vocab_lse_hbm_bytes_per_call"], tj["note"]
+                else:
+                    traffic_note = "profiles/traffic_latest.json was measured on other kernel sources / another fixture: omitted"
+            ex = v["tflops"] / m.flops_per_row_vocab * exec_per_row_vocab if split else v["tflops"]
+            roofline = {"kernel": kname, "bound": "mfma", "achieved": round(v["tflops"], 2), "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(v["tflops"] / peak, 4),
+                        "frac_of_dense_f16": round(ex / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
+                        "executed_tflops": round(ex, 1),
+                        "traffic": traffic, "traffic_source": traffic_note,
+                        "avg_launch_ms": round(v["avg_ms"], 4), "launches": v["launches"],
+                        "flops_per_launch": v["flops_per_launch"],
+                        "mfma_dtype": ("f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): `peak` = %.1f dense f16 / %d passes prices "
+                                       "ALGORITHMIC flops; frac_of_dense_f16 prices the executed ones (3 passes, k padded to 16)"
+                                       % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES) if split else "f32 (v_mfma_f32_32x32x2_f32)"),
+                        "measured": "HIP events around every launch of the dominant kernel on its stream, in a repeat of the timed decode"}
+        g = kernel_stats(durs, rows, "gate_gemm", 2.0 * H * 4 * H * (SPLIT_PASSES if gsplit else 1))
+        gate_obj = None
+        if g:
+            gpeak = F16_MFMA_PEAK_TFLOPS if gsplit else F32_MFMA_PEAK_TFLOPS
+            counted = g["tflops"] / (SPLIT_PASSES if gsplit else 1) * (H + m.E_in) / H
+            gate_obj = {"kernel": ("gate_xg_kernel (jlm_lstm_step_xg: one 160 x 128 tile per CU; the input side x.W_x+b is a per-word "
+                                   "table row added in the epilogue, the MFMAs contract over the state only)" if gsplit
+                                   else "gemm2_kernel<64x64,EpiGate> (jlm_lstm_step)"),
+                        "mfma_util_pct": round(100.0 * g["tflops"] / gpeak, 2),
+                        "executed_tflops": round(g["tflops"], 1), "peak": round(gpeak, 1), "unit": "TFLOP/s",
+                        "flops_executed": "%d x 2*H*4H per live row (K = H = %d)" % (SPLIT_PASSES if gsplit else 1, H),
+                        "reference_step_counted_tflops": round(counted, 1),
+                        "reference_step_counted": "2*(H+E)*4H per row, one pass (the reference's step, model.py:125-131), not executed work",
+                        "avg_launch_ms": round(g["avg_ms"], 4), "launches": g["launches"]}
+        return roofline, gate_obj
 
     cpu = None
+    line_extra = {}
+    if args.config == 5:
+        # ------------------------------------------------------------------------------------ BASELINE configs[4]
+        root, cfg, alphabet, dec = make_decoder(args.fixture, "static")
+        for _ in range(max(0, args.warmup - 1)):
+            shard.decode_sharded(dec, synth.make_sentences(1024 * world, args.length, seed=77, alphabet=alphabet), rank, world,
+                                 beam_width=args.beam)
+        dt, chars, n_mine = run_config5(dec, alphabet, args.steps)
+        value = chars * args.steps / dt
+        sents = synth.make_sentences(1024, args.length, seed=5555 + rank, alphabet=alphabet)
+        lat = BatchLattice(dec._builder, sents, args.beam)
+        roofline, gate_obj = measure_kernels(dec, lat, "static", {}, 3)
+        workload = ("BASELINE configs[4]: tied softmax V=50k (h=512, e=256), beam=10, ONE set of %d sentences x %d kana sharded over "
+                    "%d GPU(s) by jlm_amd.shard.decode_sharded, %d per GPU in chunks of 1 024" % (
+                        CONFIG5_SENTENCES, args.length, world, n_mine))
+        scaling = "strong"
+        steps_ms = dt / args.steps * 1e3
+        cpu_sents, cpu_dec, cpu_root = sents, dec, root
+    else:
+        # ------------------------------------------------------------------------------------ BASELINE configs[1]
+        root, cfg, alphabet, dec = make_decoder(args.fixture, args.decoder)
+        eng = dec._engine
+        # every rank decodes its own sentences (seeded by rank): sentence sharding, no data-path collective
+        sents = synth.make_sentences(args.batch, args.length, seed=4242 + rank, alphabet=alphabet)
+        chars_per_step = sum(len(s) for s in sents)
+        dec.max_batch = args.batch
+        lat = BatchLattice(dec._builder, sents, args.beam)
+        ekind, ekw = "static", {}
+        if args.decoder == "static-vs":
+            w_, o_, _l = lat.static_vocab()
+            ekw = dict(vocab=(w_, o_))
+        elif args.decoder == "dynamic":
+            ekind, ekw = "dynamic", dict(dyn_lists=lat.dynamic_vocab()[:4])
+
+        def run_device_steps(n):
+            """n steps with the lattice resident; the host read-out of step i overlaps the GPU work of step i+1."""
+            inflight = deque()                 # two steps in flight, as Decoder.decode_batch keeps its chunks
+            for _ in range(n):
+                inflight.append(eng.submit(lat, ekind, topN=10, **ekw))
+                if len(inflight) > dec.pipeline_depth:
+                    eng.collect(inflight.popleft())
+            while inflight:
+                eng.collect(inflight.popleft())
+
+        # untimed: the requested warm-up steps, and at least 12 decode calls in total (plans for both
+        # streams and both pipeline slots exist before the clock starts)
+        if args.warmup:
+            dec.decode_batch(sents * args.warmup, beam_width=args.beam, **dkw)
+        dec.decode_batch(sents * max(4, 12 - args.warmup), beam_width=args.beam, **dkw)
+        barrier()
+        t0 = time.perf_counter()
+        out = dec.decode_batch(sents * args.steps, beam_width=args.beam, **dkw)      # K steps = K pipelined 256-sentence batches
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
+        total_chars_per_step = sum_over_ranks(float(chars_per_step))
+        value = total_chars_per_step * args.steps / dt
+        steps_ms = dt / args.steps * 1e3
+        # the same with the lattice already in HBM (not `value`): device decode + n-best traces back on the host
+        run_device_steps(4)
+        barrier()
+        t1 = time.perf_counter()
+        run_device_steps(args.steps)
+        barrier()
+        dt_dev = max_over_ranks(time.perf_counter() - t1)
+        line_extra["device_resident_chars_per_s"] = round(total_chars_per_step * args.steps / dt_dev, 1)
+        line_extra["device_resident_ms_per_step"] = round(dt_dev / args.steps * 1e3, 3)
+        line_extra["device_resident_note"] = ("same K steps with the batch's lattice (CSR) already resident in HBM: launch sequence "
+                                              "+ n-best traces back on the host, no lattice build / upload / string read-out")
+        roofline, gate_obj = measure_kernels(dec, lat, ekind, ekw, min(args.steps, 20))
+        # diagnostic: does this box overlap the two batches in flight?  The same pipelined loop with one
+        # stream and with the engine's two (on some boxes the two are equal: the queues of the two streams
+        # are not run side by side there).
+        if eng.n_streams >= 2:
+            def timed_ms(n):
+                barrier()
+                t = time.perf_counter()
+                run_device_steps(n)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            keep = eng.n_streams
+            two = timed_ms(12)
+            eng.n_streams = 1
+            run_device_steps(3)
+            one = timed_ms(12)
+            eng.n_streams = keep
+            eng._rr = 0
+            line_extra["stream_overlap"] = {"one_stream_ms_per_step": round(one, 3), "two_streams_ms_per_step": round(two, 3),
+                                            "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
+        workload = ("BASELINE configs[1]: LSTM h=512, D-softmax* segs=(200,100,50), V=50k, beam=10, batch=256 sentences x 20 kana "
+                    "per GPU; strings in -> n-best strings out (SURVEY 8d)"
+                    if (args.fixture == "mid-vtable" and args.decoder == "static" and args.batch == 256 and args.length == 20
+                        and args.beam == 10) else
+                    "%s batch=%d length=%d beam=%d decoder=%s" % (args.fixture, args.batch, args.length, args.beam, args.decoder))
+        scaling = "weak"
+        cpu_sents, cpu_dec, cpu_root = sents, dec, root
+        # ------------------------------------------------------------------ extra leg: BASELINE configs[4] at this N
+        if not args.no_config5 and args.decoder == "static":
+            _r5, _c5, alphabet5, dec5 = make_decoder("mid-tied", "static")
+            dt5, chars5, n5 = run_config5(dec5, alphabet5, args.config5_passes)
+            line_extra["config5"] = {
+                "workload": "BASELINE configs[4]: tied softmax V=50k, beam=10, ONE set of %d sentences x %d kana sharded over %d GPU(s) "
+                            "(jlm_amd.shard.decode_sharded), %d on this rank in chunks of 1 024; strings in -> n-best strings out" % (
+                                CONFIG5_SENTENCES, args.length, world, n5),
+                "value": round(chars5 * args.config5_passes / dt5, 1), "unit": "chars/s", "n_gpus": world, "scaling": "strong",
+                "passes": args.config5_passes, "ms_per_pass": round(dt5 / args.config5_passes * 1e3, 2),
+                "note": "`python bench.py --gpus N --config 5` makes this leg the headline line"}
+            del dec5
+            jconfig.set_root(root)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     if not args.no_cpu_baseline and world == 1:
         from oracle import jlm_oracle as orc
-        o = (orc.OracleDynamicDecoder if args.decoder == "dynamic" else orc.OracleDecoder)(root, 1)
-        n = min(args.cpu_sentences, len(sents))
+        o = (orc.OracleDynamicDecoder if args.decoder == "dynamic" else orc.OracleDecoder)(cpu_root, 1)
+        n = min(args.cpu_sentences, len(cpu_sents))
         # BLAS threads = the CPUs this job may use (the box shows 256 hardware threads behind a cgroup quota
         # of 16; more threads than that only get the process throttled)
         from jlm_amd import usable_cpus
@@ -286,41 +354,38 @@ def main():
         except ImportError:
             limit = None
         t2 = time.perf_counter()
-        ref_out = [o.decode(s, beam_width=args.beam, **dkw) for s in sents[:n]]
+        ref_out = [o.decode(s, beam_width=args.beam, **dkw) for s in cpu_sents[:n]]
         cdt = time.perf_counter() - t2
         if limit is not None:
             limit.restore_original_limits()
-        gpu_out = dec.decode_batch(sents[:n], beam_width=args.beam, **dkw)
+        gpu_out = cpu_dec.decode_batch(cpu_sents[:n], beam_width=args.beam, **dkw)
         same = sum(1 for a, b in zip(ref_out, gpu_out) if a[0][1] == b[0][1])
-        cpu = {"value": round(sum(len(s) for s in sents[:n]) / cdt, 2), "unit": "chars/s", "cores": cores,
+        cpu = {"value": round(sum(len(s) for s in cpu_sents[:n]) / cdt, 2), "unit": "chars/s", "cores": cores,
                "kind": "port",
                "sample": "%d of the step's %d sentences, sentence-at-a-time numpy oracle (oracle/jlm_oracle.py), "
                          "BLAS threads = usable CPUs (affinity capped by the cgroup quota; %d hardware threads visible); lstm %.1f%% / proj+softmax %.1f%% of its time; "
                          "1-best identical to the GPU path on %d/%d" % (
-                             n, len(sents), os.cpu_count(), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
+                             n, len(cpu_sents), os.cpu_count(), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
 
-    value = total_chars_per_step * args.steps / dt
+    m = cpu_dec.model.dev
     line = {
-        "metric": "decoded chars/sec at beam=%d, vocab=%dk (lattice resident in HBM -> n-best traces on host)" % (
+        "metric": "decoded chars/sec at beam=%d, vocab=%dk (kana strings in -> n-best strings out, SURVEY 8d)" % (
             args.beam, cfg["vocab_size"] // 1000),
         "value": round(value, 1), "unit": "chars/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_eager_with_events": round(dt_eager / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(steps_ms, 3),
+        "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate: f32-grade error, tests/test_gpu_kernels.py; "
                   "scores f64)" if getattr(m, "split_array", None) is not None else "f32"),
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: LSTM h=512, D-softmax* segs=(200,100,50), V=50k, beam=10, "
-                               "batch=256 sentences x 20 kana per GPU"
-                   if (args.fixture == "mid-vtable" and args.decoder == "static" and args.batch == 256) else
-                               "%s batch=%d length=%d beam=%d" % (args.fixture, args.batch, args.length, args.beam),
-                   "fixture": args.fixture, "sentences_per_gpu": args.batch, "kana_per_sentence": args.length,
-                   "beam": args.beam, "decoder": args.decoder, "timed": "end_to_end" if args.end_to_end else "device",
+        "config": {"workload": workload, "baseline_config": args.config, "fixture": args.fixture,
+                   "sentences_per_gpu": args.batch if args.config == 2 else CONFIG5_SENTENCES // world,
+                   "kana_per_sentence": args.length, "beam": args.beam, "decoder": args.decoder if args.config == 2 else "static",
+                   "timed": "strings -> strings (lattice build, upload, device decode, n-best read-out), pipelined",
                    "parallelism": "sentence-sharded x%d, no collective" % world},
-        "end_to_end_chars_per_s": round(e2e, 1), "stream_overlap": overlap,
-        "roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu,
-
     }
+    line.update(line_extra)
+    line.update({"roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu})
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

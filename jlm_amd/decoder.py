@@ -20,10 +20,16 @@ one stream; the default keeps the native frame loop and the two alternating
 streams.  ``jlm_amd.eval`` and the ``compat/`` shims for the reference's
 ``eval.py`` (which prints those lists) switch it on.
 
+``beam_width=None`` (decoder.py:227: no pruning, the frame keeps every candidate, exponential in the
+input length) runs the reference's own loop on the host over ``LSTM_Model.predict_with_context``
+(:meth:`Decoder._decode_unpruned`) for as long as a frame holds at most ``max_unpruned_paths``
+hypotheses; the result is unsorted, as in the reference.
+
+``compat_quirks = True`` reproduces the stale ``lattice_vocab`` (decoder.py:62,176: once a call with
+``vocab_select=True`` has run, later calls without it still normalise over that old list and fail
+with ValueError when a word is not in it); off by default.
+
 Deliberate differences (DESIGN.md "Reference quirks"):
-  * ``beam_width=None`` (no pruning, exponential) is rejected;
-  * a stale ``lattice_vocab`` from an earlier ``vocab_select=True`` call is not
-    reused by a later full-vocabulary call (decoder.py:62,176 would);
   * the LSTM step of the last frame is skipped (its result is never read,
     decoder.py:233-237).
 """
@@ -75,6 +81,8 @@ class Decoder():
         self.perf_sen = 0
         self.perf_log_lstm = []
         self.perf_log_softmax = []
+        self.compat_quirks = False       # True: the stale lattice_vocab of decoder.py:62,176 (module docstring)
+        self.max_unpruned_paths = 20000  # beam_width=None: largest frame the host-side unpruned search accepts
         self.perf_timing = False         # True: per-frame HIP-event timings into perf_log_* (eval.py reads them), slower path
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.last_lattice = None
@@ -113,13 +121,17 @@ class Decoder():
 
     def decode_batch(self, inputs, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
                      random_sampling=False):
-        if beam_width is None:
-            raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+        inputs = list(inputs)
+        if beam_width is None:       # the reference's unpruned search, sentence at a time on the host
+            return [self._decode_unpruned(x, topN, vocab_select, samples, top_sampling, random_sampling) for x in inputs]
         if not 1 <= int(beam_width) <= 64:
             raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
-        inputs = list(inputs)
         if not inputs:
             return []
+        if self.compat_quirks and not vocab_select and self.lattice_vocab:
+            # decoder.py:176: `if self.lattice_vocab:` is still true after an earlier vocab_select call, so the full-vocabulary
+            # call indexes the OLD list: ValueError for a word outside it, else the old list is what the rows are normalised over
+            return [self._decode_stale_vocab(x, topN, beam_width) for x in inputs]
         if any(len(x) == 0 for x in inputs):
             # the reference's loop over an empty input leaves the <eos> path alone: [(0.0, [])] (decoder.py:220-241)
             keep = [i for i, x in enumerate(inputs) if len(x)]
@@ -154,6 +166,61 @@ class Decoder():
             self._log_perf()
         self.perf_sen += len(inputs)
         return out
+
+    def _decode_unpruned(self, input, topN, vocab_select, samples, top_sampling, random_sampling, beam_width=None, vocab=None):
+        """Decoder.decode of the reference with ``beam_width=None`` (decoder.py:220-241), statement for statement on the
+        host: every candidate survives, each frame is one ``predict_with_context`` call over all of its paths (the GPU
+        kernels behind LSTM_Model's numpy API), the result is the final frame in generation order, unsorted.  Also the
+        engine of :meth:`_decode_stale_vocab` (a beam and a fixed vocabulary list)."""
+        import math
+        import numpy as np
+        if len(input) == 0:
+            return [(0.0, [])]
+        lat = self.last_lattice = BatchLattice(self._builder, [input], 1)
+        ends = lat.backward_lookup(0)
+        if vocab is None and vocab_select:
+            vocab = list(lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))[2][0])
+            self.lattice_vocab = vocab
+        col = (lambda w: vocab.index(w)) if vocab is not None else (lambda w: w)       # ValueError for a word outside the list
+        H = self.model.hidden_size
+        # a path: (score, nodes tuple, word id of its last node); per frame also its state rows and probability rows
+        frames = {0: dict(paths=[(0.0, (), ends[0][0][2])])}
+        for i in range(len(input) + 1):
+            if i > 0:
+                paths = []
+                for (st, _ln, w, word) in ends[i]:
+                    prev = frames[st if st >= 0 else 0]
+                    c = col(w)
+                    for k, (score, nodes, _lw) in enumerate(prev["paths"]):
+                        paths.append((score - math.log(prev["pred"][k][c]), nodes + (word,), w, st if st >= 0 else 0, k))
+                if beam_width is not None:
+                    paths.sort(key=lambda x: x[0])          # stable, like list.sort in the reference
+                    paths = paths[:beam_width]
+                if len(paths) > self.max_unpruned_paths:
+                    raise ValueError("beam_width=None: frame %d holds %d hypotheses (max_unpruned_paths = %d)" % (
+                        i, len(paths), self.max_unpruned_paths))
+                frames[i] = dict(paths=[(p[0], p[1], p[2]) for p in paths], src=[(p[3], p[4]) for p in paths])
+            cur = frames[i]
+            if i == len(input):
+                break                                        # (the reference steps the last frame too and drops the result)
+            if i == 0:
+                hid, cel = np.zeros((1, H)), np.zeros((1, H))
+            else:
+                hid = np.stack([frames[f]["h"][k] for f, k in cur["src"]])
+                cel = np.stack([frames[f]["c"][k] for f, k in cur["src"]])
+            if not cur["paths"]:
+                cur["pred"], cur["h"], cur["c"] = [], [], []
+                continue
+            (pred, _y, _t1, _t2), h2, c2 = self.model.predict_with_context([p[2] for p in cur["paths"]], hid, cel, vocab)
+            cur["pred"], cur["h"], cur["c"] = pred, h2, c2
+        out = [(score, [w for w in nodes if w != "<eos>"]) for score, nodes, _lw in frames[len(input)]["paths"]]
+        self.perf_sen += 1
+        return out[:topN]
+
+    def _decode_stale_vocab(self, input, topN, beam_width):
+        """compat_quirks: a full-vocabulary call after a vocab_select call keeps normalising over the old list
+        (decoder.py:62,176) -- ValueError from ``list.index`` when the lattice has a word outside it."""
+        return self._decode_unpruned(input, topN, False, 0, False, False, beam_width=beam_width, vocab=list(self.lattice_vocab))
 
     def _prefetched(self, prepare, starts, workers=1):
         """prepare(start) for every chunk, results in order, up to ``workers`` + 1 chunks ahead of the consumer:

@@ -31,7 +31,7 @@ class DynamicDecoder(Decoder):
     def decode_batch(self, inputs, topN=10, beam_width=10, vocab_select=False, samples=0, top_sampling=False,
                      random_sampling=False):
         if beam_width is None:
-            raise ValueError("beam_width=None (unpruned search) is not supported on the GPU path")
+            raise ValueError("beam_width=None (unpruned search) is not supported by the incremental decoder's GPU path")
         if not 1 <= int(beam_width) <= 64:
             raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
         if not vocab_select:

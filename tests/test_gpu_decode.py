@@ -32,14 +32,27 @@ def _decoder(f, kind):
     return _DEC[key]
 
 
-def _check_nbest(out, gold, tag, strict_nbest=True):
+TIE_REL = 1e-6        # two hypotheses whose reference scores are this close (relative) may come out in either order
+
+
+def _check_nbest(out, gold, tag):
+    """1-best identical, scores at 1e-5 relative / 1e-3 absolute, and the n-best ORDER identical -- except between
+    hypotheses whose reference scores are within TIE_REL of each other (float32-derived path scores cannot order those)."""
     assert len(out) == len(gold), tag
     assert out[0][1] == gold[0][1], ("1-best differs", tag, out[0], gold[0])
     np.testing.assert_allclose([s for s, _ in out], [s for s, _ in gold], rtol=1e-5, atol=1e-3, err_msg=str(tag))
-    same = [w for _, w in out] == [w for _, w in gold]
-    if strict_nbest:
-        assert same, ("n-best order differs", tag)
-    return same
+    if [w for _, w in out] == [w for _, w in gold]:
+        return True
+    gscore = {tuple(w): s for s, w in gold}
+    for i, (_s, w) in enumerate(out):
+        if w == gold[i][1]:
+            continue
+        ref_here = gold[i][0]
+        # the hypothesis at this rank must be one the reference scores within the tie distance of its own rank-i score
+        # (a hypothesis that fell off the reference's list altogether can only have tied with its last entry)
+        ref_mine = gscore.get(tuple(w), gold[-1][0])
+        assert abs(ref_mine - ref_here) <= TIE_REL * max(1.0, abs(ref_here)), ("n-best order differs beyond a tie", tag, i, w, gold[i])
+    return False
 
 
 @pytest.mark.parametrize("name", gc.LM_FIXTURES)
@@ -91,11 +104,8 @@ def test_decode_matches_reference_golden(case, fast, fx, golden_decode):
             outs.append(dec.decode(s, **kwargs))
     else:
         outs = dec.decode_batch(sents, **kwargs)
-    n_same = 0
     for si, out in enumerate(outs):
-        n_same += _check_nbest(out, gold[si]["nbest"], (name, si), strict_nbest=False)
-    # n-best ORDER may legitimately flip where two hypotheses tie to ~1e-6; it must be rare
-    assert n_same >= 0.9 * len(outs), (name, n_same, len(outs))
+        _check_nbest(out, gold[si]["nbest"], (name, si))       # order identical unless two reference scores tie to 1e-6
 
 
 @pytest.mark.parametrize("fixture", ["small-vtable", "small-tied"])
@@ -189,10 +199,14 @@ def _readings_ok(words, text):
     return r == text
 
 
+N_ORACLE = 16          # sentences of every full-size case that are decoded by the oracle as well
+
+
 @pytest.mark.parametrize("fixture,kind,kwargs,n,beam", [
     ("mid-vtable", "static", {}, 256, 10),                                  # BASELINE.json configs[1]
     ("mid-tied", "dynamic", dict(vocab_select=True), 256, 10),              # configs[3]
     ("big-tied", "static", {}, 1024, 20),                                   # configs[2]
+    ("mid-tied", "static", {}, 1024, 10),                                   # configs[4]: one GPU's share of the 8 192 sentences
 ])
 def test_full_size_properties(fixture, kind, kwargs, n, beam, fx):
     """Size-independent properties at the benchmark's batch sizes + oracle parity on a sample."""
@@ -218,11 +232,11 @@ def test_full_size_properties(fixture, kind, kwargs, n, beam, fx):
     for a, b in zip(sub, out[5:37]):
         assert [w for _, w in a][0] == [w for _, w in b][0]
         np.testing.assert_allclose([x for x, _ in a], [x for x, _ in b], rtol=0, atol=2e-5)
-    # oracle on a small sample of the same inputs
+    # oracle on a sample of the same inputs, spread over the batch (first, last and evenly in between)
     o = (orc.OracleDynamicDecoder if kind == "dynamic" else orc.OracleDecoder)(f["root"], 1)
-    for si in (0, n // 2, n - 1)[: (2 if fixture == "big-tied" else 3)]:
+    for si in sorted({int(round(x)) for x in np.linspace(0, n - 1, N_ORACLE)}):
         want = o.decode(sents[si], beam_width=beam, **kwargs)
-        _check_nbest(out[si], want, (fixture, si), strict_nbest=False)
+        _check_nbest(out[si], want, (fixture, si))
 
 
 @pytest.mark.parametrize("case", [c for c in gc.DECODE_CASES if c[0] in (

@@ -59,12 +59,49 @@ def test_empty_batch_and_bad_input(fx):
     f = fx("small-tied")
     d, _ = _pair(f, "static")
     assert d.decode_batch([]) == []
-    with pytest.raises(ValueError):
-        d.decode_batch(["アイ", ""])
-    with pytest.raises(ValueError):
-        d.decode("アイ", beam_width=None)
+    got = d.decode_batch(["アイ", ""])            # the reference's loop over an empty input leaves the <eos> path alone
+    assert got[1] == [(0.0, [])] and got[0] == d.decode("アイ")
+    assert d.decode("") == [(0.0, [])]
     with pytest.raises(ValueError):
         d.decode("アイ", beam_width=65)        # one wave lane per surviving hypothesis: 64 is the widest beam
+
+
+def test_unpruned_search_and_stale_vocab_quirk(fx):
+    """beam_width=None (decoder.py:227): every candidate survives, unsorted output -- the host-side path over the predict
+    API against the oracle's restatement of the same loop; compat_quirks: the stale lattice_vocab of decoder.py:62,176"""
+    f = fx("small-tied")
+    d, o = _pair(f, "static")
+    for s in synth.make_ragged_sentences(4, 2, 3, seed=21, alphabet=f["alphabet"]):
+        want = orc.OracleDecoder(f["root"], 1).decode(s, beam_width=None)     # (a fresh oracle: it keeps the reference's stale list)
+        d.lattice_vocab = None
+        got = d.decode(s, beam_width=None)
+        assert [w for _, w in got] == [w for _, w in want]             # generation order, not score order
+        np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
+        want = orc.OracleDecoder(f["root"], 1).decode(s, beam_width=None, vocab_select=True)
+        got = d.decode(s, beam_width=None, vocab_select=True)
+        assert [w for _, w in got] == [w for _, w in want]
+        np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
+    d.max_unpruned_paths = 50
+    with pytest.raises(ValueError):
+        d.decode("".join(synth.make_sentences(1, 12, seed=3, alphabet=f["alphabet"])), beam_width=None)
+    # stale vocabulary: the oracle keeps the reference's behaviour (jlm_oracle.py: "stale lattice_vocab across calls")
+    d2, o2 = _pair(f, "static")
+    d2.compat_quirks = True
+    s1, s2 = synth.make_ragged_sentences(2, 4, 6, seed=33, alphabet=f["alphabet"])
+    assert [w for _, w in d2.decode(s1, beam_width=4, vocab_select=True)] == [w for _, w in o2.decode(s1, beam_width=4, vocab_select=True)]
+    try:
+        want = o2.decode(s2, beam_width=4)          # normalised over s1's list, or ValueError for a word outside it
+    except ValueError:
+        with pytest.raises(ValueError):
+            d2.decode(s2, beam_width=4)
+    else:
+        got = d2.decode(s2, beam_width=4)
+        assert [w for _, w in got] == [w for _, w in want]
+        np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
+    want = o2.decode(s1, beam_width=4)              # every word of s1 is in its own list: the quirk changes only the normaliser
+    got = d2.decode(s1, beam_width=4)
+    assert [w for _, w in got] == [w for _, w in want]
+    np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
 
 
 def test_odd_vocabulary_size(tmp_path):

@@ -1,0 +1,77 @@
+"""GPU, BASELINE.json configs[4]: the sentence-sharded decode of the tied V=50k model.  Two ranks over gloo,
+BOTH on cuda:0 (the GPU boxes have one device; the 8-GPU run is the driver's), each decoding its shard through
+jlm_amd.shard.decode_sharded exactly as `bench.py --config 5` does; the merged n-best lists must equal the one-rank decode
+of the same sentences -- the shards cover every sentence once, and a sentence's result does not depend on which other
+sentences share its batch (beyond the last float32 bits of a score)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+from jlm_amd import shard, synth          # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N_SENT = 512
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, root, sents, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    import jlm_amd  # noqa: F401  (defaults GPU_MAX_HW_QUEUES before the HIP runtime starts)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jlm_amd import config as jconfig
+        jconfig.set_root(root)
+        from jlm_amd.decoder import Decoder
+        dec = Decoder(1)
+        dec.max_batch = 128                       # several pipelined chunks per rank
+        idx, res = shard.decode_sharded(dec, sents, rank, world, beam_width=10)
+        dist.barrier()
+        merged = shard.gather_to_rank0(idx, res, len(sents), dist, rank, world)
+        if rank == 0:
+            q.put(merged)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank(fx):
+    f = fx("mid-tied")
+    sents = synth.make_sentences(N_SENT - 40, 20, seed=5555, alphabet=f["alphabet"]) + \
+        synth.make_ragged_sentences(40, 3, 31, seed=9, alphabet=f["alphabet"])          # ragged lengths exercise the length-sorted deal
+    lens = [len(s) for s in sents]
+    a, b = shard.shard_indices(lens, 0, 2), shard.shard_indices(lens, 1, 2)
+    assert sorted(a + b) == list(range(len(sents))) and abs(sum(lens[i] for i in a) - sum(lens[i] for i in b)) <= max(lens)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, f["root"], sents, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from jlm_amd import config as jconfig
+    jconfig.set_root(f["root"])
+    from jlm_amd.decoder import Decoder
+    one = Decoder(1).decode_batch(sents, beam_width=10)
+    assert len(merged) == len(one) == len(sents)
+    for si, (x, y) in enumerate(zip(merged, one)):
+        assert [w for _, w in x] == [w for _, w in y], si
+        np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=0, atol=2e-5)

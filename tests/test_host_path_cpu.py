@@ -87,7 +87,9 @@ def test_single_sentence_api_and_attrs(fx, fake, golden_decode):
     assert [w for _, w in out] == [w for _, w in golden_decode[case[0]][2]["nbest"]]
     assert dec.perf_sen == 1
     ends = orc.build_lattice(sents[2], dec.full_lexicon, dec.full_reading_dict, dec.w2i)
-    assert dec.backward_lookup == ends
+    # the reference's shape: dict frame -> [Node] (decoder.py:79-135)
+    assert isinstance(dec.backward_lookup, dict) and sorted(dec.backward_lookup) == list(range(len(ends)))
+    assert [[(n.start_idx, n.reading_length, n.word_idx, n.word) for n in dec.backward_lookup[i]] for i in range(len(ends))] == ends
     assert dec.lattice_vocab == orc.static_vocab(ends)
     bl = dec._build_lattice(sents[2])
     assert [[(n.start_idx, n.reading_length, n.word_idx, n.word) for n in bl[i]] for i in range(len(ends))] == ends
@@ -171,3 +173,31 @@ def test_usable_cpus_follows_quota_and_local_world_size(monkeypatch):
     assert jlm_amd.usable_cpus() == max(1, base // 4)           # the ranks of a node share the quota
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
     assert jlm_amd.usable_cpus() == base
+
+
+def test_unpruned_search_and_compat_quirks_cpu(fx, fake):
+    """beam_width=None (decoder.py:227) and the stale lattice_vocab (decoder.py:62,176, compat_quirks) through the host-side
+    path over the predict API, against the oracle's restatement of the reference loop"""
+    from jlm_amd import synth
+    f = fx("small-tied")
+    d = _decoder(f, "static")
+    o = orc.OracleDecoder(f["root"], 1)
+    for s in synth.make_ragged_sentences(3, 2, 3, seed=21, alphabet=f["alphabet"]):
+        for kw in ({}, dict(vocab_select=True)):
+            want = orc.OracleDecoder(f["root"], 1).decode(s, beam_width=None, **kw)
+            d.lattice_vocab = None
+            got = d.decode(s, beam_width=None, **kw)
+            assert [w for _, w in got] == [w for _, w in want]         # generation order, not score order
+            np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
+    assert d.decode("", beam_width=None) == [(0.0, [])]
+    d2 = _decoder(f, "static")
+    d2.compat_quirks = True
+    s1 = synth.make_ragged_sentences(1, 4, 6, seed=33, alphabet=f["alphabet"])[0]
+    assert [w for _, w in d2.decode(s1, beam_width=4, vocab_select=True)] == [w for _, w in o.decode(s1, beam_width=4, vocab_select=True)]
+    want = o.decode(s1, beam_width=4)           # the oracle keeps the stale list, as the reference does
+    got = d2.decode(s1, beam_width=4)
+    assert [w for _, w in got] == [w for _, w in want]
+    np.testing.assert_allclose([x for x, _ in got], [x for x, _ in want], rtol=2e-6, atol=2e-5)
+    d2.compat_quirks = False                    # default: a full-vocabulary call normalises over the full vocabulary
+    fresh = orc.OracleDecoder(f["root"], 1).decode(s1, beam_width=4)
+    np.testing.assert_allclose([x for x, _ in d2.decode(s1, beam_width=4)], [x for x, _ in fresh], rtol=2e-6, atol=2e-5)
