@@ -104,7 +104,6 @@ def main():
     from jlm_amd.decoder import Decoder
     from jlm_amd.decoder_dynamic import DynamicDecoder
     from jlm_amd.lattice import BatchLattice
-    from jlm_amd.model import KernelRecorder
 
     def barrier():
         if dist is not None:
@@ -161,18 +160,19 @@ def main():
         return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12, flops_per_launch=flops / n)
 
     def measure_kernels(dec, lat, ekind, ekw, steps):
-        """The same decode once more with a HIP event pair around every GEMM launch (same kernels, same arguments, on the
-        launching stream; kept out of the throughput loops so that the event records do not perturb them)."""
+        """The same decode once more, timed: HIP events on the launching stream around the LSTM step and around the vocabulary
+        kernel of every frame (same kernels, same arguments; kept out of the throughput loops so that the event records and
+        the single stream do not perturb them)."""
         eng, m = dec._engine, dec.model.dev
-        rec = KernelRecorder(torch)
-        eng.recorder = rec
-        n_live = []
+        eng.keep_n_live = True
+        n_live, durs = [], {"gate_gemm": [], "vocab_lse": []}
         for _ in range(steps):
-            eng.decode(lat, ekind, topN=10, **ekw)
+            eng.decode(lat, ekind, topN=10, timing=True, **ekw)       # jlm_decode_frames records the events (include/jlm_hip.h)
             n_live.append(eng.last_n_live)
+            for k in durs:
+                durs[k].extend(eng.last_kernel_ms[k])
         torch.cuda.synchronize()
-        eng.recorder = None
-        durs = rec.durations_ms()
+        eng.keep_n_live = False
         rows = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in n_live])    # live rows per launch
         H = m.H
         split = getattr(m, "split_array", None) is not None

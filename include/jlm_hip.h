@@ -355,12 +355,22 @@ typedef struct {
     int *out_nodes; int *out_len; double *out_score; int stride;    /* jlm_backtrace outputs */
 } jlm_decode_plan;
 
-/* Returns 0, a hipError_t, or -2 when the model is outside the shapes this call
- * covers (full vocabulary with a segment of k > 256: enqueue the calls one by
- * one then).  st_host->lse_part / n_parts are managed by the call. */
+/* Returns 0 or a hipError_t.  st_host->lse_part / n_parts are managed by the call.  A full-vocabulary
+ * model with a segment of k > 256 (untied: k = H, model.py:189-191) takes the tile form of the normaliser
+ * (jlm_vocab_lse_partials per segment, one slice per 128 words: plan.max_parts >= the number of such tiles).
+ *
+ * events (may be NULL): JLM_EVENTS_PER_FRAME * n_frames hipEvent_t created by the caller (timing enabled).
+ * They are recorded on `stream` around the kernel groups of every frame -- the edge logits then run on
+ * `stream` too, so each bracket holds exactly what it names:
+ *   [0] frame start  [1] after the incremental merge ("vocab fix", decoder_dynamic.py:112-148)
+ *   [2] after the beam step ([1]..[2] = "lattice path fix" for the incremental decoder, :150-175)
+ *   [3] after the LSTM step ([2]..[3] = perf_log_lstm, decoder.py:206-218; the gate GEMM alone)
+ *   [4] after the T projection and the edge logits   [5] after the normaliser ([4]..[5] = the vocabulary
+ *   kernel alone; [3]..[5] = perf_log_softmax).  Frames past the last stepped one record [0]..[2] only. */
+#define JLM_EVENTS_PER_FRAME 6
 int jlm_decode_frames(const jlm_decode_model *model_host, const jlm_decode_plan *plan_host,
                       const jlm_lattice *lat_host, const jlm_beam_state *st_host,
-                      void *stream, void *side_stream);
+                      void *stream, void *side_stream, void *const *events);
 
 #ifdef __cplusplus
 }

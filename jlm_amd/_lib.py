@@ -86,7 +86,7 @@ _SIGS = {
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
-    "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P], c_int),
+    "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P, P], c_int),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -40,17 +40,26 @@ thread_local EventPool g_events;
 }  // namespace
 
 extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_plan *p, const jlm_lattice *lat,
-                                 const jlm_beam_state *st_in, void *stream, void *side_stream) {
+                                 const jlm_beam_state *st_in, void *stream, void *side_stream, void *const *events) {
     const int B = lat->n_sent, beam = lat->beam, F = lat->n_frames;
     const int rmax = B * beam;
     const bool dynamic = p->kind == 2, select = p->kind == 1, full = p->kind == 0;
     const int mode = m->self_norm ? 1 : (dynamic ? 2 : 0);
     const bool wl_split = m->split_segs != nullptr && m->n_segs == 1 && beam <= 32;
+    // a segment with k > 256 (untied models: k = H) is outside the rows-stationary normalisers: one tile GEMM per segment
+    // with a per-tile log-sum-exp epilogue (jlm_vocab_lse_partials), its slices folded by the next frame's beam step
+    bool tile_form = false;
     if (full && !m->self_norm)
         for (int i = 0; i < m->n_segs; ++i)
-            if (m->segs[i].k > 256) return -2;
+            if (m->segs[i].k > 256) tile_form = true;
     jlm_beam_state st = *st_in;
-    hipStream_t main_s = (hipStream_t)stream, side_s = (hipStream_t)side_stream;
+    hipStream_t main_s = (hipStream_t)stream, side_s = events ? nullptr : (hipStream_t)side_stream;
+    // events != NULL: JLM_EVENTS_PER_FRAME timing events per frame, recorded on `stream` (no side stream then, so that
+    // every bracket holds exactly the kernels it names)
+    auto stamp = [&](int f, int i) -> int {
+        if (!events) return 0;
+        return (int)hipEventRecord((hipEvent_t)events[(size_t)f * JLM_EVENTS_PER_FRAME + i], main_s);
+    };
     hipEvent_t join = nullptr;
     int pending_parts = 0;
 
@@ -72,6 +81,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
             join = nullptr;
         }
+        JLM_TRY(stamp(f, 0));
         if (dynamic && !m->self_norm && f >= 2) {
             int r = -2;
             if (wl_split && p->dd_max <= 128)
@@ -81,10 +91,12 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             if (r == -2) r = wl_lse(p->g0, p->cidx, p->dd_words, p->dd_off, p->sidx, f * B, 1, (f - 1) * B, p->dd_max);
             JLM_TRY(r);
         }
+        JLM_TRY(stamp(f, 1));
         st.lse_part = pending_parts ? p->part : nullptr;
         st.ld_part = rmax;
         st.n_parts = pending_parts;
         JLM_TRY(jlm_beam_step(lat, &st, f, mode, p->max_cands, stream));
+        JLM_TRY(stamp(f, 2));
         pending_parts = 0;
         if (f == F - 1) break;
         const int *rows = st.live + (size_t)f * rmax;
@@ -98,6 +110,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         else
             JLM_TRY(jlm_lstm_step((const float *)p->h, p->c, m->H, (float *)p->h, p->c, rows, st.bp, st.word, m->emb,
                                   m->ld_emb, m->wt, m->gate_bias, m->kpad, m->H, m->E, rmax, ndev, stream));
+        JLM_TRY(stamp(f, 3));
         if (!m->untied) {
             if (m->split_lstm)
                 JLM_TRY(jlm_gemm_nt_split(p->h, m->H, rows, m->pmt_split, m->H, nullptr, p->T, m->ldt, rows, nullptr,
@@ -121,12 +134,24 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_HIP(g_events.get(&join));
             JLM_HIP(hipEventRecord(join, side_s));
         }
+        JLM_TRY(stamp(f, 4));
         if (!m->self_norm) {
             if (dynamic)
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, p->di_idx, 2 * cell, 0, B, p->di_max));
             else if (select)
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, p->sidx, 0, 0, B, p->vs_max));
-            else {
+            else if (tile_form) {
+                int n_parts = 0;
+                for (int i = 0; i < m->n_segs; ++i) {
+                    const jlm_segment &sg = m->segs[i];
+                    int r = jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, p->T + sg.t_off, m->ldt, rows,
+                                                   m->b2 + sg.v_start, p->part, rmax, n_parts, rmax, ndev, stream);
+                    if (r < 0) return r;
+                    n_parts += r;
+                }
+                if (n_parts > p->max_parts) return -1;
+                pending_parts = n_parts;
+            } else {
                 // frame 0 has one row per sentence: the bound lets the kernel cut the vocabulary into more ranges
                 const int bound = f == 0 ? B : rmax;
                 int r = m->split_segs
@@ -139,6 +164,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 pending_parts = r;
             }
         }
+        JLM_TRY(stamp(f, 5));
     }
     if (join) JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
     return jlm_backtrace(lat, &st, p->out_nodes, p->out_len, p->out_score, p->stride, stream);

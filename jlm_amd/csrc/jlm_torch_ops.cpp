@@ -1,0 +1,312 @@
+// jlm_torch_ops.cpp -- the PyTorch-ROCm custom-op boundary of the decode path.
+//
+// A thin TORCH_LIBRARY shim over the C-ABI launchers of libjlm_hip.so (include/jlm_hip.h): torch owns every device buffer,
+// the ops take torch.Tensor arguments (never raw pointers from Python), launch on the CURRENT torch HIP stream of the
+// tensors' device, and turn a non-zero return into a c10::Error (TORCH_CHECK) carrying hipGetErrorString.  What it
+// replaces on the reference's side are the call sites decoder/decoder.py:202-218 -> decoder/model.py:195-198
+// (Decoder._batch_predict -> LSTM_Model.predict_with_context) and the frame loop around them (decoder.py:220-241).
+//
+//   torch.classes.jlm.Model   the model's weight panels as jlm_decode_model (keeps the tensors alive)
+//   torch.classes.jlm.Plan    the buffers of one decode shape as jlm_lattice / jlm_beam_state / jlm_decode_plan,
+//                             plus the timing events of a timed decode
+//   torch.ops.jlm.decode_frames(Model, Plan, n_frames, vs_max, di_max, dd_max, use_side, timed)
+//                             the whole frame loop of a batch: ONE op (jlm_decode_frames)
+//   torch.ops.jlm.frame_times(Plan) -> Tensor [n_frames, 5] milliseconds of the last timed decode (after it finished)
+//   torch.ops.jlm.lstm_step / gemm_nt / softmax_rows      LSTM_Model.predict / project (numpy-facing API)
+//   torch.ops.jlm.pack_split_f16 / pack_split_f16_col     weight preparation at load
+//
+// Built by __graft_entry__.build():  g++ -shared ... -> jlm_amd/_torch_ops.so, loaded with torch.ops.load_library.
+#include <torch/library.h>
+#include <torch/custom_class.h>
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/jlm_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = c10::optional<Tensor>;
+using TDict = c10::Dict<std::string, Tensor>;
+using IDict = c10::Dict<std::string, int64_t>;
+using FDict = c10::Dict<std::string, double>;
+
+void jlm_check(int rc, const char *what) {
+    if (rc == 0) return;
+    if (rc > 0)
+        TORCH_CHECK(false, what, " failed: ", hipGetErrorString(static_cast<hipError_t>(rc)), " (hipError_t ", rc, ")");
+    TORCH_CHECK(false, what, " rejected its arguments (code ", rc,
+                ": -1 = shape / alignment the kernels cannot handle, -2 = outside the shapes this entry point covers, "
+                "-3 = the kernel's LDS size could not be set; include/jlm_hip.h)");
+}
+
+void on_gpu(const Tensor &t, const char *name) {
+    TORCH_CHECK(t.defined() && t.is_cuda(), "jlm: `", name, "` must be a tensor on the GPU (there is no CPU path)");
+    TORCH_CHECK(t.is_contiguous(), "jlm: `", name, "` must be contiguous");
+}
+
+template <class T = void> T *ptr(const Tensor &t, const char *name) {
+    on_gpu(t, name);
+    return reinterpret_cast<T *>(t.data_ptr());
+}
+template <class T = void> T *optr(const OptTensor &t, const char *name) {
+    if (!t.has_value() || !t->defined()) return nullptr;
+    return ptr<T>(*t, name);
+}
+
+// the current torch stream of the device the tensor lives on (ops never switch devices themselves: the caller's
+// torch.cuda.device context / set_device is what the HIP runtime launches on)
+hipStream_t stream_of(const Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+struct Segments {
+    std::vector<jlm_segment> v;
+    std::vector<Tensor> keep;
+    Segments() = default;
+    // meta: (v_start, v_end, k, t_off, ldb) per segment
+    Segments(const std::vector<Tensor> &B, const std::vector<int64_t> &meta) : keep(B) {
+        TORCH_CHECK(meta.size() == 5 * B.size() && B.size() <= JLM_MAX_SEGMENTS, "jlm: malformed segment table");
+        for (size_t i = 0; i < B.size(); ++i) {
+            jlm_segment s;
+            s.v_start = (int)meta[5 * i]; s.v_end = (int)meta[5 * i + 1]; s.k = (int)meta[5 * i + 2];
+            s.t_off = (int)meta[5 * i + 3]; s.ldb = (int)meta[5 * i + 4];
+            s.B = ptr<const float>(B[i], "segment block");
+            v.push_back(s);
+        }
+    }
+};
+
+const Tensor *find(const TDict &d, const char *key) {
+    auto it = d.find(key);
+    return it == d.end() ? nullptr : &it->value();
+}
+int64_t geti(const IDict &d, const char *key, int64_t dflt = 0) {
+    auto it = d.find(key);
+    return it == d.end() ? dflt : it->value();
+}
+double getf(const FDict &d, const char *key, double dflt = 0.0) {
+    auto it = d.find(key);
+    return it == d.end() ? dflt : it->value();
+}
+template <class T = void> T *tptr(const TDict &d, const char *key) {
+    const Tensor *t = find(d, key);
+    return t ? ptr<T>(*t, key) : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------- Model
+struct JlmModel : torch::CustomClassHolder {
+    TDict tensors;
+    Segments segs, split;
+    std::vector<float> t_scale, descale;
+    std::vector<int> bias_col;
+    jlm_decode_model m{};
+    JlmModel(TDict t, IDict i, FDict f, std::vector<Tensor> seg_B, std::vector<int64_t> seg_meta, std::vector<Tensor> split_B,
+             std::vector<int64_t> split_meta, std::vector<double> split_t_scale, std::vector<double> split_descale,
+             std::vector<int64_t> split_bias_col)
+        : tensors(std::move(t)), segs(seg_B, seg_meta), split(split_B, split_meta) {
+        for (double x : split_t_scale) t_scale.push_back((float)x);
+        for (double x : split_descale) descale.push_back((float)x);
+        for (int64_t x : split_bias_col) bias_col.push_back((int)x);
+        TORCH_CHECK(t_scale.size() == split.v.size() && descale.size() == split.v.size() && bias_col.size() == split.v.size(),
+                    "jlm.Model: one scale / descale / bias column per split segment");
+        m.segs = segs.v.data(); m.n_segs = (int)segs.v.size();
+        m.b2 = tptr<const float>(tensors, "b2");
+        m.H = (int)geti(i, "H"); m.ldt = (int)geti(i, "ldt");
+        m.untied = (int)geti(i, "untied"); m.self_norm = (int)geti(i, "self_norm"); m.split_lstm = (int)geti(i, "split_lstm");
+        m.emb = tptr<const float>(tensors, "emb"); m.ld_emb = (int)geti(i, "ld_emb");
+        m.wt = tptr<const float>(tensors, "wt"); m.gate_bias = tptr<const float>(tensors, "gate_bias");
+        m.kpad = (int)geti(i, "kpad"); m.E = (int)geti(i, "E");
+        m.wt_split = nullptr; m.kpad_split = (int)geti(i, "kpad_split");
+        m.gate_descale = (float)getf(f, "gate_descale"); m.h_scale = (float)getf(f, "h_scale"); m.xgate = nullptr;
+        m.wt8 = tptr<const void>(tensors, "wt8"); m.xgate8 = tptr<const float>(tensors, "xgate8");
+        m.pmt = tptr<const float>(tensors, "pmt"); m.pmt_split = tptr<const void>(tensors, "pmt_split");
+        m.n_t = (int)geti(i, "n_t"); m.t_descale = (float)getf(f, "t_descale");
+        if (!split.v.empty()) {
+            m.split_segs = split.v.data(); m.split_t_scale = t_scale.data(); m.split_descale = descale.data();
+            m.split_bias_col = bias_col.data();
+        }
+        TORCH_CHECK(m.b2 && m.n_segs >= 1 && m.H > 0, "jlm.Model: b2, the segments and H are required");
+        TORCH_CHECK(!m.split_lstm || (m.wt8 && m.xgate8 && m.pmt_split), "jlm.Model: split_lstm needs wt8, xgate8, pmt_split");
+    }
+};
+
+// ------------------------------------------------------------------------------------------------- Plan
+struct JlmPlan : torch::CustomClassHolder {
+    TDict tensors;
+    jlm_lattice lat{};
+    jlm_beam_state st{};
+    jlm_decode_plan p{};
+    int frames_cap = 0;
+    std::vector<hipEvent_t> events;         // JLM_EVENTS_PER_FRAME per frame, created on first timed decode
+    int timed_frames = 0;                   // frames of the last timed decode (0: the last decode was not timed)
+    int device = -1;
+
+    JlmPlan(TDict t, IDict i) : tensors(std::move(t)) {
+        const Tensor *ints = find(tensors, "ints");
+        TORCH_CHECK(ints && ints->scalar_type() == at::kInt, "jlm.Plan: `ints` (int32 staging block) is required");
+        device = ints->device().index();
+        const int *base = ptr<const int>(*ints, "ints");
+        auto at_off = [&](const char *key) -> const int * {
+            auto it = i.find(key);
+            TORCH_CHECK(it != i.end(), "jlm.Plan: missing offset ", key);
+            TORCH_CHECK(it->value() >= 0 && it->value() < ints->numel(), "jlm.Plan: offset ", key, " outside `ints`");
+            return base + it->value();
+        };
+        lat.n_sent = (int)geti(i, "n_sent"); lat.beam = (int)geti(i, "beam"); lat.n_frames = 0;
+        frames_cap = (int)geti(i, "frames");
+        lat.sent_len = at_off("off_sent_len"); lat.end_off = at_off("off_end_off");
+        lat.node_start = at_off("off_node_start"); lat.node_word = at_off("off_node_word");
+        st.score = tptr<double>(tensors, "score"); st.lse = tptr<double>(tensors, "lse"); st.ysum = tptr<double>(tensors, "ysum");
+        st.bp = tptr<int>(tensors, "bp"); st.node = tptr<int>(tensors, "node"); st.word = tptr<int>(tensors, "word");
+        st.cnt = tptr<int>(tensors, "cnt"); st.live = tptr<int>(tensors, "live"); st.n_live = tptr<int>(tensors, "n_live");
+        st.edge = tptr<const float>(tensors, "edge"); st.live_base = tptr<int>(tensors, "live_base");
+        st.lse_part = nullptr; st.ld_part = 0; st.n_parts = 0;
+        p.kind = (int)geti(i, "kind"); p.max_cands = (int)geti(i, "max_cands");
+        p.h = tptr<void>(tensors, "h"); p.c = tptr<float>(tensors, "c"); p.T = tptr<float>(tensors, "T");
+        p.g0 = at_off("off_g0"); p.cidx = at_off("off_cidx"); p.sidx = at_off("off_sidx");
+        p.sg_word = at_off("off_sg_word"); p.sg_off = at_off("off_sg_off"); p.sg_node = at_off("off_sg_node");
+        p.edge = tptr<float>(tensors, "edge");
+        p.vs_words = at_off("off_vs_words"); p.vs_off = at_off("off_vs_off");
+        p.di_words = at_off("off_di_words"); p.di_off = at_off("off_di_off"); p.di_idx = at_off("off_sidx2");
+        p.dd_words = at_off("off_dd_words"); p.dd_off = at_off("off_dd_off");
+        p.run_max = tptr<float>(tensors, "run_max"); p.run_sum = tptr<double>(tensors, "run_sum");
+        p.part = tptr<float>(tensors, "part"); p.max_parts = (int)geti(i, "max_parts");
+        p.out_nodes = tptr<int>(tensors, "out_nodes"); p.out_len = tptr<int>(tensors, "out_len");
+        p.out_score = tptr<double>(tensors, "out_score"); p.stride = (int)geti(i, "stride");
+        TORCH_CHECK(st.score && st.lse && st.bp && st.node && st.word && st.cnt && st.live && st.n_live && st.live_base && p.h && p.c &&
+                        p.T && p.edge && p.out_nodes && p.out_len && p.out_score && lat.n_sent > 0 && lat.beam > 0 && frames_cap > 0,
+                    "jlm.Plan: a required buffer is missing");
+    }
+    ~JlmPlan() override {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+
+// side stream of each launch stream (edge logits beside the normaliser): ONE per launch stream for the whole process -- ROCm
+// maps streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise (jlm_amd/__init__.py)
+std::map<std::pair<int, hipStream_t>, c10::hip::HIPStream> g_side;
+
+int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intrusive_ptr<JlmPlan> &plan, int64_t n_frames,
+                      int64_t vs_max, int64_t di_max, int64_t dd_max, bool use_side, bool timed) {
+    JlmPlan &pl = *plan;
+    TORCH_CHECK(n_frames >= 1 && n_frames <= pl.frames_cap, "jlm.decode_frames: ", n_frames, " frames, the plan holds ", pl.frames_cap);
+    c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(pl.device);
+    pl.lat.n_frames = (int)n_frames;
+    pl.p.vs_max = (int)vs_max; pl.p.di_max = (int)di_max; pl.p.dd_max = (int)dd_max;
+    void *side_s = nullptr;
+    if (use_side && !timed) {
+        const auto key = std::make_pair(pl.device, main.stream());
+        auto it = g_side.find(key);
+        if (it == g_side.end()) it = g_side.emplace(key, c10::hip::getStreamFromPool(false, pl.device)).first;
+        side_s = it->second.stream();
+    }
+    void *const *ev = nullptr;
+    pl.timed_frames = 0;
+    if (timed) {
+        const size_t need = (size_t)n_frames * JLM_EVENTS_PER_FRAME;
+        while (pl.events.size() < need) {
+            hipEvent_t e;
+            jlm_check((int)hipEventCreate(&e), "hipEventCreate");
+            pl.events.push_back(e);
+        }
+        ev = reinterpret_cast<void *const *>(pl.events.data());
+        pl.timed_frames = (int)n_frames;
+    }
+    const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, ev);
+    if (rc == -2) return -2;
+    jlm_check(rc, "jlm_decode_frames");
+    return 0;
+}
+
+// [n_frames, 5] milliseconds of the plan's last TIMED decode, which must have finished (the caller synchronised on it):
+// vocab fix, lattice path fix (beam step), LSTM step, T projection + edge logits, normaliser (include/jlm_hip.h, events)
+Tensor frame_times(const c10::intrusive_ptr<JlmPlan> &plan) {
+    JlmPlan &pl = *plan;
+    const int F = pl.timed_frames;
+    Tensor out = at::zeros({F, 5}, at::kDouble);
+    auto a = out.accessor<double, 2>();
+    for (int f = 0; f < F; ++f) {
+        const int last = (f == F - 1) ? 2 : 5;          // the last frame is not stepped
+        for (int i = 0; i < last; ++i) {
+            float ms = 0.0f;
+            jlm_check((int)hipEventElapsedTime(&ms, pl.events[(size_t)f * JLM_EVENTS_PER_FRAME + i],
+                                               pl.events[(size_t)f * JLM_EVENTS_PER_FRAME + i + 1]), "hipEventElapsedTime");
+            a[f][i] = ms;
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------ LSTM_Model.predict / project
+void lstm_step(const Tensor &h_in, const Tensor &c_in, int64_t ld_state, const Tensor &h_out, const Tensor &c_out, const OptTensor &rows,
+               const Tensor &prev, const Tensor &word, const Tensor &emb, int64_t ld_emb, const Tensor &wt, const Tensor &bias,
+               int64_t kpad, int64_t H, int64_t E, int64_t n_rows_max, const OptTensor &n_dev) {
+    jlm_check(jlm_lstm_step(ptr<const float>(h_in, "h_in"), ptr<const float>(c_in, "c_in"), (int)ld_state, ptr<float>(h_out, "h_out"),
+                            ptr<float>(c_out, "c_out"), optr<const int>(rows, "rows"), ptr<const int>(prev, "prev"),
+                            ptr<const int>(word, "word"), ptr<const float>(emb, "emb"), (int)ld_emb, ptr<const float>(wt, "wt"),
+                            ptr<const float>(bias, "bias"), (int)kpad, (int)H, (int)E, (int)n_rows_max, optr<const int>(n_dev, "n_dev"),
+                            stream_of(h_in)),
+              "jlm_lstm_step");
+}
+
+// C[c_rows[m], n] = sum_k A[a_rows[m], k] * B[b_rows[n], k] + bias[n]; a_off / c_off / bias_off: element offsets of the
+// views inside their storage (a column range of T, of the logits, of b2)
+void gemm_nt(const Tensor &A, int64_t a_off, int64_t lda, const OptTensor &a_rows, const Tensor &B, int64_t ldb, const OptTensor &b_rows,
+             const Tensor &C, int64_t c_off, int64_t ldc, const OptTensor &c_rows, const OptTensor &bias, int64_t bias_off, int64_t M,
+             int64_t N, int64_t K, const OptTensor &m_dev) {
+    TORCH_CHECK(a_off >= 0 && a_off < A.numel() && c_off >= 0 && c_off < C.numel(), "jlm.gemm_nt: offset outside the tensor");
+    const float *bp = optr<const float>(bias, "bias");
+    jlm_check(jlm_gemm_nt(ptr<const float>(A, "A") + a_off, (int)lda, optr<const int>(a_rows, "a_rows"), ptr<const float>(B, "B"), (int)ldb,
+                          optr<const int>(b_rows, "b_rows"), ptr<float>(C, "C") + c_off, (int)ldc, optr<const int>(c_rows, "c_rows"),
+                          bp ? bp + bias_off : nullptr, (int)M, (int)N, (int)K, optr<const int>(m_dev, "m_dev"), stream_of(A)),
+              "jlm_gemm_nt");
+}
+
+void softmax_rows(const Tensor &y, const Tensor &pred, int64_t ld, int64_t n_rows, int64_t n_cols, bool self_norm) {
+    jlm_check(jlm_softmax_rows(ptr<const float>(y, "y"), ptr<float>(pred, "pred"), (int)ld, (int)n_rows, (int)n_cols, self_norm ? 1 : 0,
+                               stream_of(y)),
+              "jlm_softmax_rows");
+}
+
+// ------------------------------------------------------------------------------------ weight preparation
+void pack_split_f16(const Tensor &src, int64_t src_off, int64_t rows, int64_t k, int64_t ld, double scale, const Tensor &dst,
+                    int64_t dst_off, int64_t ld_dst) {
+    TORCH_CHECK(src_off >= 0 && src_off < src.numel() && dst_off >= 0 && dst_off < dst.numel(), "jlm.pack_split_f16: offset outside the tensor");
+    jlm_check(jlm_pack_split_f16(ptr<const float>(src, "src") + src_off, (int)rows, (int)k, (int)ld, (float)scale,
+                                 ptr<float>(dst, "dst") + dst_off, (int)ld_dst, stream_of(src)),
+              "jlm_pack_split_f16");
+}
+
+void pack_split_f16_col(const Tensor &v, int64_t v_off, int64_t rows, double scale, const Tensor &dst, int64_t ld_dst, int64_t col) {
+    TORCH_CHECK(v_off >= 0 && v_off + rows <= v.numel(), "jlm.pack_split_f16_col: range outside the vector");
+    jlm_check(jlm_pack_split_f16_col(ptr<const float>(v, "v") + v_off, (int)rows, (float)scale, ptr<float>(dst, "dst"), (int)ld_dst, (int)col,
+                                     stream_of(v)),
+              "jlm_pack_split_f16_col");
+}
+
+int64_t abi_version() { return jlm_abi_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(jlm, m) {
+    m.class_<JlmModel>("Model").def(
+        torch::init<TDict, IDict, FDict, std::vector<Tensor>, std::vector<int64_t>, std::vector<Tensor>, std::vector<int64_t>,
+                    std::vector<double>, std::vector<double>, std::vector<int64_t>>());
+    m.class_<JlmPlan>("Plan").def(torch::init<TDict, IDict>());
+    m.def("decode_frames(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, int n_frames, int vs_max, "
+          "int di_max, int dd_max, bool use_side, bool timed) -> int", decode_frames);
+    m.def("frame_times(__torch__.torch.classes.jlm.Plan plan) -> Tensor", frame_times);
+    m.def("lstm_step(Tensor h_in, Tensor c_in, int ld_state, Tensor(a!) h_out, Tensor(b!) c_out, Tensor? rows, Tensor prev, Tensor word, "
+          "Tensor emb, int ld_emb, Tensor wt, Tensor bias, int kpad, int H, int E, int n_rows_max, Tensor? n_dev) -> ()", lstm_step);
+    m.def("gemm_nt(Tensor A, int a_off, int lda, Tensor? a_rows, Tensor B, int ldb, Tensor? b_rows, Tensor(a!) C, int c_off, int ldc, "
+          "Tensor? c_rows, Tensor? bias, int bias_off, int M, int N, int K, Tensor? m_dev) -> ()", gemm_nt);
+    m.def("softmax_rows(Tensor y, Tensor(a!) pred, int ld, int n_rows, int n_cols, bool self_norm) -> ()", softmax_rows);
+    m.def("pack_split_f16(Tensor src, int src_off, int rows, int k, int ld, float scale, Tensor(a!) dst, int dst_off, int ld_dst) -> ()",
+          pack_split_f16);
+    m.def("pack_split_f16_col(Tensor v, int v_off, int rows, float scale, Tensor(a!) dst, int ld_dst, int col) -> ()", pack_split_f16_col);
+    m.def("abi_version() -> int", abi_version);
+}

@@ -11,11 +11,10 @@ Counterpart of ``LSTM_Model`` (reference decoder/model.py:36-198):
 
 Arrays at this boundary are numpy (float64, like the reference's); on the
 device everything is float32 and runs through the HIP kernels of
-libjlm_hip.so (exact-f32 MFMA).  :class:`DeviceModel` holds the packed weight
+libjlm_hip.so (exact-f32 MFMA), bound as torch custom ops (jlm_amd/ops.py).  :class:`DeviceModel` holds the packed weight
 panels in HBM and is shared with the batched decoders, which never come back
 to numpy between frames.
 """
-import ctypes
 import json
 import os
 import pickle
@@ -26,6 +25,7 @@ import numpy as np
 
 from . import _lib
 from . import config as _config
+from . import ops as _ops
 
 GATES = "ifog"
 
@@ -128,30 +128,6 @@ class _Stamp:
         if self.ev is not None:
             return self.ev.elapsed_time(other.ev) * 1e-3
         return other.t - self.t
-
-
-class KernelRecorder:
-    """HIP-event brackets around single kernel launches on the launching stream
-    (bench.py's live per-kernel durations).  Events are resolved after the run."""
-
-    def __init__(self, torch):
-        self.torch = torch
-        self.spans = {}
-        self._open = {}
-
-    def begin(self, name):
-        e = self.torch.cuda.Event(enable_timing=True)
-        e.record()
-        self._open[name] = e
-
-    def end(self, name):
-        e = self.torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.spans.setdefault(name, []).append((self._open.pop(name), e))
-
-    def durations_ms(self):
-        """name -> list of per-launch milliseconds (call after a synchronize)."""
-        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.spans.items()}
 
 
 def _sync(torch, device):
@@ -278,10 +254,6 @@ class DeviceModel:
         self.n_vocab_tiles = sum((sg["v_end"] - sg["v_start"] + 127) // 128 for sg in self.segments)
         self.stationary_ok = all(sg["k"] <= 256 for sg in self.segments)
         self.flops_per_row_vocab = sum(2.0 * sg["k"] * (sg["v_end"] - sg["v_start"]) for sg in self.segments)
-        arr = (_lib.Segment * len(self.segments))()
-        for i, sg in enumerate(self.segments):
-            arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], sg["k"], sg["t_off"], self.seg_B[i].data_ptr(), sg["ldb"])
-        self.seg_array = arr
         self.n_segs = len(self.segments)
         # --- split-f16 copies of the output embeddings (include/jlm_hip.h "f16x3"): the vocabulary
         #     reduction then runs on the f16 matrix pipe with f32-grade products.  JLM_PRECISION=f32
@@ -289,7 +261,7 @@ class DeviceModel:
         self.precision = os.environ.get("JLM_PRECISION", "f16x3")
         if self.precision not in ("f16x3", "f32"):
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
-        self.split_array = None
+        self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
         self.split_lstm = False
         if self.stationary_ok and self.precision == "f16x3":
             self._build_split(None if self.pmt is None else np.abs(pmt).sum(axis=1))
@@ -299,188 +271,131 @@ class DeviceModel:
         <= 2^14, 2^eT puts the largest value a T column can take (|h| < 1, so |T_j| <= sum_i |PM_ij|)
         times log2(e) at <= 2^15 -- both inside the f16 range with their low halves out of the
         subnormals."""
-        import ctypes
-        torch, L = self.torch, _lib.lib()
+        torch, O = self.torch, _ops.backend()
         n = self.n_segs
-        arr = (_lib.Segment * n)()
-        self.split_t_scale, self.split_descale = (ctypes.c_float * n)(), (ctypes.c_float * n)()
-        self.seg_split = []
+        self.split_t_scale, self.split_descale, self.split_bias_col = [], [], []
+        self.seg_split, self.split_segments = [], []
 
         def pow2_below(limit, value):
             if not (value > 0.0) or not np.isfinite(value):
                 return 0
             return int(np.clip(np.floor(np.log2(limit / value)), -40, 40))
 
-        self.split_bias_col = (ctypes.c_int * n)()
-        for i, sg in enumerate(self.segments):
-            nv, k = sg["v_end"] - sg["v_start"], sg["k"]
-            k16 = _pad(k, 16)
-            # a segment with a spare (padded) column carries its bias there: b2 * 2^eB against a constant
-            # 1.0 on the T side, so the kernel's fold has no bias add
-            bias_col = k if (k % 16 != 0 and nv > 0) else -1
-            b2seg = self.b2[sg["v_start"]:sg["v_end"]]
-            bmax = float(self.seg_B[i].abs().max().item()) if nv else 0.0
-            if bias_col >= 0:
-                bmax = max(bmax, float(b2seg.abs().max().item()))
-            eB = pow2_below(2.0 ** 14, bmax)
-            tb = 1.0 if t_bound is None else float(t_bound[sg["t_off"]:sg["t_off"] + k].max())
-            if bias_col >= 0:
-                tb = max(tb, 1.0)
-            eT = pow2_below(2.0 ** 15, tb * 1.4426950408889634)
-            dst = torch.zeros((max(nv, 1), k16), dtype=torch.float32, device=self.device)
-            strm = self.stream() if self.device.type == "cuda" else None
-            _lib.check(L.jlm_pack_split_f16(self.seg_B[i].data_ptr(), nv, k, sg["ldb"], float(2.0 ** eB), dst.data_ptr(), k16,
-                                            strm), "jlm_pack_split_f16")
-            if bias_col >= 0:
-                _lib.check(L.jlm_pack_split_f16_col(b2seg.data_ptr(), nv, float(2.0 ** eB), dst.data_ptr(), k16, bias_col,
-                                                    strm), "jlm_pack_split_f16_col")
-            self.split_bias_col[i] = bias_col
-            self.seg_split.append(dst)
-            arr[i] = _lib.Segment(sg["v_start"], sg["v_end"], k, sg["t_off"], dst.data_ptr(), k16)
-            self.split_t_scale[i] = 2.0 ** eT
-            self.split_descale[i] = 2.0 ** -(eT + eB)
-        self.split_array = arr
-        # --- the LSTM step and the T projection on split rows (tied / D-softmax / V-table models; an
-        #     untied model's T is the state itself and its k = H > 256 reduction stays on the f32 pipe)
-        self.split_lstm = self.pmt is not None
-        if self.split_lstm:
-            H, st = self.H, (self.stream() if self.device.type == "cuda" else None)
-            wh = self._wmax[0]
-            self.h_scale = 2.0 ** 14                                   # |h| < 1
-            # input side of the gates as a table: xgate[w] = emb[w] . W_x^T + b (f64 product, rounded once),
-            # [V, 4H] f32 in the packed column order -- 410 MB at V = 50k, H = 512 out of 288 GB; the step's
-            # GEMM then contracts over the state only (a third less staging traffic, which is what it is
-            # bound by) and the epilogue adds one gathered row per hypothesis
-            S = 14 + pow2_below(2.0 ** 14, wh)
-            # gate-interleave-8 row order of jlm_lstm_step_xg: a 32-row MFMA block = the four gates of eight units
-            u = np.arange(H)
-            perm8 = np.empty(4 * H, dtype=np.int64)
-            for gi in range(4):
-                perm8[(u // 8) * 32 + gi * 8 + (u % 8)] = (u // 16) * 64 + gi * 16 + (u % 16)
-            wt_host = self.wt.cpu().numpy()
-            # float64 product on the host (the reference's own arithmetic, np.dot), rounded once, pre-multiplied by
-            # 2^S = 1 / descale so that a table row is the accumulators' start value
-            wx = wt_host[perm8, H:H + self.Epad].astype(np.float64)
-            xg = self.emb.cpu().numpy().astype(np.float64) @ wx.T
-            xg += self.gate_bias.cpu().numpy().astype(np.float64)[perm8]
-            xg *= 2.0 ** S
-            self.xgate8 = torch.from_numpy(xg.astype(np.float32)).to(self.device)
-            del xg, wx
-            self.kpad_split = H
-            wt8 = torch.from_numpy(np.ascontiguousarray(wt_host[perm8, :H])).to(self.device)
-            self.wt8 = torch.zeros((4 * H, H), dtype=torch.float32, device=self.device)
-            _lib.check(L.jlm_pack_split_f16(wt8.data_ptr(), 4 * H, H, H, float(2.0 ** (S - 14)),
-                                            self.wt8.data_ptr(), H, st), "jlm_pack_split_f16(W_h)")
-            if self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)      # wt8's source goes out of scope
-            del wt8
-            self.gate_descale = 2.0 ** -S
-            eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
-            self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
-            _lib.check(L.jlm_pack_split_f16(self.pmt.data_ptr(), self.pmt.shape[0], H, H, float(2.0 ** eP),
-                                            self.pmt_split.data_ptr(), H, st), "jlm_pack_split_f16(PM)")
-            self.t_descale = 2.0 ** -(14 + eP)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-
-    def decode_desc(self):
-        """jlm_decode_model of this model (include/jlm_hip.h): what jlm_decode_frames needs to enqueue
-        the frame loop by itself.  The arrays it points into stay owned by this object."""
-        d = getattr(self, "_decode_desc", None)
-        if d is None:
-            ptr = lambda t: t.data_ptr() if t is not None else None
-            d = _lib.DecodeModel()
-            d.segs, d.n_segs, d.b2 = self.seg_array, self.n_segs, self.b2.data_ptr()
-            d.H, d.ldt = self.H, self.ldt
-            d.untied, d.self_norm, d.split_lstm = int(self.mode == "untied"), int(self.self_norm), int(self.split_lstm)
-            d.emb, d.ld_emb, d.wt, d.gate_bias = self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr()
-            d.kpad, d.E = self.kpad, self.Epad
+        with self._ctx():
+            for i, sg in enumerate(self.segments):
+                nv, k = sg["v_end"] - sg["v_start"], sg["k"]
+                k16 = _pad(k, 16)
+                # a segment with a spare (padded) column carries its bias there: b2 * 2^eB against a constant
+                # 1.0 on the T side, so the kernel's fold has no bias add
+                bias_col = k if (k % 16 != 0 and nv > 0) else -1
+                b2seg = self.b2[sg["v_start"]:sg["v_end"]]
+                bmax = float(self.seg_B[i].abs().max().item()) if nv else 0.0
+                if bias_col >= 0:
+                    bmax = max(bmax, float(b2seg.abs().max().item()))
+                eB = pow2_below(2.0 ** 14, bmax)
+                tb = 1.0 if t_bound is None else float(t_bound[sg["t_off"]:sg["t_off"] + k].max())
+                if bias_col >= 0:
+                    tb = max(tb, 1.0)
+                eT = pow2_below(2.0 ** 15, tb * 1.4426950408889634)
+                dst = torch.zeros((max(nv, 1), k16), dtype=torch.float32, device=self.device)
+                if nv:
+                    O.pack_split_f16(self.seg_B[i], 0, nv, k, sg["ldb"], float(2.0 ** eB), dst, 0, k16)
+                    if bias_col >= 0:
+                        O.pack_split_f16_col(self.b2, sg["v_start"], nv, float(2.0 ** eB), dst, k16, bias_col)
+                self.split_bias_col.append(bias_col)
+                self.seg_split.append(dst)
+                self.split_segments.append(dict(v_start=sg["v_start"], v_end=sg["v_end"], k=k, t_off=sg["t_off"], ldb=k16))
+                self.split_t_scale.append(2.0 ** eT)
+                self.split_descale.append(2.0 ** -(eT + eB))
+            self.split_array = list(zip(self.split_segments, self.seg_split))
+            # --- the LSTM step and the T projection on split rows (tied / D-softmax / V-table models; an
+            #     untied model's T is the state itself and its k = H > 256 reduction stays on the f32 pipe)
+            self.split_lstm = self.pmt is not None
             if self.split_lstm:
-                d.wt8, d.xgate8, d.kpad_split = self.wt8.data_ptr(), self.xgate8.data_ptr(), self.kpad_split
-                d.gate_descale, d.h_scale = self.gate_descale, self.h_scale
-                d.pmt_split, d.t_descale = self.pmt_split.data_ptr(), self.t_descale
-            d.pmt, d.n_t = ptr(self.pmt), (self.pmt.shape[0] if self.pmt is not None else 0)
+                H = self.H
+                wh = self._wmax[0]
+                self.h_scale = 2.0 ** 14                                   # |h| < 1
+                # input side of the gates as a table: xgate[w] = emb[w] . W_x^T + b for every vocabulary word, [V, 4H] f32
+                # -- 410 MB at V = 50k, H = 512 out of 288 GB; the step's GEMM then contracts over the state only (a third
+                # less staging traffic, which is what it is bound by) and the epilogue adds one gathered row per hypothesis
+                S = 14 + pow2_below(2.0 ** 14, wh)
+                # gate-interleave-8 row order of jlm_lstm_step_xg: a 32-row MFMA block = the four gates of eight units
+                u = np.arange(H)
+                perm8 = np.empty(4 * H, dtype=np.int64)
+                for gi in range(4):
+                    perm8[(u // 8) * 32 + gi * 8 + (u % 8)] = (u // 16) * 64 + gi * 16 + (u % 16)
+                wt_host = self.wt.cpu().numpy()
+                # float64 product on the host (the reference's own arithmetic, np.dot), rounded once, pre-multiplied by
+                # 2^S = 1 / descale: the kernel adds a table row to its accumulators before descaling
+                wx = wt_host[perm8, H:H + self.Epad].astype(np.float64)
+                xg = self.emb.cpu().numpy().astype(np.float64) @ wx.T
+                xg += self.gate_bias.cpu().numpy().astype(np.float64)[perm8]
+                xg *= 2.0 ** S
+                self.xgate8 = torch.from_numpy(xg.astype(np.float32)).to(self.device)
+                del xg, wx
+                self.kpad_split = H
+                wt8 = torch.from_numpy(np.ascontiguousarray(wt_host[perm8, :H])).to(self.device)
+                self.wt8 = torch.zeros((4 * H, H), dtype=torch.float32, device=self.device)
+                O.pack_split_f16(wt8, 0, 4 * H, H, H, float(2.0 ** (S - 14)), self.wt8, 0, H)
+                self.gate_descale = 2.0 ** -S
+                eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
+                self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
+                O.pack_split_f16(self.pmt, 0, self.pmt.shape[0], H, H, float(2.0 ** eP), self.pmt_split, 0, H)
+                self.t_descale = 2.0 ** -(14 + eP)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)      # wt8's source goes out of scope
+                del wt8
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+
+    def _ctx(self):
+        """every launch of this model happens with ITS device current (streams, events and the launches of the HIP runtime
+        follow the current device, not the tensors')"""
+        if self.device.type == "cuda":
+            return self.torch.cuda.device(self.device)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def decode_model(self):
+        """torch.classes.jlm.Model of this model (jlm_decode_model, include/jlm_hip.h): what the frame-loop op needs to
+        enqueue a whole batch by itself.  The object keeps the tensors it points into alive."""
+        d = getattr(self, "_decode_model", None)
+        if d is None:
+            O = _ops.backend()
+            t = dict(b2=self.b2, emb=self.emb, wt=self.wt, gate_bias=self.gate_bias)
+            i = dict(H=self.H, ldt=self.ldt, untied=int(self.mode == "untied"), self_norm=int(self.self_norm),
+                     split_lstm=int(self.split_lstm), ld_emb=self.Epad, kpad=self.kpad, E=self.Epad,
+                     n_t=(self.pmt.shape[0] if self.pmt is not None else 0))
+            f = {}
+            if self.pmt is not None:
+                t["pmt"] = self.pmt
+            if self.split_lstm:
+                t.update(wt8=self.wt8, xgate8=self.xgate8, pmt_split=self.pmt_split)
+                i["kpad_split"] = self.kpad_split
+                f.update(gate_descale=self.gate_descale, h_scale=self.h_scale, t_descale=self.t_descale)
+            meta = lambda segs: [int(sg[k]) for sg in segs for k in ("v_start", "v_end", "k", "t_off", "ldb")]
             if self.split_array is not None:
-                d.split_segs = self.split_array
-                d.split_t_scale = ctypes.cast(self.split_t_scale, ctypes.POINTER(ctypes.c_float))
-                d.split_descale = ctypes.cast(self.split_descale, ctypes.POINTER(ctypes.c_float))
-                d.split_bias_col = ctypes.cast(self.split_bias_col, ctypes.POINTER(ctypes.c_int))
-            self._decode_desc = d
+                sp = (list(self.seg_split), meta(self.split_segments), [float(x) for x in self.split_t_scale],
+                      [float(x) for x in self.split_descale], [int(x) for x in self.split_bias_col])
+            else:
+                sp = ([], [], [], [], [])
+            d = self._decode_model = O.Model(t, i, f, list(self.seg_B), meta(self.segments), *sp)
         return d
 
-    # -- enqueue helpers (all on torch's current HIP stream) ------------------
-    def stream(self):
-        return self.torch.cuda.current_stream().cuda_stream
+    # -- launch helpers of LSTM_Model.predict / project (f32 operands, torch's current stream) --------------------
+    def lstm_step(self, h_in, c_in, h_out, c_out, prev, word, n_rows):
+        """One fused LSTM step on plain f32 state rows (K1+K2+K3, model.py:125-139); the decode engine's step runs
+        inside the frame-loop op on split rows."""
+        _ops.backend().lstm_step(h_in, c_in, self.H, h_out, c_out, None, prev, word, self.emb, self.Epad, self.wt, self.gate_bias,
+                                 self.kpad, self.H, self.Epad, n_rows, None)
 
-    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, n_rows_max, n_dev, stream, rec=None, split=False):
-        """One fused LSTM step.  split=True: h_in / h_out hold SPLIT ROWS of the state (the decode
-        engine's layout when self.split_lstm); otherwise plain f32 (LSTM_Model.predict)."""
-        L = _lib.lib()
-        if rec is not None:
-            rec.begin("gate_gemm")
-        if split:
-            _lib.check(L.jlm_lstm_step_xg(h_in, c_in, ld, h_out, c_out, rows, prev, word, self.wt8.data_ptr(),
-                                          self.xgate8.data_ptr(), self.H, self.gate_descale, self.h_scale, n_rows_max, n_dev,
-                                          stream), "jlm_lstm_step_xg")
-        else:
-            _lib.check(L.jlm_lstm_step(h_in, c_in, ld, h_out, c_out, rows, prev, word,
-                                       self.emb.data_ptr(), self.Epad, self.wt.data_ptr(), self.gate_bias.data_ptr(),
-                                       self.kpad, self.H, self.Epad, n_rows_max, n_dev, stream), "jlm_lstm_step")
-        if rec is not None:
-            rec.end("gate_gemm")
-
-    def project_T(self, h, ldh, T, rows, n_rows_max, n_dev, stream, split=False):
-        """T[g] = h[g].[PM | PM.VT_i^T ...]: one GEMM.  No-op for untied models
-        (T aliases h there).  split=True: h holds split rows."""
+    def project_T(self, h, T, n_rows):
+        """T[r] = h[r].[PM | PM.VT_i^T ...]: one GEMM (model.py:145,162,175-177,184-186).  No-op for untied models
+        (T aliases h there)."""
         if self.mode == "untied":
             return
-        L = _lib.lib()
-        n_t = self.pmt.shape[0]
-        if split:
-            _lib.check(L.jlm_gemm_nt_split(h, ldh, rows, self.pmt_split.data_ptr(), self.H, None, T, self.ldt, rows, None,
-                                           self.t_descale, n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt_split(PM)")
-        else:
-            _lib.check(L.jlm_gemm_nt(h, ldh, rows, self.pmt.data_ptr(), self.H, None, T, self.ldt, rows, None,
-                                     n_rows_max, n_t, self.H, n_dev, stream), "jlm_gemm_nt(PM)")
-
-    def full_vocab_lse(self, T, rows, part, ld_part, max_parts, lse, n_rows_max, n_dev, stream, rec=None, combine=True):
-        """lse[g] over the full vocabulary for the listed rows (K5+K6 fused).
-        Rows-stationary kernel when every segment's k <= 256, else one tile GEMM
-        per segment.  combine=False leaves the partial slices for jlm_beam_step to
-        fold (jlm_beam_state.lse_part); returns the number of slices."""
-        L = _lib.lib()
-        if self.stationary_ok:
-            if rec is not None:
-                rec.begin("vocab_lse")
-            if self.split_array is not None:
-                r = L.jlm_vocab_lse_split(self.split_array, self.split_t_scale, self.split_descale, self.split_bias_col,
-                                          self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part, ld_part, max_parts,
-                                          n_rows_max, n_dev, stream)
-            else:
-                r = L.jlm_vocab_lse_stationary(self.seg_array, self.n_segs, self.b2.data_ptr(), T, self.ldt, rows, part,
-                                               ld_part, max_parts, n_rows_max, n_dev, stream)
-            if rec is not None:
-                rec.end("vocab_lse")
-            if r < 0:
-                raise _lib.JlmHipError("rows-stationary vocabulary LSE failed with code %d" % r)
-            n_parts = r
-        else:
-            n_parts = 0
-            for i, sg in enumerate(self.segments):
-                nv = sg["v_end"] - sg["v_start"]
-                if rec is not None:
-                    rec.begin("vocab_lse")
-                r = L.jlm_vocab_lse_partials(self.seg_B[i].data_ptr(), sg["ldb"], nv, sg["k"], T + 4 * sg["t_off"],
-                                             self.ldt, rows, self.b2.data_ptr() + 4 * sg["v_start"], part, ld_part,
-                                             n_parts, n_rows_max, n_dev, stream)
-                if rec is not None:
-                    rec.end("vocab_lse")
-                if r < 0:
-                    raise _lib.JlmHipError("jlm_vocab_lse_partials failed with code %d" % r)
-                n_parts += r
-        if combine:
-            _lib.check(L.jlm_lse_combine(part, ld_part, n_parts, rows, lse, n_rows_max, n_dev, stream), "jlm_lse_combine")
-        return n_parts
+        _ops.backend().gemm_nt(h, 0, self.H, None, self.pmt, self.H, None, T, 0, self.ldt, None, None, 0, n_rows,
+                               self.pmt.shape[0], self.H, None)
 
 
 class LSTM_Model():
@@ -498,7 +413,7 @@ class LSTM_Model():
         self.hidden = np.zeros((1, self.hidden_size))
         self.cell = np.zeros((1, self.hidden_size))
         self.device = device if device is not None else _lib.require_gpu()
-        _lib.lib()
+        _ops.backend()
         self.dev = DeviceModel(self.config, self.weights, self.blocks, self.v_tables, self.device)
 
     # ------------------------------------------------------------------ helpers
@@ -526,8 +441,7 @@ class LSTM_Model():
         """Materialised logits [n_rows, n_cols] float32 on the device (K5a-K5e)."""
         torch = self.dev.torch
         d = self.dev
-        L = _lib.lib()
-        st = d.stream()
+        O = _ops.backend()
         plan, bias_ids = self._segment_columns(vocab)
         if d.mode == "untied" and vocab:
             # model.py:189: UM[vocab] indexes ROWS of UM[H, V]; kept as the reference's behaviour
@@ -539,22 +453,18 @@ class LSTM_Model():
         else:
             bias_all = d.b2
         c0 = 0
-        keep = []
         for i, ids in plan:
             sg = d.segments[i]
             if ids is None:
                 n, bmap = sg["v_end"] - sg["v_start"], None
             else:
                 n = len(ids)
-                bm = torch.as_tensor([v - sg["v_start"] for v in ids], device=self.device, dtype=torch.int32)
-                keep.append(bm)
-                bmap = bm.data_ptr()
+                bmap = torch.as_tensor([v - sg["v_start"] for v in ids], device=self.device, dtype=torch.int32)
             if n:
-                _lib.check(L.jlm_gemm_nt(T.data_ptr() + 4 * sg["t_off"], ldt, None, d.seg_B[i].data_ptr(), sg["ldb"], bmap,
-                                         y.data_ptr() + 4 * c0, y.shape[1], None, bias_all.data_ptr() + 4 * c0,
-                                         n_rows, n, sg["k"], None, st), "jlm_gemm_nt(logits)")
+                O.gemm_nt(T, sg["t_off"], ldt, None, d.seg_B[i], sg["ldb"], bmap, y, c0, y.shape[1], None, bias_all, c0,
+                          n_rows, n, sg["k"], None)
             c0 += n
-        return y, n_cols, keep
+        return y, n_cols
 
     def _project_dev(self, hdev, n_rows, vocab):
         torch = self.dev.torch
@@ -563,7 +473,7 @@ class LSTM_Model():
             T, ldt = hdev, d.H
         else:
             T = torch.empty((n_rows, d.ldt), device=self.device, dtype=torch.float32)
-            d.project_T(hdev.data_ptr(), d.H, T.data_ptr(), None, n_rows, None, d.stream())
+            d.project_T(hdev, T, n_rows)
             ldt = d.ldt
         return self._logits_from_T(T, ldt, n_rows, vocab)
 
@@ -574,7 +484,6 @@ class LSTM_Model():
             self.cell = np.zeros(shape=self.cell.shape)
         torch = self.dev.torch
         d = self.dev
-        L = _lib.lib()
         index = [int(i) for i in index]
         R = len(index)
         hid = np.asarray(self.hidden, dtype=np.float64)
@@ -588,22 +497,20 @@ class LSTM_Model():
                 R = len(index)
             else:
                 raise ValueError("operands could not be broadcast together with shapes {} ({},)".format(hid.shape, R))
-        ev0, ev1, ev2 = (_Stamp(torch, self.device) for _ in range(3))
-        h_in, c_in = self._to_dev(hid), self._to_dev(cel)
-        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
-        ident = torch.arange(R, device=self.device, dtype=torch.int32)
-        word = torch.as_tensor(index, device=self.device, dtype=torch.int32)
-        st = d.stream()
-        ev0.record()
-        d.lstm_step(h_in.data_ptr(), c_in.data_ptr(), d.H, h_out.data_ptr(), c_out.data_ptr(), None, ident.data_ptr(),
-                    word.data_ptr(), R, None, st)
-        ev1.record()
-        y, n_cols, _keep = self._project_dev(h_out, R, vocab)
-        pred = torch.empty_like(y)
-        _lib.check(L.jlm_softmax_rows(y.data_ptr(), pred.data_ptr(), y.shape[1], R, n_cols,
-                                      1 if self.config['self_norm'] else 0, st), "jlm_softmax_rows")
-        ev2.record()
-        _sync(torch, self.device)
+        with d._ctx():
+            ev0, ev1, ev2 = (_Stamp(torch, self.device) for _ in range(3))
+            h_in, c_in = self._to_dev(hid), self._to_dev(cel)
+            h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+            ident = torch.arange(R, device=self.device, dtype=torch.int32)
+            word = torch.as_tensor(index, device=self.device, dtype=torch.int32)
+            ev0.record()
+            d.lstm_step(h_in, c_in, h_out, c_out, ident, word, R)
+            ev1.record()
+            y, n_cols = self._project_dev(h_out, R, vocab)
+            pred = torch.empty_like(y)
+            _ops.backend().softmax_rows(y, pred, y.shape[1], R, n_cols, bool(self.config['self_norm']))
+            ev2.record()
+            _sync(torch, self.device)
         self.hidden = h_out.double().cpu().numpy()
         self.cell = c_out.double().cpu().numpy()
         y_np = y[:, :n_cols].double().cpu().numpy()
@@ -614,8 +521,9 @@ class LSTM_Model():
         hid = np.asarray(hidden, dtype=np.float64)
         if hid.ndim == 1:
             hid = hid[None, :]
-        y, n_cols, _keep = self._project_dev(self._to_dev(hid), hid.shape[0], vocab)
-        _sync(self.dev.torch, self.device)
+        with self.dev._ctx():
+            y, n_cols = self._project_dev(self._to_dev(hid), hid.shape[0], vocab)
+            _sync(self.dev.torch, self.device)
         return y[:, :n_cols].double().cpu().numpy()
 
     def predict_with_context(self, index, hidden, cell, vocab=None):

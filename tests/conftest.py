@@ -20,7 +20,7 @@ def pytest_configure(config):
     # The built libraries are git-ignored; on a tree that has none yet, build them once (hipcc cross-compiles
     # gfx950 without a GPU).  An existing build is left alone: rebuilding is __graft_entry__.build()'s job.
     built = [os.path.join(REPO, "jlm_amd", "csrc", "libjlm_hip.so"), os.path.join(REPO, "jlm_amd", "csrc", "libjlm_host.so"),
-             os.path.join(REPO, "jlm_amd", "_readout.so")]
+             os.path.join(REPO, "jlm_amd", "_readout.so"), os.path.join(REPO, "jlm_amd", "_torch_ops.so")]
     if not all(os.path.exists(b) for b in built):
         try:
             import __graft_entry__ as ge

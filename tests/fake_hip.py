@@ -46,7 +46,7 @@ class FakeLib:
         return 4
 
     # ------------------------------------------------------- the frame loop (ABI 3)
-    def jlm_decode_frames(self, m, p, lat, st, stream, side_stream):
+    def jlm_decode_frames(self, m, p, lat, st, stream, side_stream, events=None):
         """Same call order as jlm_amd/csrc/jlm_decode.hip, over the doubles below: checks that the
         engine fills jlm_decode_model / jlm_decode_plan the way the individual calls were fed."""
         B, beam, F = lat.n_sent, lat.beam, lat.n_frames
@@ -55,8 +55,7 @@ class FakeLib:
         mode = 1 if m.self_norm else (2 if dynamic else 0)
         split = bool(m.split_segs)
         wl_split = split and m.n_segs == 1 and beam <= 32
-        if full and not m.self_norm and any(m.segs[i].k > 256 for i in range(m.n_segs)):
-            return -2
+        tile_form = full and not m.self_norm and any(m.segs[i].k > 256 for i in range(m.n_segs))
         off = lambda base, n: (base or 0) + 4 * n
 
         def wl_lse(g0, cidx, words, woff, idx, base, merge, n_groups, max_words):
@@ -120,6 +119,18 @@ class FakeLib:
                     r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.di_words, p.di_off, p.di_idx, 2 * cell, 0, B, p.di_max)
                 elif select:
                     r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.vs_words, p.vs_off, p.sidx, 0, 0, B, p.vs_max)
+                elif tile_form:
+                    n_parts = 0
+                    for i in range(m.n_segs):
+                        sg = m.segs[i]
+                        r = self.jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, off(p.T, sg.t_off), m.ldt,
+                                                        rows, off(m.b2, sg.v_start), p.part, rmax, n_parts, rmax, ndev, stream)
+                        if r < 0:
+                            return r
+                        n_parts += r
+                    if n_parts > p.max_parts:
+                        return -1
+                    pending, r = n_parts, 0
                 else:
                     bound = B if f == 0 else rmax
                     if split:
@@ -675,25 +686,139 @@ class FakeLib:
         return 0
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The package talks to torch custom ops (jlm_amd/ops.py -> csrc/jlm_torch_ops.cpp).  FakeOps is the CPU double of THAT
+# interface: it does what the C++ shim does -- turn tensor arguments into the C structs and pointers of include/jlm_hip.h
+# -- and hands them to the numpy double of the C ABI above, so the host code is driven through the same two layers.
+class _FakeModel:
+    def __init__(self, t, i, f, seg_B, seg_meta, split_B, split_meta, t_scale, descale, bias_col):
+        from jlm_amd import _lib
+        self.keep = (t, list(seg_B), list(split_B))
+
+        def segs(B, meta):
+            arr = (_lib.Segment * max(len(B), 1))()
+            for k, b in enumerate(B):
+                arr[k] = _lib.Segment(*[int(x) for x in meta[5 * k:5 * k + 4]], b.data_ptr(), int(meta[5 * k + 4]))
+            return arr
+        self.segs, self.split = segs(seg_B, seg_meta), segs(split_B, split_meta)
+        self.ts = (ctypes.c_float * max(len(t_scale), 1))(*t_scale)
+        self.ds = (ctypes.c_float * max(len(descale), 1))(*descale)
+        self.bc = (ctypes.c_int * max(len(bias_col), 1))(*bias_col)
+        ptr = lambda k: t[k].data_ptr() if k in t else None
+        m = self.m = _lib.DecodeModel()
+        m.segs, m.n_segs, m.b2 = self.segs, len(seg_B), ptr("b2")
+        m.H, m.ldt = i["H"], i["ldt"]
+        m.untied, m.self_norm, m.split_lstm = i.get("untied", 0), i.get("self_norm", 0), i.get("split_lstm", 0)
+        m.emb, m.ld_emb, m.wt, m.gate_bias = ptr("emb"), i.get("ld_emb", 0), ptr("wt"), ptr("gate_bias")
+        m.kpad, m.E, m.kpad_split = i.get("kpad", 0), i.get("E", 0), i.get("kpad_split", 0)
+        m.gate_descale, m.h_scale, m.t_descale = f.get("gate_descale", 0.0), f.get("h_scale", 0.0), f.get("t_descale", 0.0)
+        m.wt8, m.xgate8, m.pmt, m.pmt_split, m.n_t = ptr("wt8"), ptr("xgate8"), ptr("pmt"), ptr("pmt_split"), i.get("n_t", 0)
+        if len(split_B):
+            m.split_segs = self.split
+            m.split_t_scale = ctypes.cast(self.ts, ctypes.POINTER(ctypes.c_float))
+            m.split_descale = ctypes.cast(self.ds, ctypes.POINTER(ctypes.c_float))
+            m.split_bias_col = ctypes.cast(self.bc, ctypes.POINTER(ctypes.c_int))
+
+
+class _FakePlan:
+    def __init__(self, t, i):
+        from jlm_amd import _lib
+        self.keep = t
+        base = t["ints"].data_ptr()
+        at = lambda name: base + 4 * i["off_" + name]
+        ptr = lambda k: t[k].data_ptr() if k in t else None
+        self.frames = i["frames"]
+        self.lat = _lib.Lattice(i["n_sent"], i["beam"], 0, at("sent_len"), at("end_off"), at("node_start"), at("node_word"))
+        self.st = _lib.BeamState(ptr("score"), ptr("lse"), ptr("ysum"), ptr("bp"), ptr("node"), ptr("word"), ptr("cnt"),
+                                 ptr("live"), ptr("n_live"), ptr("edge"), ptr("live_base"), None, 0, 0)
+        d = self.p = _lib.DecodePlan()
+        d.kind, d.max_cands = i["kind"], i["max_cands"]
+        d.h, d.c, d.T = ptr("h"), ptr("c"), ptr("T")
+        d.g0, d.cidx, d.sidx = at("g0"), at("cidx"), at("sidx")
+        d.sg_word, d.sg_off, d.sg_node, d.edge = at("sg_word"), at("sg_off"), at("sg_node"), ptr("edge")
+        d.vs_words, d.vs_off = at("vs_words"), at("vs_off")
+        d.di_words, d.di_off, d.di_idx = at("di_words"), at("di_off"), at("sidx2")
+        d.dd_words, d.dd_off = at("dd_words"), at("dd_off")
+        d.run_max, d.run_sum, d.part, d.max_parts = ptr("run_max"), ptr("run_sum"), ptr("part"), i["max_parts"]
+        d.out_nodes, d.out_len, d.out_score, d.stride = ptr("out_nodes"), ptr("out_len"), ptr("out_score"), i["stride"]
+        self.timed_frames = 0
+
+
+class FakeOps:
+    """CPU double of jlm_amd.ops.HipOps (same methods, tensors in)."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or FakeLib()
+        self.Model, self.Plan = _FakeModel, _FakePlan
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed with code %d" % (what, rc))
+
+    @staticmethod
+    def _o(t, off=0):
+        return None if t is None else t.data_ptr() + 4 * int(off)
+
+    def abi_version(self):
+        return self.lib.jlm_abi_version()
+
+    def decode_frames(self, model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed):
+        assert 1 <= n_frames <= plan.frames
+        plan.lat.n_frames = int(n_frames)
+        plan.p.vs_max, plan.p.di_max, plan.p.dd_max = int(vs_max), int(di_max), int(dd_max)
+        plan.timed_frames = int(n_frames) if timed else 0
+        rc = self.lib.jlm_decode_frames(model.m, plan.p, plan.lat, plan.st, 0, None, None)
+        if rc == -2:
+            return -2
+        self._chk(rc, "jlm_decode_frames")
+        return 0
+
+    def frame_times(self, plan):
+        import torch
+        return torch.full((plan.timed_frames, 5), 1e-3, dtype=torch.float64)
+
+    def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E, n_rows_max, n_dev):
+        o = self._o
+        self._chk(self.lib.jlm_lstm_step(o(h_in), o(c_in), ld, o(h_out), o(c_out), o(rows), o(prev), o(word), o(emb), ld_emb, o(wt),
+                                         o(bias), kpad, H, E, n_rows_max, o(n_dev), 0), "jlm_lstm_step")
+
+    def gemm_nt(self, A, a_off, lda, a_rows, B, ldb, b_rows, C, c_off, ldc, c_rows, bias, bias_off, M, N, K, m_dev):
+        o = self._o
+        self._chk(self.lib.jlm_gemm_nt(o(A, a_off), lda, o(a_rows), o(B), ldb, o(b_rows), o(C, c_off), ldc, o(c_rows),
+                                       o(bias, bias_off), M, N, K, o(m_dev), 0), "jlm_gemm_nt")
+
+    def softmax_rows(self, y, pred, ld, n_rows, n_cols, self_norm):
+        self._chk(self.lib.jlm_softmax_rows(self._o(y), self._o(pred), ld, n_rows, n_cols, int(bool(self_norm)), 0), "jlm_softmax_rows")
+
+    def pack_split_f16(self, src, src_off, rows, k, ld, scale, dst, dst_off, ld_dst):
+        self._chk(self.lib.jlm_pack_split_f16(self._o(src, src_off), rows, k, ld, scale, self._o(dst, dst_off), ld_dst, 0),
+                  "jlm_pack_split_f16")
+
+    def pack_split_f16_col(self, v, v_off, rows, scale, dst, ld_dst, col):
+        self._chk(self.lib.jlm_pack_split_f16_col(self._o(v, v_off), rows, scale, self._o(dst), ld_dst, col, 0),
+                  "jlm_pack_split_f16_col")
+
+
 def install(monkeypatch):
-    """Route jlm_amd's library handle and device checks to the CPU double."""
+    """Route jlm_amd's op backend, library handle and device checks to the CPU doubles."""
     import torch
-    from jlm_amd import _lib, model
+    from jlm_amd import _lib, ops
 
     fake = FakeLib()
     monkeypatch.setattr(_lib, "lib", lambda: fake)
     monkeypatch.setattr(_lib, "require_gpu", lambda: torch.device("cpu"))
-    monkeypatch.setattr(model.DeviceModel, "stream", lambda self: 0)
+    monkeypatch.setattr(ops, "_backend", FakeOps(fake))
     return fake
 
 
 def install_plain():
     """Same as install() for processes without a pytest monkeypatch (spawned ranks)."""
     import torch
-    from jlm_amd import _lib, model
+    from jlm_amd import _lib, ops
 
     fake = FakeLib()
     _lib.lib = lambda: fake
     _lib.require_gpu = lambda: torch.device("cpu")
-    model.DeviceModel.stream = lambda self: 0
+    ops.set_backend(FakeOps(fake))
     return fake

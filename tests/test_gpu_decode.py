@@ -134,23 +134,26 @@ def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
     ("small-vtable", "static", {}), ("small-tied", "static", {"vocab_select": True}),
     ("small-tied", "dynamic", {"vocab_select": True}), ("small-untied", "static", {}),
     ("small-tied-sn", "static", {})])
-def test_native_frame_loop_equals_call_by_call_loop(fixture, kind, kw, fx):
-    """jlm_decode_frames (one C call per batch) enqueues the same launches as the engine's Python loop:
-    same kernels, same operands -> identical n-best and bit-identical scores.  (An untied model's
-    full-vocabulary decode is outside the native call's shapes: it must fall back, not fail.)"""
+def test_timed_frame_loop_equals_fast_frame_loop(fixture, kind, kw, fx):
+    """torch.ops.jlm.decode_frames (one op per batch) in its two forms -- fast: alternating streams, edge logits on a side
+    stream; timed: one stream, HIP events around every frame's kernel groups (what eval.py's perf logs and bench.py's
+    per-kernel durations read) -- launches the same kernels on the same operands: identical n-best, bit-identical scores.
+    The untied model (k = H > 256: tile-form normaliser) runs inside the same op."""
     f = fx(fixture)
     dec = _decoder(f, kind)
     eng = dec._engine
     sents = synth.make_ragged_sentences(14, 1, 17, seed=91, alphabet=f["alphabet"])
-    if os.environ.get("JLM_NATIVE_LOOP", "1") == "0":
-        pytest.skip("the suite is running with JLM_NATIVE_LOOP=0")
-    assert eng.native_loop
+    dec.perf_timing = False
     a = dec.decode_batch(sents, beam_width=6, **kw)
-    eng.native_loop = False
+    dec.perf_timing = True
+    n0 = len(dec.perf_log_lstm)
     try:
         b = dec.decode_batch(sents, beam_width=6, **kw)
     finally:
-        eng.native_loop = True
+        dec.perf_timing = False
+    steps = max(len(s) for s in sents)
+    assert len(dec.perf_log_lstm) - n0 == steps and all(t > 0 for t in dec.perf_log_lstm[n0:])
+    assert len(eng.last_kernel_ms["gate_gemm"]) == steps and len(eng.last_fix_timing) == steps + 1
     for x, y in zip(a, b):
         assert [w for _, w in x] == [w for _, w in y]
         assert [v for v, _ in x] == [v for v, _ in y]
@@ -160,23 +163,23 @@ def test_native_frame_loop_equals_call_by_call_loop(fixture, kind, kw, fx):
                                              ("small-tied", "dynamic", {"vocab_select": True})])
 def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
     """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- two streams, side
-    streams, native frame loop, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
-    a time on one stream with the call-by-call loop.  Same kernels, same operands: bit-identical results."""
+    streams, frame-loop op, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
+    a time on one stream, timed (no side stream either).  Same kernels, same operands: bit-identical results."""
     f = fx(fixture)
     dec = _decoder(f, kind)
     eng = dec._engine
     dec.perf_timing = False
     sents = synth.make_ragged_sentences(24 * 48, 1, 22, seed=123, alphabet=f["alphabet"])
-    keep = (dec.max_batch, eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers)
+    keep = (dec.max_batch, eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers)
     try:
         dec.max_batch, dec.prefetch_workers = 48, 3
         fast = dec.decode_batch(sents, beam_width=8, **kw)
-        eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers = 1, False, 0, 1
+        eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = 1, True, 0, 1
         slow = []
         for i in range(0, len(sents), 48):
             slow.extend(dec.decode_batch(sents[i:i + 48], beam_width=8, **kw))
     finally:
-        dec.max_batch, eng.n_streams, eng.native_loop, dec.pipeline_depth, dec.prefetch_workers = keep
+        dec.max_batch, eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = keep
     assert len(fast) == len(slow) == len(sents)
     assert fast == slow
 
