@@ -241,20 +241,30 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
     // waves 4-7 (6 MFMAs) after their MFMAs, so one is on the matrix pipe while the other pays the DMA issue cost.
     constexpr bool DMA_FIRST = (NP == 4);
     Frag fa, fb;
+    // issue order of a half step: ONE fragment read behind every MFMA (tools/probes/gate_loop.hip: the 2 + 2 NB reads grouped in
+    // front of the MFMAs cost 12 % of the k-step, interleaved 1:1 they are free)
+    auto interleave = [&](bool with_reads) {
+#pragma unroll
+        for (int i = 0; i < 3 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (with_reads && i < 2 + 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto kstep = [&](auto has_next, auto vm, auto do_issue, int kt) {
+        __builtin_amdgcn_sched_barrier(0);
         read_half(kt, 1, fb);
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(fa);
-        __builtin_amdgcn_sched_barrier(0);
+        interleave(true);
         touch(fb);
         if constexpr (decltype(has_next)::value) {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(decltype(vm)::value) : "memory");
             if constexpr (DMA_FIRST && decltype(do_issue)::value) issue(kt & 3);
+            __builtin_amdgcn_sched_barrier(0);
             read_half(kt + 1, 0, fa);
         }
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(fb);
-        __builtin_amdgcn_sched_barrier(0);
+        interleave(decltype(has_next)::value);
         if constexpr (!DMA_FIRST && decltype(do_issue)::value) issue(kt & 3);
         if constexpr (decltype(has_next)::value) touch(fa);
     };

@@ -24,6 +24,9 @@
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
 #define split8 jlm_split8
+#ifndef JLM_LSE_PRIO
+#define JLM_LSE_PRIO 0
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // f32 [rows, k] (ld) -> split rows (stride ld_dst 4-byte units): the blocks covering k rounded up to
@@ -258,6 +261,9 @@ __device__ __forceinline__ void lse_split_body(
     __syncthreads();
     JLM_PROF_MARK(p_t2);
     int buf = 0;
+#if JLM_LSE_PRIO == 2
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef JLM_TILETRACE
     int tt_n = 0;
     const int tt_cls = NS <= 4 ? 2 : (NS <= 7 ? 1 : 0);
@@ -269,6 +275,9 @@ __device__ __forceinline__ void lse_split_body(
         const bool tt_on = tt_wg && t == vt0 + 3;
 #endif
         JLM_TT(1);
+#if JLM_LSE_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool last_c = (c == NC - 1);
@@ -301,18 +310,28 @@ __device__ __forceinline__ void lse_split_body(
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < 4 && more) {           // both planes of step j+1: 8 MFMAs until the first use
+                if (j + 1 < 4 && more) {           // both planes of step j+1 (lo refilled in place: behind the lo.hi group)
                     load_plane(al, j + 1 < 4 ? j + 1 : 0, 1);
                     load_plane(ah[(j + 1) & 1], j + 1 < 4 ? j + 1 : 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], tlo[st], acc[mt], 0, 0, 0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], thi[st], acc[mt], 0, 0, 0);
+                // issue order: the MT lo.hi MFMAs, then ONE fragment read behind every following MFMA (tools/probes/gate_loop.hip:
+                // reads grouped in front of an MFMA group cost 12 % of the k-step, interleaved 1:1 they are free)
+                __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+                if (j + 1 < 4 && more) {
+#pragma unroll
+                    for (int i = 0; i < 2 * MT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 JLM_TT(10 + st);
             }
@@ -328,6 +347,9 @@ __device__ __forceinline__ void lse_split_body(
             JLM_PROF_ADD(p_bar, p_x);
             buf ^= 1;
         }
+#if JLM_LSE_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         JLM_PROF_MARK(p_x);
         // fold this tile's 16*MT logits of the lane's row into (m, s), base-2 units
         if (BG) {

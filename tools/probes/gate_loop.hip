@@ -7,7 +7,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NB, bool READS, bool BAR, bool SPLITACC>
+template <int NB, bool READS, bool BAR, int ILV>
 __device__ __forceinline__ void body(float *out, unsigned long long *cyc, int iters, float *smem, int wave, int lane) {
     const int li = lane & 31, hf = lane >> 5;
     int goff[2][2];
@@ -52,18 +52,34 @@ __device__ __forceinline__ void body(float *out, unsigned long long *cyc, int it
     };
     __syncthreads();
     unsigned long long t0 = clock64();
+    auto half = [&](int stage, int st, Frag &nxt, const Frag &cur) {
+        if (ILV == 0) {
+            read_half(stage, st, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(cur);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // one MFMA, one ds_read, one MFMA, ... (sched_group_barrier: mask 0x8 = MFMA, 0x100 = DS read)
+            read_half(stage, st, nxt);
+            mfmas(cur);
+#pragma unroll
+            for (int i = 0; i < 3 * NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (READS && i < 2 + 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     for (int kt = 0; kt < iters; ++kt) {
-        read_half(kt, 1, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ILV == 2) __builtin_amdgcn_s_setprio(1);
+        half(kt, 1, fb, fa);
         touch(fb);
+        if (ILV == 2) __builtin_amdgcn_s_setprio(0);
         if (BAR) asm volatile("s_barrier" ::: "memory");
-        read_half(kt + 1, 0, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(fb);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ILV == 2) __builtin_amdgcn_s_setprio(1);
+        half(kt + 1, 0, fa, fb);
         touch(fa);
+        if (ILV == 2) __builtin_amdgcn_s_setprio(0);
     }
     unsigned long long t1 = clock64();
     float r = 0;
@@ -73,20 +89,20 @@ __device__ __forceinline__ void body(float *out, unsigned long long *cyc, int it
     if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
 
-template <bool READS, bool BAR, int NBA, int NBB>
+template <bool READS, bool BAR, int NBA, int NBB, int ILV = 0>
 __global__ __launch_bounds__(512, 1) void k(float *out, unsigned long long *cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < 4 * 9216; i += 512) smem[i] = 0.001f * (i & 255);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (wave < 4) body<NBA, READS, BAR, false>(out, cyc, iters, smem, wave, lane);
-    else body<NBB, READS, BAR, false>(out, cyc, iters, smem, wave, lane);
+    if (wave < 4) body<NBA, READS, BAR, ILV>(out, cyc, iters, smem, wave, lane);
+    else body<NBB, READS, BAR, ILV>(out, cyc, iters, smem, wave, lane);
 }
 
-template <bool READS, bool BAR, int NBA, int NBB>
+template <bool READS, bool BAR, int NBA, int NBB, int ILV = 0>
 void run(const char *name, float *out, unsigned long long *cyc) {
     const int iters = 4000;
-    auto kern = k<READS, BAR, NBA, NBB>;
+    auto kern = k<READS, BAR, NBA, NBB, ILV>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), 147456, 0, out, cyc, iters);
@@ -114,5 +130,9 @@ int main() {
     run<false, false, 2, 2>("MFMAs only, 2 + 2 blocks", out, cyc);
     run<true, true, 2, 2>("MFMAs + reads + barrier, 2 + 2 blocks", out, cyc);
     run<false, false, 5, 1>("MFMAs only, 5 + 1 blocks", out, cyc);
+    run<true, true, 3, 2, 1>("reads interleaved 1:1, barrier, 3 + 2", out, cyc);
+    run<true, false, 3, 2, 1>("reads interleaved 1:1, no barrier, 3 + 2", out, cyc);
+    run<true, true, 4, 4, 1>("reads interleaved 1:1, barrier, 4 + 4", out, cyc);
+    run<true, true, 3, 2, 2>("grouped + setprio(1) around compute, 3 + 2", out, cyc);
     return 0;
 }
