@@ -352,6 +352,10 @@ typedef struct {
     const int *dd_words, *dd_off; int dd_max;   /* kind 2: words new at a frame, per (frame, sentence) */
     float *run_max; double *run_sum;            /* kinds 1, 2: running (max, sum exp) per row */
     float *part; int max_parts;                 /* kind 0: [max_parts][rmax][2] partial slices */
+    /* kind 0: share (percent, 0 = all) of the CUs the vocabulary kernel may fill.  With two batches in flight on two streams
+     * the other batch's latency-bound kernels (beam step, LSTM step, T projection) run on the CUs it leaves free instead of
+     * behind it: 2.61 -> 2.33 ms per step at BASELINE configs[1] with 16 instead of 24 vocabulary ranges (tools/ab_np.py) */
+    int lse_cu_share_pct;
     int *out_nodes; int *out_len; double *out_score; int stride;    /* jlm_backtrace outputs */
 } jlm_decode_plan;
 

@@ -55,7 +55,7 @@ class DecodePlan(Structure):
                 ("vs_words", c_void_p), ("vs_off", c_void_p), ("vs_max", c_int),
                 ("di_words", c_void_p), ("di_off", c_void_p), ("di_idx", c_void_p), ("di_max", c_int),
                 ("dd_words", c_void_p), ("dd_off", c_void_p), ("dd_max", c_int),
-                ("run_max", c_void_p), ("run_sum", c_void_p), ("part", c_void_p), ("max_parts", c_int),
+                ("run_max", c_void_p), ("run_sum", c_void_p), ("part", c_void_p), ("max_parts", c_int), ("lse_cu_share_pct", c_int),
                 ("out_nodes", c_void_p), ("out_len", c_void_p), ("out_score", c_void_p), ("stride", c_int)]
 
 

@@ -154,9 +154,18 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             } else {
                 // frame 0 has one row per sentence: the bound lets the kernel cut the vocabulary into more ranges
                 const int bound = f == 0 ? B : rmax;
+                // the share of the chip this batch's normaliser takes: its range count is capped so that ranges x row tiles
+                // (one 8-wave workgroup per CU each) fill that share; the launcher rounds down to a multiple of 8 ranges
+                int cap = p->max_parts;
+                if (p->lse_cu_share_pct > 0 && p->lse_cu_share_pct < 100) {
+                    const int n_ptiles = (bound + 255) / 256;
+                    int c = 256 * p->lse_cu_share_pct / 100 / n_ptiles;
+                    if (c < m->n_segs) c = m->n_segs;
+                    if (c < cap) cap = c;
+                }
                 int r = m->split_segs
                             ? jlm_vocab_lse_split(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col,
-                                                  m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax, p->max_parts, bound,
+                                                  m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax, cap, bound,
                                                   ndev, stream)
                             : jlm_vocab_lse_stationary(m->segs, m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax,
                                                        p->max_parts, bound, ndev, stream);

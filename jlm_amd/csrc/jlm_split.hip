@@ -525,9 +525,10 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (np < n_segs) np = n_segs;
     if (np > cap) np = cap;
     if (np >= 8 && np8) np &= ~7;
-    static int np_force = -1;                  // experiments: JLM_LSE_NP=<ranges> for launches that would use >= 8
-    if (np_force < 0) { const char *e = getenv("JLM_LSE_NP"); np_force = e ? atoi(e) : 0; }
-    if (np_force > 0 && np >= 8 && np_force <= cap) np = np_force;
+    // JLM_LSE_NP=<ranges> for launches that would use >= 8 (read on every call: tools/ab_np.py changes it in-process)
+    int np_force = 0;
+    { const char *e = getenv("JLM_LSE_NP"); np_force = e ? atoi(e) : 0; }
+    if (np_force > 0 && np_force <= cap) np = np_force;
     if (np < n_segs) np = n_segs;
     int given = 0, k[JLM_MAX_SEGMENTS];
     for (int i = 0; i < n_segs; ++i) {

@@ -9,7 +9,7 @@
 //   torch.classes.jlm.Model   the model's weight panels as jlm_decode_model (keeps the tensors alive)
 //   torch.classes.jlm.Plan    the buffers of one decode shape as jlm_lattice / jlm_beam_state / jlm_decode_plan,
 //                             plus the timing events of a timed decode
-//   torch.ops.jlm.decode_frames(Model, Plan, n_frames, vs_max, di_max, dd_max, use_side, timed)
+//   torch.ops.jlm.decode_frames(Model, Plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct)
 //                             the whole frame loop of a batch: ONE op (jlm_decode_frames)
 //   torch.ops.jlm.frame_times(Plan) -> Tensor [n_frames, 5] milliseconds of the last timed decode (after it finished)
 //   torch.ops.jlm.lstm_step / gemm_nt / softmax_rows      LSTM_Model.predict / project (numpy-facing API)
@@ -191,12 +191,13 @@ struct JlmPlan : torch::CustomClassHolder {
 std::map<std::pair<int, hipStream_t>, c10::hip::HIPStream> g_side;
 
 int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intrusive_ptr<JlmPlan> &plan, int64_t n_frames,
-                      int64_t vs_max, int64_t di_max, int64_t dd_max, bool use_side, bool timed) {
+                      int64_t vs_max, int64_t di_max, int64_t dd_max, bool use_side, bool timed, int64_t lse_cu_share_pct) {
     JlmPlan &pl = *plan;
     TORCH_CHECK(n_frames >= 1 && n_frames <= pl.frames_cap, "jlm.decode_frames: ", n_frames, " frames, the plan holds ", pl.frames_cap);
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(pl.device);
     pl.lat.n_frames = (int)n_frames;
     pl.p.vs_max = (int)vs_max; pl.p.di_max = (int)di_max; pl.p.dd_max = (int)dd_max;
+    pl.p.lse_cu_share_pct = (int)lse_cu_share_pct;
     void *side_s = nullptr;
     if (use_side && !timed) {
         const auto key = std::make_pair(pl.device, main.stream());
@@ -298,7 +299,7 @@ TORCH_LIBRARY(jlm, m) {
                     std::vector<double>, std::vector<double>, std::vector<int64_t>>());
     m.class_<JlmPlan>("Plan").def(torch::init<TDict, IDict>());
     m.def("decode_frames(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, int n_frames, int vs_max, "
-          "int di_max, int dd_max, bool use_side, bool timed) -> int", decode_frames);
+          "int di_max, int dd_max, bool use_side, bool timed, int lse_cu_share_pct) -> int", decode_frames);
     m.def("frame_times(__torch__.torch.classes.jlm.Plan plan) -> Tensor", frame_times);
     m.def("lstm_step(Tensor h_in, Tensor c_in, int ld_state, Tensor(a!) h_out, Tensor(b!) c_out, Tensor? rows, Tensor prev, Tensor word, "
           "Tensor emb, int ld_emb, Tensor wt, Tensor bias, int kpad, int H, int E, int n_rows_max, Tensor? n_dev) -> ()", lstm_step);

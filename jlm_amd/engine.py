@@ -169,6 +169,7 @@ class DecodeEngine:
         # (beam step, LSTM step, T projection: two thirds of the launches, a third of the time, most CUs
         # idle) fill in beside the vocabulary kernel of batch i.  JLM_STREAMS=1 keeps one stream.
         self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "2")))
+        self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
 
@@ -266,8 +267,11 @@ class DecodeEngine:
         side = self.use_side and self.device.type == "cuda" and (
             self.n_streams < 2 or hw_queues_ok() or os.environ.get("JLM_SIDE") == "1")
         # the whole launch sequence of the batch: ONE op, no host synchronisation inside (csrc/jlm_decode.hip)
+        # another batch in flight: this batch's vocabulary kernel takes LSE_SHARE_PCT of the CUs and the other batch's
+        # latency-bound kernels the rest, side by side (include/jlm_hip.h, jlm_decode_plan.lse_cu_share_pct)
+        share = self.lse_share_pct if (not timing and any(q.busy and q is not p for q in self.plans)) else 0
         rc = ops.backend().decode_frames(self.m.decode_model(), p.obj, lat.n_frames, max_words["vs"], max_words["di"],
-                                         max_words["dd"], bool(side), bool(timing))
+                                         max_words["dd"], bool(side), bool(timing), int(share))
         if rc != 0:
             raise _lib.JlmHipError("jlm.decode_frames: the model is outside the shapes the frame loop covers (code %d)" % rc)
         p.h_nodes.copy_(p.out_nodes, non_blocking=True)

@@ -763,7 +763,7 @@ class FakeOps:
     def abi_version(self):
         return self.lib.jlm_abi_version()
 
-    def decode_frames(self, model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed):
+    def decode_frames(self, model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct=0):
         assert 1 <= n_frames <= plan.frames
         plan.lat.n_frames = int(n_frames)
         plan.p.vs_max, plan.p.di_max, plan.p.dd_max = int(vs_max), int(di_max), int(dd_max)
