@@ -134,6 +134,13 @@ int jlm_vocab_lse_stationary(const jlm_segment *segs_host, int n_segs, const flo
 int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale,
                        void *dst, int ld_dst, void *stream);
 
+/* ABI 4: k-means compressed weights (train/comp.py:52-80; selected by decoder/model.py:74-78 through `comp`): per tensor a
+ * uint8 code array and a float32 codebook of <= 256 entries.  dst[r][c] = codebook[code[r][c]] for c < k, on the device
+ * (what np.take(codebook, code) does on the host in train/comp.py:70): the codes stay resident, the float panel is
+ * expanded from them where the kernels need it. */
+int jlm_dequant_u8(const uint8_t *code, int rows, int k, int ld_code, const float *codebook, int n_codes,
+                   float *dst, int ld_dst, void *stream);
+
 /* jlm_lstm_step on split rows (K1+K2+K3+K9): h_in / h_out are split rows of the
  * state scaled by h_scale (a power of two <= 2^14; |h| < 1), emb the split rows
  * of the input embedding, wt the split rows of the packed gate matrix whose

@@ -73,6 +73,7 @@ _SIGS = {
                              P], c_int),
     "jlm_lstm_step_xg": ([P, P, c_int, P, P, P, P, P, P, P, c_int, c_float, c_float, c_int, P, P], c_int),
     "jlm_gemm_nt_split": ([P, c_int, P, P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, P, P], c_int),
+    "jlm_dequant_u8": ([P, c_int, c_int, c_int, P, c_int, P, c_int, P], c_int),
     "jlm_pack_split_f16_col": ([P, c_int, c_float, P, c_int, c_int, P], c_int),
     "jlm_vocab_lse_split": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), POINTER(c_int), c_int, P, P, c_int, P, P,
                              c_int, c_int, c_int, P, P], c_int),

@@ -80,6 +80,39 @@ extern "C" int jlm_pack_split_f16_col(const float *v, int rows, float scale, voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// k-means compressed weights (train/comp.py:52-80: per tensor a uint8 code array of the tensor's shape and a float32
+// codebook): the codes stay resident in HBM, the panels the kernels consume are expanded from them ON THE DEVICE --
+// dst[r][c] = codebook[code[r][c]], what `np.take(codebook, code)` does on the host in train/comp.py:70 -- with the
+// codebook (<= 256 entries) in LDS.  A quarter of the upload, and the decoded float copy never exists on the host.
+__global__ __launch_bounds__(256) void dequant_u8_kernel(const uint8_t *__restrict__ code, int rows, int k, int ld_code,
+                                                         const float *__restrict__ book, int n_codes, float *__restrict__ dst,
+                                                         int ld_dst) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (int)threadIdx.x < n_codes ? book[threadIdx.x] : 0.0f;
+    __syncthreads();
+    const int k4 = (k + 3) >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * k4) return;
+    const int r = (int)(i / k4), c = (int)(i % k4) * 4;
+    const uint8_t *src = code + (size_t)r * ld_code + c;
+    float *d = dst + (size_t)r * ld_dst + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c + j < k) d[j] = lut[src[j]];
+}
+
+extern "C" int jlm_dequant_u8(const uint8_t *code, int rows, int k, int ld_code, const float *codebook, int n_codes, float *dst,
+                              int ld_dst, void *stream) {
+    if (rows < 0 || k <= 0 || ld_code < k || ld_dst < k || n_codes < 1 || n_codes > 256) return -1;
+    if (rows == 0) return 0;
+    const long n = (long)rows * ((k + 3) / 4);
+    hipLaunchKernelGGL(dequant_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, code, rows, k, ld_code,
+                       codebook, n_codes, dst, ld_dst);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows-stationary vocabulary log-sum-exp, split-f16 form.  Same structure as
 // vocab_lse_stationary_kernel (jlm_gemm.hip): a workgroup keeps 128 hypothesis rows' operands in
 // registers (32 rows per wave, both planes, the whole contraction) and streams a range of

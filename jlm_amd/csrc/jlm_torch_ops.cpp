@@ -13,7 +13,7 @@
 //                             the whole frame loop of a batch: ONE op (jlm_decode_frames)
 //   torch.ops.jlm.frame_times(Plan) -> Tensor [n_frames, 5] milliseconds of the last timed decode (after it finished)
 //   torch.ops.jlm.lstm_step / gemm_nt / softmax_rows      LSTM_Model.predict / project (numpy-facing API)
-//   torch.ops.jlm.pack_split_f16 / pack_split_f16_col     weight preparation at load
+//   torch.ops.jlm.pack_split_f16 / pack_split_f16_col / dequant_u8     weight preparation at load
 //
 // Built by __graft_entry__.build():  g++ -shared ... -> jlm_amd/_torch_ops.so, loaded with torch.ops.load_library.
 #include <torch/library.h>
@@ -289,6 +289,16 @@ void pack_split_f16_col(const Tensor &v, int64_t v_off, int64_t rows, double sca
               "jlm_pack_split_f16_col");
 }
 
+// dst[r][c] = codebook[code[r][c]]: the k-means (code, codebook) form of a weight tensor expanded on the device
+void dequant_u8(const Tensor &code, int64_t rows, int64_t k, int64_t ld_code, const Tensor &codebook, const Tensor &dst, int64_t ld_dst) {
+    TORCH_CHECK(code.scalar_type() == at::kByte && codebook.scalar_type() == at::kFloat && dst.scalar_type() == at::kFloat,
+                "jlm.dequant_u8: uint8 codes, float32 codebook and destination");
+    TORCH_CHECK(rows * ld_code <= code.numel() && (rows == 0 || (rows - 1) * ld_dst + k <= dst.numel()), "jlm.dequant_u8: shape outside the tensors");
+    jlm_check(jlm_dequant_u8(ptr<const uint8_t>(code, "code"), (int)rows, (int)k, (int)ld_code, ptr<const float>(codebook, "codebook"),
+                             (int)codebook.numel(), ptr<float>(dst, "dst"), (int)ld_dst, stream_of(code)),
+              "jlm_dequant_u8");
+}
+
 int64_t abi_version() { return jlm_abi_version(); }
 
 }  // namespace
@@ -309,5 +319,6 @@ TORCH_LIBRARY(jlm, m) {
     m.def("pack_split_f16(Tensor src, int src_off, int rows, int k, int ld, float scale, Tensor(a!) dst, int dst_off, int ld_dst) -> ()",
           pack_split_f16);
     m.def("pack_split_f16_col(Tensor v, int v_off, int rows, float scale, Tensor(a!) dst, int ld_dst, int col) -> ()", pack_split_f16_col);
+    m.def("dequant_u8(Tensor code, int rows, int k, int ld_code, Tensor codebook, Tensor(a!) dst, int ld_dst) -> ()", dequant_u8);
     m.def("abi_version() -> int", abi_version);
 }

@@ -144,7 +144,7 @@ class DeviceModel:
     Untied: T is the hidden state itself.  Pad columns are produced as exact
     zeros (zero rows in the packed matrices)."""
 
-    def __init__(self, config, weights, blocks, v_tables, device):
+    def __init__(self, config, weights, blocks, v_tables, device, codes=None):
         import torch
         self.torch = torch
         self.device = device
@@ -162,6 +162,27 @@ class DeviceModel:
 
         def dev(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=f32)).to(device)
+
+        # k-means compressed model (train/comp.py; comp > 0): where the (code uint8, codebook) form of a vocabulary block is
+        # on disk, the CODES are uploaded and stay resident and the float panel is expanded from them on the device
+        # (jlm_dequant_u8) -- a quarter of the upload; the split rows are packed from that panel on the device as well
+        self.seg_codes = {}
+
+        def block(idx, name, host_padded, k, transpose=False):
+            pair = (codes or {}).get(name)
+            if pair is None:
+                return dev(host_padded)
+            code, book = pair
+            code = np.ascontiguousarray(code.T if transpose else code)
+            if code.shape != (host_padded.shape[0], k):
+                return dev(host_padded)
+            cd = torch.from_numpy(code).to(device)
+            bk = torch.from_numpy(np.ascontiguousarray(book, dtype=f32)).to(device)
+            dst = torch.zeros(host_padded.shape, dtype=torch.float32, device=device)
+            with self._ctx():
+                _ops.backend().dequant_u8(cd, code.shape[0], k, k, bk, dst, host_padded.shape[1])
+            self.seg_codes[idx] = (cd, bk)
+            return dst
 
         # --- input embedding + packed gate matrix (model.py:125-131)
         LM = np.asarray(weights["LM"])
@@ -193,7 +214,7 @@ class DeviceModel:
         if self.mode == "untied":
             self.ldt = H
             um_t = np.ascontiguousarray(np.asarray(weights["UM"], dtype=f32).T)      # [V, H]
-            self.seg_B.append(dev(um_t))
+            self.seg_B.append(block(0, "UM", um_t, H, transpose=True))
             self.segments.append(dict(v_start=0, v_end=self.V, k=H, t_off=0, ldb=H))
         else:
             PM = np.asarray(weights["PM"], dtype=f32)                                 # [H, Ecols]
@@ -205,7 +226,7 @@ class DeviceModel:
                 pmt[:k] = PM.T
                 blk = np.zeros((self.V, kp), dtype=f32)
                 blk[:, :k] = np.asarray(weights["LM"], dtype=f32)
-                self.seg_B.append(dev(blk))
+                self.seg_B.append(block(0, "LM", blk, k))
                 self.segments.append(dict(v_start=0, v_end=self.V, k=kp, t_off=0, ldb=kp))
             elif self.mode == "dsoftmax":
                 offs, off = [], 0
@@ -237,7 +258,7 @@ class DeviceModel:
                     kp = _pad(size, 4)
                     blk = np.zeros((e - s, kp), dtype=f32)
                     blk[:, :size] = np.asarray(blocks[i], dtype=f32)
-                    self.seg_B.append(dev(blk))
+                    self.seg_B.append(block(i, "LM{}".format(i), blk, size))
                     self.segments.append(dict(v_start=s, v_end=e, k=kp, t_off=off, ldb=kp))
                     part = np.zeros((kp if i != 0 else E0p, H), dtype=f32)
                     if i == 0:
@@ -414,7 +435,9 @@ class LSTM_Model():
         self.cell = np.zeros((1, self.hidden_size))
         self.device = device if device is not None else _lib.require_gpu()
         _ops.backend()
-        self.dev = DeviceModel(self.config, self.weights, self.blocks, self.v_tables, self.device)
+        from . import weights as _w
+        self.dev = DeviceModel(self.config, self.weights, self.blocks, self.v_tables, self.device,
+                               codes=_w.load_codes(experiment_id, comp) if comp else None)
 
     # ------------------------------------------------------------------ helpers
     def _to_dev(self, a, dtype=None):

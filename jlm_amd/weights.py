@@ -29,6 +29,36 @@ def decode_codebook(code, codebook):
     return np.take(np.asarray(codebook), np.asarray(code))
 
 
+def load_codes(experiment_id=0, comp=0):
+    """The (code uint8, codebook float32) pairs of a k-means compressed model where train/comp.py left them
+    (comp_{bit}/lstm_weights_comp_dump.pkl, or the debug text files) and every code fits a byte -- else None.
+    DeviceModel keeps these resident and expands the vocabulary blocks from them on the device (jlm_dequant_u8)."""
+    if not comp:
+        return None
+    cdir = os.path.join(weights_dir(experiment_id), "comp_{}".format(comp))
+    dump = os.path.join(cdir, "lstm_weights_comp_dump.pkl")
+    pairs = None
+    if os.path.exists(dump):
+        with open(dump, "rb") as f:
+            pairs = pickle.load(f)
+    elif os.path.isdir(cdir):
+        pairs = {}
+        for fn in sorted(os.listdir(cdir)):
+            if fn.endswith("_code.txt"):
+                name = fn[:-len("_code.txt")]
+                pairs[name] = (np.loadtxt(os.path.join(cdir, fn), dtype=np.int64),
+                               np.loadtxt(os.path.join(cdir, name + "_codebook.txt"), dtype=np.float32))
+    if not pairs:
+        return None
+    out = {}
+    for k, (code, book) in pairs.items():
+        code, book = np.asarray(code), np.asarray(book, dtype=np.float32).reshape(-1)
+        if book.size > 256 or code.size == 0 or int(code.max()) >= book.size or int(code.min()) < 0:
+            continue
+        out[k] = (np.ascontiguousarray(code.astype(np.uint8)), book)
+    return out or None
+
+
 def _load_text_tensors(d, config):
     out = {}
     names = list(TENSOR_NAMES)

@@ -374,6 +374,19 @@ class FakeLib:
         out[:, :, 1, :] = lo.reshape(rows, k16 // 8, 8)
         return 0
 
+    def jlm_dequant_u8(self, code, rows, k, ld_code, codebook, n_codes, dst, ld_dst, stream):
+        if rows < 0 or k <= 0 or ld_code < k or ld_dst < k or not 1 <= n_codes <= 256:
+            return -1
+        if rows == 0:
+            return 0
+        buf = (ctypes.c_uint8 * (rows * ld_code)).from_address(_p(code))
+        cv = np.frombuffer(buf, dtype=np.uint8).reshape(rows, ld_code)[:, :k]
+        book = view(codebook, n_codes, np.float32)
+        out = view(dst, (rows - 1) * ld_dst + k, np.float32)
+        for r in range(rows):
+            out[r * ld_dst:r * ld_dst + k] = book[cv[r]]
+        return 0
+
     def jlm_pack_split_f16_col(self, v, rows, scale, dst, ld_dst, col, stream):
         if rows < 0 or ld_dst % 16 or col < 0 or col >= ld_dst:
             return -1
@@ -794,6 +807,10 @@ class FakeOps:
     def pack_split_f16(self, src, src_off, rows, k, ld, scale, dst, dst_off, ld_dst):
         self._chk(self.lib.jlm_pack_split_f16(self._o(src, src_off), rows, k, ld, scale, self._o(dst, dst_off), ld_dst, 0),
                   "jlm_pack_split_f16")
+
+    def dequant_u8(self, code, rows, k, ld_code, codebook, dst, ld_dst):
+        self._chk(self.lib.jlm_dequant_u8(code.data_ptr(), rows, k, ld_code, codebook.data_ptr(), codebook.numel(), dst.data_ptr(),
+                                          ld_dst, 0), "jlm_dequant_u8")
 
     def pack_split_f16_col(self, v, v_off, rows, scale, dst, ld_dst, col):
         self._chk(self.lib.jlm_pack_split_f16_col(self._o(v, v_off), rows, scale, self._o(dst), ld_dst, col, 0),

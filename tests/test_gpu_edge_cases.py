@@ -212,3 +212,29 @@ def test_operand_ranges_of_the_split_kernels(name, edit, tag, tmp_path):
     got = d.decode_batch(sents, beam_width=6)
     for s, g in zip(sents, got):
         _same(g, o.decode(s, beam_width=6), (tag, s))
+
+
+@pytest.mark.parametrize("mode", ["tied", "vtable", "untied"])
+def test_kmeans_compressed_model_on_device(mode, tmp_path):
+    """comp=8 (decoder/model.py:74-78, train/comp.py:52-80): the (code uint8, codebook) pairs go to the device, the vocabulary
+    panels are expanded from them there (jlm_dequant_u8) and the decode equals the oracle run on the decoded weights"""
+    from jlm_amd import weights as W
+    root = str(tmp_path)
+    cfg = synth.make_config(3000, 64, 32, mode, segs=[(32, 0, 700), (16, 700, 1800), (8, 1800, None)])
+    synth.write_lexicon(root, 3000, alphabet=10)
+    synth.write_experiment(root, 1, cfg, scale=0.3)
+    decoded = synth.write_compressed(root, 1, bit=8, formats=("dump",))
+    jconfig.set_root(root)
+    from jlm_amd.decoder import Decoder
+    d = Decoder(1, comp=8)
+    m = d.model.dev
+    assert len(m.seg_codes) == m.n_segs and all(c.dtype == torch.uint8 and c.is_cuda for c, _b in m.seg_codes.values())
+    names = {"tied": ["LM"], "untied": ["UM"], "vtable": ["LM0", "LM1", "LM2"]}[mode]
+    for i, nm in enumerate(names):          # bit-exact LUT expansion
+        want = decoded[nm].T if mode == "untied" else decoded[nm]
+        np.testing.assert_array_equal(m.seg_B[i].cpu().numpy()[:, :want.shape[1]], want.astype(np.float32))
+    o = orc.OracleDecoder(root, 1)
+    o.model = orc.OracleLM(o.config, W.load_weights(1, 8))          # what model.py:74-78 would have unpickled
+    sents = synth.make_ragged_sentences(10, 2, 14, seed=4, alphabet=10)
+    for s, g in zip(sents, d.decode_batch(sents, beam_width=6)):
+        _same(g, o.decode(s, beam_width=6), (mode, s))

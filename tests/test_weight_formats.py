@@ -67,6 +67,10 @@ def test_decoder_on_compressed_model_matches_oracle(exp, monkeypatch):
     from jlm_amd.decoder import Decoder
     dec = Decoder(1, comp=6)
     dec.perf_timing = False
+    # the vocabulary block was expanded from the resident (code, codebook) pair by the device-side de-quantiser
+    m = dec.model.dev
+    assert 0 in m.seg_codes and m.seg_codes[0][0].dtype == __import__("torch").uint8
+    np.testing.assert_array_equal(m.seg_B[0].numpy()[:, :m.segments[0]["k"]][:, :16], W.load_weights(1, 6)["LM"])
     # oracle on the decoded weights (what model.py:74-78 would have unpickled)
     decoded = W.load_weights(1, 6)
     o = orc.OracleDecoder(root, 1)
