@@ -85,6 +85,7 @@ class Decoder():
         self.max_unpruned_paths = 20000  # beam_width=None: largest frame the host-side unpruned search accepts
         self.perf_timing = False         # True: per-frame HIP-event timings into perf_log_* (eval.py reads them), slower path
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
+        self.plan_budget_bytes = 6 << 30  # state rows of one batch (frames x sentences x beam x (2 H + ldt) x 4 B): see _chunks
         self.last_lattice = None
         self._pool = None                # worker threads that build the lattices of upcoming chunks
         from . import usable_cpus
@@ -141,31 +142,63 @@ class Decoder():
             for i, r in zip(keep, sub):
                 out[i] = r
             return out
-        def prepare(i):
-            """host side of chunk i: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
-            lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
-            if not vocab_select:
-                return lat, None, None
-            words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
-            return lat, (words, off), lists[-1]
+        chunks = self._chunks(inputs, beam_width, reorder=not (samples and random_sampling))
 
-        out, inflight = [], deque()
+        def prepare(idx):
+            """host side of one chunk: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
+            lat = BatchLattice(self._builder, [inputs[j] for j in idx], beam_width)
+            if not vocab_select:
+                return idx, lat, None, None
+            words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
+            return idx, lat, (words, off), lists
+
+        out, inflight = [None] * len(inputs), deque()
+
+        def finish(item):
+            idx, ticket = item
+            for j, r in zip(idx, self._engine.collect(ticket)):
+                out[j] = r
+            self._log_perf()
+
         workers = 1 if (samples and random_sampling) else self.prefetch_workers
-        for lat, vocab, last_list in self._prefetched(prepare, range(0, len(inputs), self.max_batch), workers):
+        for idx, lat, vocab, lists in self._prefetched(prepare, chunks, workers):
             self.last_lattice = lat
-            if vocab_select:
-                self.lattice_vocab = last_list
-            inflight.append(self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing))
+            if vocab_select and (len(inputs) - 1) in idx:
+                self.lattice_vocab = lists[idx.index(len(inputs) - 1)]      # the reference leaves the LAST sentence's list behind
+            inflight.append((idx, self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)))
             # two chunks stay in flight (the engine alternates streams); the strings of chunk i-2 are
             # built while the GPU decodes chunks i-1 and i
             if len(inflight) > self.pipeline_depth:
-                out.extend(self._engine.collect(inflight.popleft()))
-                self._log_perf()
+                finish(inflight.popleft())
         while inflight:
-            out.extend(self._engine.collect(inflight.popleft()))
-            self._log_perf()
+            finish(inflight.popleft())
         self.perf_sen += len(inputs)
         return out
+
+    def _chunks(self, inputs, beam_width, reorder=True):
+        """Index lists of the device batches of one decode_batch call.  A batch's frame loop and buffers run to its LONGEST
+        sentence (frames x sentences x beam state rows of 2 H + ldt floats: every frame's state stays resident, a lattice word
+        may reach back any number of frames), so sentences are dealt by decreasing length -- as shard.py deals them over the
+        ranks -- and a batch closes at ``max_batch`` sentences or when its state rows would exceed ``plan_budget_bytes``: one
+        200-kana input costs its own small batch, not 12 GB for the 1 023 short sentences that happened to follow it.
+        reorder=False keeps the caller's order (random_sampling draws from the global RNG sentence by sentence)."""
+        n = len(inputs)
+        order = list(range(n))
+        if reorder and n > self.max_batch:
+            order.sort(key=lambda i: -len(inputs[i]))
+        m = self.model.dev
+        row_bytes = (2 * m.H + (0 if m.mode == "untied" else m.ldt)) * 4 + 64
+        chunks, cur, longest = [], [], 0
+        for i in order:
+            frames = (max(longest, len(inputs[i])) + 1 + 7) // 8 * 8
+            if cur and (len(cur) >= self.max_batch or frames * (len(cur) + 1) * beam_width * row_bytes > self.plan_budget_bytes):
+                chunks.append(cur)
+                cur, longest = [], 0
+            cur.append(i)
+            longest = max(longest, len(inputs[i]))
+        if cur:
+            chunks.append(cur)
+        return chunks
 
     def _decode_unpruned(self, input, topN, vocab_select, samples, top_sampling, random_sampling, beam_width=None, vocab=None):
         """Decoder.decode of the reference with ``beam_width=None`` (decoder.py:220-241), statement for statement on the

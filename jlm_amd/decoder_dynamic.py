@@ -47,10 +47,13 @@ class DynamicDecoder(Decoder):
             for i, r in zip(keep, sub):
                 res[i] = r
             return res
-        out, inflight = [], deque()
+        out, inflight = [None] * len(inputs), deque()
+        chunks = self._chunks(inputs, beam_width, reorder=not (samples and random_sampling))
 
-        def finish(ticket):
-            out.extend(self._engine.collect(ticket))
+        def finish(item):
+            idx, ticket = item
+            for j, r in zip(idx, self._engine.collect(ticket)):
+                out[j] = r
             self._log_perf()
             # perf_timing: HIP events around the merge of a frame's new words into the older rows (the reference's
             # "vocab fix", decoder_dynamic.py:112-148) and around the re-scoring beam step ("lattice path fix", :150-175)
@@ -59,21 +62,22 @@ class DynamicDecoder(Decoder):
                     self.perf_log_fix_vocab.append(t_vocab)
                     self.perf_log_fix_lattice_path_prob.append(t_path)
 
-        def prepare(i):
-            lat = BatchLattice(self._builder, inputs[i:i + self.max_batch], beam_width)
-            return (lat,) + tuple(lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i)))
+        def prepare(idx):
+            lat = BatchLattice(self._builder, [inputs[j] for j in idx], beam_width)
+            return (idx, lat) + tuple(lat.dynamic_vocab(samples, top_sampling, random_sampling, len(self.w2i)))
 
         workers = 1 if (samples and random_sampling) else self.prefetch_workers
         last_lv = None
-        for lat, iw, io, dw, do, lv_final in self._prefetched(prepare, range(0, len(inputs), self.max_batch), workers):
+        for idx, lat, iw, io, dw, do, lv_final in self._prefetched(prepare, chunks, workers):
             self.last_lattice = lat
-            last_lv = lv_final
-            inflight.append(self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN,
-                                                timing=self.perf_timing))
+            if (len(inputs) - 1) in idx:
+                last_lv = lv_final[idx.index(len(inputs) - 1)]
+            inflight.append((idx, self._engine.submit(lat, "dynamic", dyn_lists=(iw, io, dw, do), topN=topN,
+                                                      timing=self.perf_timing)))
             if len(inflight) > self.pipeline_depth:
                 finish(inflight.popleft())
         while inflight:
             finish(inflight.popleft())
-        self.lattice_vocab = last_lv[-1]          # the reference leaves the LAST sentence's dict behind
+        self.lattice_vocab = last_lv              # the reference leaves the LAST sentence's dict behind
         self.perf_sen += len(inputs)
         return out

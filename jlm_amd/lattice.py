@@ -17,6 +17,7 @@ Arrays (int32, frame-major cells ``cell = frame * n_sent + sentence``):
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -82,6 +83,7 @@ class LatticeBuilder:
                 if len(reading) > self.max_len:
                     self.max_len = len(reading)
         self._native = None
+        self._native_lock = threading.Lock()          # decode_batch's prefetch threads all ask for the trie on first use
         from . import usable_cpus
         self.n_threads = min(4, usable_cpus())     # per build; decode_batch runs several builds side by side
         self.use_native = os.environ.get("JLM_NATIVE_LATTICE", "1") != "0"
@@ -90,7 +92,11 @@ class LatticeBuilder:
         """Handle of the C++ trie (built on first use), or None."""
         if not self.use_native or host_lib() is None:
             return None
-        if self._native is None:
+        if self._native is not None:
+            return self._native
+        with self._native_lock:
+            if self._native is not None:
+                return self._native
             readings = list(self.table)
             cps = [_utf32(r) for r in readings]
             r_off = np.zeros(len(readings) + 1, dtype=np.int32)

@@ -201,3 +201,29 @@ def test_unpruned_search_and_compat_quirks_cpu(fx, fake):
     d2.compat_quirks = False                    # default: a full-vocabulary call normalises over the full vocabulary
     fresh = orc.OracleDecoder(f["root"], 1).decode(s1, beam_width=4)
     np.testing.assert_allclose([x for x, _ in d2.decode(s1, beam_width=4)], [x for x, _ in fresh], rtol=2e-6, atol=2e-5)
+
+
+def test_decode_batch_chunks_by_length_and_memory_budget(fx, fake):
+    """decode_batch deals sentences into device batches by decreasing length, closes a batch at max_batch sentences or at
+    plan_budget_bytes of state rows, and hands the results back in the caller's order"""
+    from jlm_amd import synth
+    f = fx("small-tied")
+    d = _decoder(f, "static")
+    sents = synth.make_ragged_sentences(30, 1, 12, seed=5, alphabet=f["alphabet"]) + [synth.make_sentences(1, 60, seed=6, alphabet=f["alphabet"])[0]]
+    d.max_batch = 8
+    chunks = d._chunks(sents, 5)
+    assert sorted(i for c in chunks for i in c) == list(range(len(sents))) and all(len(c) <= 8 for c in chunks)
+    assert chunks[0][0] == len(sents) - 1                                  # the 60-kana outlier leads the first batch
+    lens = [[len(sents[i]) for i in c] for c in chunks]
+    assert all(l == sorted(l, reverse=True) for l in lens) and lens[1][0] >= lens[-1][0]
+    m = d.model.dev
+    row = (2 * m.H + m.ldt) * 4 + 64
+    d.plan_budget_bytes = 64 * 2 * 5 * row                                 # room for two sentences of 64 frames at beam 5
+    tight = d._chunks(sents, 5)
+    assert len(tight[0]) <= 2 and sorted(i for c in tight for i in c) == list(range(len(sents)))
+    assert d._chunks(sents, 5, reorder=False)[0][0] == 0                   # random_sampling: the caller's order is kept
+    want = [d.decode(s, beam_width=5) for s in sents]
+    got = d.decode_batch(sents, beam_width=5)
+    for a, b in zip(got, want):
+        assert [w for _, w in a] == [w for _, w in b]
+        np.testing.assert_allclose([x for x, _ in a], [x for x, _ in b], rtol=1e-9, atol=1e-6)
