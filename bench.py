@@ -175,21 +175,22 @@ def main():
         eng.keep_n_live = False
         rows = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in n_live])    # live rows per launch
         H = m.H
-        split = getattr(m, "split_array", None) is not None
+        split = getattr(m, "split_array", None) is not None or getattr(m, "um_split", None) is not None
         gsplit = getattr(m, "split_lstm", False)
         # executed MFMA work: 3 passes, contraction padded to whole 16-value steps (+ the bias column where it rides in the GEMM)
-        k16 = lambda sg: (sg["k"] + (1 if sg["k"] % 16 else 0) + 15) // 16 * 16
+        k16 = lambda sg: (sg["k"] + (1 if (sg["k"] % 16 and m.stationary_ok) else 0) + 15) // 16 * 16
         exec_per_row_vocab = SPLIT_PASSES * sum(2.0 * k16(sg) * (sg["v_end"] - sg["v_start"]) for sg in m.segments)
         v = kernel_stats(durs, rows, "vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
         roofline = None
         if v:
-            kname = ("vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
+            kname = ("gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
+                     "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                      else "gemm2_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
             peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_note = None, "not measured in this run (tools/gpu_traffic.sh + tools/traffic_report.py write profiles/traffic_latest.json)"
             tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-            if split and os.path.exists(tpath):
+            if split and m.stationary_ok and os.path.exists(tpath):
                 with open(tpath) as tf:
                     tj = json.load(tf)
                 if tj.get("source_sha256") == kernel_source_sha256() and tj.get("fixture") == args.fixture:
@@ -376,7 +377,7 @@ def main():
         "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate: f32-grade error, tests/test_gpu_kernels.py; "
-                  "scores f64)" if getattr(m, "split_array", None) is not None else "f32"),
+                  "scores f64)" if getattr(m, "split_lstm", False) else "f32"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "fixture": args.fixture,
                    "sentences_per_gpu": args.batch if args.config == 2 else CONFIG5_SENTENCES // world,

@@ -169,11 +169,22 @@ int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void 
  *                  (a 32-row MFMA block = four gates of eight units: the cell update needs no transposition);
  *   xgate8         f32 [V, 4H], same column order: (emb[w] . W_x^T + bias) / descale for every vocabulary word
  *                  (model.py:125-131 computes x.IM_g + h.HM_g + b_g; the table is the x.IM_g + b_g part);
+ *   h_f32_out      optional (may be NULL): h' also as plain f32 rows, same stride (untied models: T is the state itself and
+ *                  the edge-logit / word-list kernels read T as f32);
  *   c stays f32.   H % 32 == 0, ld_state % 16 == 0. */
 int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
                      const int *rows, const int *prev, const int *word,
-                     const void *wt8, const float *xgate8, int H, float descale, float h_scale,
+                     const void *wt8, const float *xgate8, int H, float descale, float h_scale, float *h_f32_out,
                      int n_rows_max, const int *n_dev, void *stream);
+
+/* jlm_vocab_lse_partials on split rows (the tile form for k > 256: untied models, k = H; model.py:189-191):
+ *   logit[v, r] = descale * sum_k Bsplit[v, k] * Tsplit[rows[r], k] + bias[v]
+ * Bsplit = split rows of the segment's matrix scaled by 2^eB, Tsplit = split rows of the row operand scaled by 2^eT (for an
+ * untied model the state rows the LSTM step wrote, eT = 14), descale = 2^-(eT + eB); strides in 4-byte units, K % 16 == 0.
+ * Same partial-slice contract and return value as jlm_vocab_lse_partials. */
+int jlm_vocab_lse_partials_split(const void *Bsplit, int ldb, int n_vocab, int K, const void *Tsplit, int ldt, const int *rows,
+                                 const float *bias, float descale, float *part, int ld_part, int tile0,
+                                 int n_rows_max, const int *n_dev, void *stream);
 
 /* jlm_gemm_nt on split rows: C = descale * (A . B^T) + bias, C plain f32. */
 int jlm_gemm_nt_split(const void *A, int lda, const int *a_rows, const void *B, int ldb, const int *b_rows,
@@ -339,6 +350,9 @@ typedef struct {
     const void *wt_split; int kpad_split; float gate_descale, h_scale; const float *xgate;
     /* jlm_lstm_step_xg operands (ABI 4; used instead of the line above when wt8 != NULL) */
     const void *wt8; const float *xgate8;
+    /* untied model on split rows (ABI 4; untied_split != NULL): the vocabulary matrix UM^T [V, H] as split rows scaled by
+     * 2^eB, untied_descale = 2^-(14 + eB); the state rows plan.h are split rows then, plan.T their plain f32 copy */
+    const void *untied_split; float untied_descale;
     /* T projection: [n_t, H] panel, plain or split rows */
     const float *pmt; const void *pmt_split; int n_t; float t_descale;
     /* full-vocabulary normaliser: split segments (NULL: f32 rows-stationary form) */

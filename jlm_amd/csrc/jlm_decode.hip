@@ -103,7 +103,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         const int *ndev = st.n_live + f;
         if (m->split_lstm && m->wt8)
             JLM_TRY(jlm_lstm_step_xg(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, m->wt8, m->xgate8, m->H,
-                                     m->gate_descale, m->h_scale, rmax, ndev, stream));
+                                     m->gate_descale, m->h_scale, m->untied ? p->T : nullptr, rmax, ndev, stream));
         else if (m->split_lstm)
             JLM_TRY(jlm_lstm_step_split(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, nullptr, 0, m->wt_split, nullptr,
                                         m->kpad_split, m->H, 0, m->gate_descale, m->h_scale, m->xgate, rmax, ndev, stream));
@@ -144,8 +144,12 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 int n_parts = 0;
                 for (int i = 0; i < m->n_segs; ++i) {
                     const jlm_segment &sg = m->segs[i];
-                    int r = jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, p->T + sg.t_off, m->ldt, rows,
-                                                   m->b2 + sg.v_start, p->part, rmax, n_parts, rmax, ndev, stream);
+                    int r = (m->untied && m->untied_split && m->split_lstm)
+                                ? jlm_vocab_lse_partials_split(m->untied_split, m->H, sg.v_end - sg.v_start, m->H, p->h, m->H, rows,
+                                                               m->b2 + sg.v_start, m->untied_descale, p->part, rmax, n_parts,
+                                                               rmax, ndev, stream)
+                                : jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, p->T + sg.t_off, m->ldt, rows,
+                                                         m->b2 + sg.v_start, p->part, rmax, n_parts, rmax, ndev, stream);
                     if (r < 0) return r;
                     n_parts += r;
                 }

@@ -61,6 +61,7 @@ __device__ float gate_zero_page[64];
 
 struct GateXgArgs {
     const float *h; const float *c_in; float *h_out; float *c_out; int ld;
+    float *h_f32;                                        // optional plain f32 copy of h' (untied models: T is the state itself)
     const int *rows, *prev, *word;
     const float *wt; const float *xg;
     int H; float descale, h_scale;
@@ -331,6 +332,7 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
         _Float16 *blk = reinterpret_cast<_Float16 *>(a.h_out + (size_t)g * ld + (u0 & ~7)) + (u0 & 7);
         *reinterpret_cast<f16x4 *>(blk) = hi4;
         *reinterpret_cast<f16x4 *>(blk + 8) = lo4;
+        if (a.h_f32) *reinterpret_cast<f32x4 *>(a.h_f32 + (size_t)g * ld + u0) = hn;
     }
 #ifdef JLM_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
 
 extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out, const int *rows,
                                 const int *prev, const int *word, const void *wt8, const float *xgate8, int H, float descale,
-                                float h_scale, int n_rows_max, const int *n_dev, void *stream) {
+                                float h_scale, float *h_f32_out, int n_rows_max, const int *n_dev, void *stream) {
     if (H <= 0 || H % 32 != 0 || ld_state % 16 != 0 || ld_state < H) return -1;
     if (n_rows_max <= 0) return 0;
     static bool attr_done = false;
@@ -378,6 +380,7 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     }
     GateXgArgs a;
     a.h = reinterpret_cast<const float *>(h_in); a.c_in = c_in; a.h_out = reinterpret_cast<float *>(h_out); a.c_out = c_out;
+    a.h_f32 = h_f32_out;
     a.ld = ld_state; a.rows = rows; a.prev = prev; a.word = word;
     a.wt = reinterpret_cast<const float *>(wt8); a.xg = xgate8; a.H = H; a.descale = descale; a.h_scale = h_scale;
     a.nrows = n_rows_max; a.ndev = n_dev;

@@ -302,6 +302,7 @@ struct EpiLse {
     const float *bias;     // per vocabulary row of this segment
     float *part;           // float2 [tiles][ld_part]
     int ld_part, tile0;
+    float scale = 1.0f;    // split-f16 mainloop: 2^-(eA + eB); 1 (exact) for the f32 mainloop
     template <class Cfg> struct Pre {};
     template <class Cfg> __device__ void prepare(Pre<Cfg> &, int, int) const {}
     template <class Cfg>
@@ -318,7 +319,7 @@ struct EpiLse {
                 for (int reg = 0; reg < 16; ++reg) {
                     int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                     bool ok = row < M;
-                    float x = ok ? acc[mt][nt][reg] + bias[row] : JLM_NEG_BIG;
+                    float x = ok ? fmaf(acc[mt][nt][reg], scale, bias[row]) : JLM_NEG_BIG;
                     v[mt][reg] = x;
                     m = fmaxf(m, x);
                 }
@@ -854,6 +855,20 @@ extern "C" int jlm_vocab_lse_partials(const float *Bseg, int ldb, int n_vocab, i
     EpiLse epi;
     epi.bias = bias; epi.part = part; epi.ld_part = ld_part; epi.tile0 = tile0;
     int r = launch_gemm2<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
+    if (r != 0) return r > 0 ? -r : r;
+    return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
+}
+
+extern "C" int jlm_vocab_lse_partials_split(const void *Bsplit, int ldb, int n_vocab, int K, const void *Tsplit, int ldt,
+                                            const int *rows, const float *bias, float descale, float *part, int ld_part,
+                                            int tile0, int n_rows_max, const int *n_dev, void *stream) {
+    if (K % 16 != 0 || ldb % 16 != 0 || ldt % 16 != 0) return -1;
+    PlainRows A, B;
+    A.base = reinterpret_cast<const float *>(Bsplit); A.map = nullptr; A.ld = ldb; A.nrows = n_vocab; A.ndev = nullptr;
+    B.base = reinterpret_cast<const float *>(Tsplit); B.map = rows; B.ld = ldt; B.nrows = n_rows_max; B.ndev = n_dev;
+    EpiLse epi;
+    epi.bias = bias; epi.part = part; epi.ld_part = ld_part; epi.tile0 = tile0; epi.scale = descale;
+    int r = launch_gemm_split<Cfg128>(A, B, K, epi, 1, (hipStream_t)stream);
     if (r != 0) return r > 0 ? -r : r;
     return (n_vocab + Cfg128::BM - 1) / Cfg128::BM;
 }

@@ -123,6 +123,7 @@ struct JlmModel : torch::CustomClassHolder {
         m.wt_split = nullptr; m.kpad_split = (int)geti(i, "kpad_split");
         m.gate_descale = (float)getf(f, "gate_descale"); m.h_scale = (float)getf(f, "h_scale"); m.xgate = nullptr;
         m.wt8 = tptr<const void>(tensors, "wt8"); m.xgate8 = tptr<const float>(tensors, "xgate8");
+        m.untied_split = tptr<const void>(tensors, "untied_split"); m.untied_descale = (float)getf(f, "untied_descale");
         m.pmt = tptr<const float>(tensors, "pmt"); m.pmt_split = tptr<const void>(tensors, "pmt_split");
         m.n_t = (int)geti(i, "n_t"); m.t_descale = (float)getf(f, "t_descale");
         if (!split.v.empty()) {
@@ -130,7 +131,7 @@ struct JlmModel : torch::CustomClassHolder {
             m.split_bias_col = bias_col.data();
         }
         TORCH_CHECK(m.b2 && m.n_segs >= 1 && m.H > 0, "jlm.Model: b2, the segments and H are required");
-        TORCH_CHECK(!m.split_lstm || (m.wt8 && m.xgate8 && m.pmt_split), "jlm.Model: split_lstm needs wt8, xgate8, pmt_split");
+        TORCH_CHECK(!m.split_lstm || (m.wt8 && m.xgate8 && (m.pmt_split || m.untied)), "jlm.Model: split_lstm needs wt8, xgate8, pmt_split");
     }
 };
 

@@ -187,7 +187,7 @@ class Decoder():
         if reorder and n > self.max_batch:
             order.sort(key=lambda i: -len(inputs[i]))
         m = self.model.dev
-        row_bytes = (2 * m.H + (0 if m.mode == "untied" else m.ldt)) * 4 + 64
+        row_bytes = (2 * m.H + (m.ldt if (m.mode != "untied" or m.split_lstm) else 0)) * 4 + 64
         chunks, cur, longest = [], [], 0
         for i in order:
             frames = (max(longest, len(inputs[i])) + 1 + 7) // 8 * 8

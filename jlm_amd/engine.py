@@ -106,7 +106,8 @@ class _Plan:
         self.edge = e(max(caps["nodes"], 1) * beam, f32)
         H, ldt = m.H, m.ldt
         self.h, self.c = e((G, H), f32), e((G, H), f32)
-        self.T = self.h if m.mode == "untied" else e((G, ldt), f32)
+        # untied models: T is the state itself -- the same buffer on the f32 path; with split state rows, their plain f32 copy
+        self.T = (e((G, H), f32) if m.split_lstm else self.h) if m.mode == "untied" else e((G, ldt), f32)
         self.run_max = self.run_sum = self.part = None
         self.n_part = 0
         if not m.self_norm:

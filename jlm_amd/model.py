@@ -284,7 +284,8 @@ class DeviceModel:
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
         self.split_lstm = False
-        if self.stationary_ok and self.precision == "f16x3":
+        self.um_split = None
+        if self.precision == "f16x3" and (self.stationary_ok or self.mode == "untied"):
             self._build_split(None if self.pmt is None else np.abs(pmt).sum(axis=1))
 
     def _build_split(self, t_bound):
@@ -303,7 +304,7 @@ class DeviceModel:
             return int(np.clip(np.floor(np.log2(limit / value)), -40, 40))
 
         with self._ctx():
-            for i, sg in enumerate(self.segments):
+            for i, sg in enumerate(self.segments if self.stationary_ok else []):
                 nv, k = sg["v_end"] - sg["v_start"], sg["k"]
                 k16 = _pad(k, 16)
                 # a segment with a spare (padded) column carries its bias there: b2 * 2^eB against a constant
@@ -328,10 +329,17 @@ class DeviceModel:
                 self.split_segments.append(dict(v_start=sg["v_start"], v_end=sg["v_end"], k=k, t_off=sg["t_off"], ldb=k16))
                 self.split_t_scale.append(2.0 ** eT)
                 self.split_descale.append(2.0 ** -(eT + eB))
-            self.split_array = list(zip(self.split_segments, self.seg_split))
-            # --- the LSTM step and the T projection on split rows (tied / D-softmax / V-table models; an
-            #     untied model's T is the state itself and its k = H > 256 reduction stays on the f32 pipe)
-            self.split_lstm = self.pmt is not None
+            if self.stationary_ok:
+                self.split_array = list(zip(self.split_segments, self.seg_split))
+            # --- the LSTM step and the T projection on split rows.  An untied model's T is the state itself (model.py:189-191):
+            #     its rows ARE the split rows the step writes (scale 2^14), the vocabulary matrix UM^T [V, H] gets split rows
+            #     too, and the k = H > 256 normaliser runs as a tile GEMM on them (jlm_vocab_lse_partials_split)
+            self.split_lstm = (self.pmt is not None and self.stationary_ok) or self.mode == "untied"
+            if self.mode == "untied":
+                eU = pow2_below(2.0 ** 14, float(self.seg_B[0].abs().max().item()))
+                self.um_split = torch.zeros((self.V, self.H), dtype=torch.float32, device=self.device)
+                O.pack_split_f16(self.seg_B[0], 0, self.V, self.H, self.H, float(2.0 ** eU), self.um_split, 0, self.H)
+                self.um_descale = 2.0 ** -(14 + eU)
             if self.split_lstm:
                 H = self.H
                 wh = self._wmax[0]
@@ -359,10 +367,12 @@ class DeviceModel:
                 self.wt8 = torch.zeros((4 * H, H), dtype=torch.float32, device=self.device)
                 O.pack_split_f16(wt8, 0, 4 * H, H, H, float(2.0 ** (S - 14)), self.wt8, 0, H)
                 self.gate_descale = 2.0 ** -S
-                eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
-                self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
-                O.pack_split_f16(self.pmt, 0, self.pmt.shape[0], H, H, float(2.0 ** eP), self.pmt_split, 0, H)
-                self.t_descale = 2.0 ** -(14 + eP)
+                self.pmt_split, self.t_descale = None, 0.0
+                if self.pmt is not None:
+                    eP = pow2_below(2.0 ** 14, float(self.pmt.abs().max().item()))
+                    self.pmt_split = torch.zeros((self.pmt.shape[0], H), dtype=torch.float32, device=self.device)
+                    O.pack_split_f16(self.pmt, 0, self.pmt.shape[0], H, H, float(2.0 ** eP), self.pmt_split, 0, H)
+                    self.t_descale = 2.0 ** -(14 + eP)
                 if self.device.type == "cuda":
                     torch.cuda.synchronize(self.device)      # wt8's source goes out of scope
                 del wt8
@@ -391,7 +401,12 @@ class DeviceModel:
             if self.pmt is not None:
                 t["pmt"] = self.pmt
             if self.split_lstm:
-                t.update(wt8=self.wt8, xgate8=self.xgate8, pmt_split=self.pmt_split)
+                t.update(wt8=self.wt8, xgate8=self.xgate8)
+                if self.pmt_split is not None:
+                    t["pmt_split"] = self.pmt_split
+                if self.um_split is not None:
+                    t["untied_split"] = self.um_split
+                    f["untied_descale"] = self.um_descale
                 i["kpad_split"] = self.kpad_split
                 f.update(gate_descale=self.gate_descale, h_scale=self.h_scale, t_descale=self.t_descale)
             meta = lambda segs: [int(sg[k]) for sg in segs for k in ("v_start", "v_end", "k", "t_off", "ldb")]

@@ -224,7 +224,7 @@ def build_fixture(root, name, exp_id=1):
     that their 2 200-word lexicon still gives a dense lattice.  Names:
 
       small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
-      mid-tied / mid-vtable                       V=50000 H=512 (configs 1 / 2)
+      mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
     """
     parts = name.split("-")

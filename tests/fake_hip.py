@@ -91,7 +91,7 @@ class FakeLib:
             rows, ndev = off(st.live, f * rmax), off(st.n_live, f)
             if m.split_lstm and m.wt8:
                 r = self.jlm_lstm_step_xg(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, m.wt8, m.xgate8, m.H,
-                                          m.gate_descale, m.h_scale, rmax, ndev, stream)
+                                          m.gate_descale, m.h_scale, p.T if m.untied else None, rmax, ndev, stream)
             elif m.split_lstm:
                 r = self.jlm_lstm_step_split(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, None, 0, m.wt_split, None,
                                              m.kpad_split, m.H, 0, m.gate_descale, m.h_scale, m.xgate, rmax, ndev, stream)
@@ -123,8 +123,13 @@ class FakeLib:
                     n_parts = 0
                     for i in range(m.n_segs):
                         sg = m.segs[i]
-                        r = self.jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, off(p.T, sg.t_off), m.ldt,
-                                                        rows, off(m.b2, sg.v_start), p.part, rmax, n_parts, rmax, ndev, stream)
+                        if m.untied and m.untied_split and m.split_lstm:
+                            r = self.jlm_vocab_lse_partials_split(m.untied_split, m.H, sg.v_end - sg.v_start, m.H, p.h, m.H, rows,
+                                                                  off(m.b2, sg.v_start), m.untied_descale, p.part, rmax, n_parts,
+                                                                  rmax, ndev, stream)
+                        else:
+                            r = self.jlm_vocab_lse_partials(sg.B, sg.ldb, sg.v_end - sg.v_start, sg.k, off(p.T, sg.t_off), m.ldt,
+                                                            rows, off(m.b2, sg.v_start), p.part, rmax, n_parts, rmax, ndev, stream)
                         if r < 0:
                             return r
                         n_parts += r
@@ -243,7 +248,7 @@ class FakeLib:
         cout[g, :H] = cn
         return 0
 
-    def jlm_lstm_step_xg(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, wt8, xgate8, H, descale, h_scale,
+    def jlm_lstm_step_xg(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, wt8, xgate8, H, descale, h_scale, h_f32_out,
                          n_rows_max, n_dev, stream):
         """table form, gate-interleave-8 order: n = (u / 8) * 32 + gate * 8 + u % 8; xgate8 pre-multiplied by 1 / descale"""
         if H <= 0 or H % 32 or ld % 16 or ld < H:
@@ -274,7 +279,29 @@ class FakeLib:
         self._split_write(h_out, gmax, ld, g, hn * np.float32(h_scale))
         cout = view(c_out, gmax * ld, np.float32).reshape(gmax, ld)
         cout[g, :H] = cn
+        if _p(h_f32_out):
+            view(h_f32_out, gmax * ld, np.float32).reshape(gmax, ld)[g, :H] = hn
         return 0
+
+    def jlm_vocab_lse_partials_split(self, Bsplit, ldb, n_vocab, K, Tsplit, ldt, rows, bias, descale, part, ld_part, tile0,
+                                     n_rows_max, n_dev, stream):
+        if K % 16 or ldb % 16 or ldt % 16:
+            return -1
+        n = _n(n_rows_max, n_dev)
+        ntile = (n_vocab + 127) // 128
+        if n == 0:
+            return ntile
+        g = _rows(rows, n)
+        Tm = self._split_read(Tsplit, int(g.max()) + 1, ldt)[g, :K]
+        Bm = self._split_read(Bsplit, n_vocab, ldb)[:, :K]
+        y = ((Tm @ Bm.T) * float(descale)).astype(np.float32) + view(bias, n_vocab, np.float32)
+        pv = view(part, (tile0 + ntile) * ld_part * 2, np.float32).reshape(tile0 + ntile, ld_part, 2)
+        for t in range(ntile):
+            yt = y[:, t * 128:(t + 1) * 128].astype(np.float64)
+            mx = yt.max(axis=1)
+            pv[tile0 + t, :n, 0] = mx
+            pv[tile0 + t, :n, 1] = np.exp(yt - mx[:, None]).sum(axis=1)
+        return ntile
 
     def jlm_gemm_nt_split(self, A, lda, a_rows, B, ldb, b_rows, C, ldc, c_rows, bias, descale, M, N, K, m_dev, stream):
         if K % 16 or lda % 16 or ldb % 16:
@@ -726,6 +753,7 @@ class _FakeModel:
         m.kpad, m.E, m.kpad_split = i.get("kpad", 0), i.get("E", 0), i.get("kpad_split", 0)
         m.gate_descale, m.h_scale, m.t_descale = f.get("gate_descale", 0.0), f.get("h_scale", 0.0), f.get("t_descale", 0.0)
         m.wt8, m.xgate8, m.pmt, m.pmt_split, m.n_t = ptr("wt8"), ptr("xgate8"), ptr("pmt"), ptr("pmt_split"), i.get("n_t", 0)
+        m.untied_split, m.untied_descale = ptr("untied_split"), f.get("untied_descale", 0.0)
         if len(split_B):
             m.split_segs = self.split
             m.split_t_scale = ctypes.cast(self.ts, ctypes.POINTER(ctypes.c_float))

@@ -53,6 +53,8 @@ DECODE_CASES = [
     ("mid-tied/dynamic", "mid-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 24, 20, 98)),
     ("mid-vtable/static", "mid-vtable", "static", dict(beam_width=10), ("fixed", 24, 20, 97)),
     ("big-tied/static-b20", "big-tied", "static", dict(beam_width=20), ("fixed", 4, 20, 96)),
+    # untied projection (model.py:189-191) at BASELINE size: V=50k, k = H = 512 (the tile-form normaliser inside the frame loop)
+    ("mid-untied/static", "mid-untied", "static", dict(beam_width=10), ("fixed", 8, 20, 95)),
 ]
 
 RANDOM_SAMPLING_SEED = 123

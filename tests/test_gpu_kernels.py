@@ -246,7 +246,8 @@ def test_lstm_step_xg(L, H, R, use_rows):
     ndg = torch.as_tensor(np.array([n_live], dtype=np.int32)).cuda() if use_rows else None
     torch.cuda.synchronize()
     hs_c, cc = hs.cpu(), torch.as_tensor(c_np.copy())
-    args = (H, 2.0 ** -S, 2.0 ** 14, R)
+    hf32 = torch.full((G, H), 7.0, dtype=torch.float32, device="cuda")      # optional plain f32 copy of h'
+    args = (H, 2.0 ** -S, 2.0 ** 14, hf32.data_ptr(), R)
     assert L.jlm_lstm_step_xg(hs.data_ptr(), cg.data_ptr(), H, hs.data_ptr(), cg.data_ptr(), rowsg.data_ptr() if use_rows else None,
                               prevg.data_ptr(), wordg.data_ptr(), ws.data_ptr(), xg8.data_ptr(), *args,
                               ndg.data_ptr() if use_rows else None, _st()) == 0
@@ -255,20 +256,57 @@ def test_lstm_step_xg(L, H, R, use_rows):
     c_gpu = cg.cpu().numpy()
     np.testing.assert_allclose(h_gpu[sel], hn, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(c_gpu[sel], cn, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(hf32.cpu().numpy()[sel], hn, rtol=2e-5, atol=2e-6)      # the f32 copy = the split rows' value
     # rows that were not stepped are untouched
     mask = np.ones(G, dtype=bool)
     mask[sel] = False
     np.testing.assert_array_equal(c_gpu[mask], c_np[mask])
+    assert (hf32.cpu().numpy()[mask] == 7.0).all()
     # the numpy double on the same split rows
     ws_c, xg_c = ws.cpu(), xg8.cpu()
     rows_c = torch.as_tensor(rows_np) if use_rows else None
     nd_c = torch.as_tensor(np.array([n_live], dtype=np.int32)) if use_rows else None
     word_c, prev_c = torch.as_tensor(word_np), torch.as_tensor(prev_np)
+    hf32_c = torch.zeros((G, H), dtype=torch.float32)
     assert FK.jlm_lstm_step_xg(hs_c.data_ptr(), cc.data_ptr(), H, hs_c.data_ptr(), cc.data_ptr(),
                                rows_c.data_ptr() if use_rows else None, prev_c.data_ptr(), word_c.data_ptr(), ws_c.data_ptr(),
-                               xg_c.data_ptr(), *args, nd_c.data_ptr() if use_rows else None, 0) == 0
+                               xg_c.data_ptr(), H, 2.0 ** -S, 2.0 ** 14, hf32_c.data_ptr(), R,
+                               nd_c.data_ptr() if use_rows else None, 0) == 0
     np.testing.assert_allclose(h_gpu[sel], (_unsplit(hs_c) / 2.0 ** 14)[sel], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(c_gpu[sel], cc.numpy()[sel], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("V,K,R", [(300, 64, 40), (5000, 512, 700), (1237, 128, 2560)])
+def test_vocab_lse_partials_split(L, V, K, R):
+    """tile-form normaliser on split rows (untied models: k = H > 256): per 128-word tile (max, sum exp) of
+    descale * B.T + bias against the f64 evaluation of the original f32 operands"""
+    rng = np.random.default_rng(V + K + R)
+    G = R + 50
+    B_np = (rng.standard_normal((V, K)) * 0.08).astype(np.float32)
+    T_np = np.tanh(rng.standard_normal((G, K))).astype(np.float32)
+    bias_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    rows_np = rng.permutation(G)[:R].astype(np.int32)
+    Bs = _pack(L, torch.as_tensor(B_np).cuda(), K, 2.0 ** 10)
+    Ts = _pack(L, torch.as_tensor(T_np).cuda(), K, 2.0 ** 14)
+    bias, rows = torch.as_tensor(bias_np).cuda(), torch.as_tensor(rows_np).cuda()
+    nd = torch.as_tensor(np.array([R - 3], dtype=np.int32)).cuda()
+    ntile = (V + 127) // 128
+    part = torch.zeros((ntile + 2, R, 2), dtype=torch.float32, device="cuda")
+    r = L.jlm_vocab_lse_partials_split(Bs.data_ptr(), K, V, K, Ts.data_ptr(), K, rows.data_ptr(), bias.data_ptr(), 2.0 ** -24,
+                                       part.data_ptr(), R, 2, R, nd.data_ptr(), _st())
+    assert r == ntile
+    torch.cuda.synchronize()
+    p = part.cpu().numpy().astype(np.float64)
+    y = T_np[rows_np[:R - 3]].astype(np.float64) @ B_np.astype(np.float64).T + bias_np
+    for t in range(ntile):
+        yt = y[:, t * 128:(t + 1) * 128]
+        want = np.log(np.exp(yt - yt.max(axis=1, keepdims=True)).sum(axis=1)) + yt.max(axis=1)
+        got = p[2 + t, :R - 3, 0] + np.log(p[2 + t, :R - 3, 1])
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    # the numpy double of the same contract
+    part_c = torch.zeros((ntile + 2, R, 2), dtype=torch.float32)
+    assert FK.jlm_vocab_lse_partials_split(Bs.cpu().data_ptr(), K, V, K, Ts.cpu().data_ptr(), K, rows.cpu().data_ptr(),
+                                           bias.cpu().data_ptr(), 2.0 ** -24, part_c.data_ptr(), R, 2, R, nd.cpu().data_ptr(), 0) == ntile
 
 
 @pytest.mark.parametrize("M,N,K,maps", [(70, 40, 32, False), (300, 352, 512, True), (2560, 352, 512, True), (1, 8, 16, False)])

@@ -189,7 +189,7 @@ def bench_gate_xg(H, R):
     word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     f = lambda: L.jlm_lstm_step_xg(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
-                                   word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, R, nd.data_ptr(), st)
+                                   word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, None, R, nd.data_ptr(), st)
     assert f() == 0
     med, mn = timeit(f)
     ex = 3 * 2.0 * H * 4 * H * R

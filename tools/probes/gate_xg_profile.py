@@ -30,7 +30,7 @@ elif mode == "ident":      # contiguous state rows instead of a gather
     prev = (torch.arange(G, device=dev, dtype=torch.int32) - 2 * R).clamp(min=0).contiguous()
 nd = torch.tensor([R], device=dev, dtype=torch.int32)
 f = lambda: L.jlm_lstm_step_xg(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
-                               word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, R, nd.data_ptr(), None)
+                               word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, None, R, nd.data_ptr(), None)
 L.jlm_prof_read_gate.argtypes = [ctypes.c_void_p]
 for _ in range(5):
     assert f() == 0
