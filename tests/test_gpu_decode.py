@@ -174,10 +174,12 @@ def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
     try:
         dec.max_batch, dec.prefetch_workers = 48, 3
         fast = dec.decode_batch(sents, beam_width=8, **kw)
+        chunks = dec._chunks(sents, 8)                     # the same device batches (dealt by decreasing length), one at a time
         eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = 1, True, 0, 1
-        slow = []
-        for i in range(0, len(sents), 48):
-            slow.extend(dec.decode_batch(sents[i:i + 48], beam_width=8, **kw))
+        slow = [None] * len(sents)
+        for idx in chunks:
+            for j, r in zip(idx, dec.decode_batch([sents[j] for j in idx], beam_width=8, **kw)):
+                slow[j] = r
     finally:
         dec.max_batch, eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = keep
     assert len(fast) == len(slow) == len(sents)
