@@ -22,9 +22,10 @@
 //     (acc[4 gate + e] = gate of unit 8 (n / 32) + 4 (lane >> 5) + e) of ONE hypothesis (lane & 31): the LSTM cell update
 //     runs in registers -- no transposition through LDS, no second barrier phase;
 //   * the input side xgate[word] (table in the same column order, pre-multiplied by 1 / descale) and the old cell state
-//     are requested at the start of the LAST four k-steps and added in the epilogue: their HBM round trip (the table is
-//     hundreds of MB, rows are random) hides under those k-steps, and -- the vmcnt counter being in order -- does not sit
-//     in front of the ring's first stage as it would if they were requested at kernel start.
+//     are requested in the MIDDLE of the mainloop, wave w at k-step 1 + w, and added in the epilogue: their HBM round trip
+//     (the table is hundreds of MB, rows are random) hides under three k-steps, the chip's 26 MB of them spread over eight
+//     k-steps, and -- the vmcnt counter being in order -- they do not sit in front of the ring's first stage as they would
+//     if they were requested at kernel start.
 // Measured and rejected (tools/probes/gate_xg_profile.py, gate_loop.hip): warming L2 with one load per operand
 // line at kernel start (+5 us: the loop is not bound by L2 misses -- with every operand L2-resident and no DMA at all a
 // k-step still takes 0.8 us); a whole-k-step register double buffer (spills at 3 hypothesis blocks).
@@ -281,15 +282,37 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
         read_half(0, 0, fa);
         touch(fa);
         int kt = 0;
+        // The epilogue's operands (NXG loads: the word's table row out of a 400-MB table -- HBM -- and the old cell state) go
+        // out in the MIDDLE of the mainloop, each wave at its own k-step (1 + wave: the chip's 26 MB spread over eight k-steps
+        // instead of one burst).  The vmcnt counter is in order: the three k-steps behind the request wait with the loads
+        // allowed in flight (they are younger than the stages waited for); the k-step after those waits for a stage that was
+        // requested behind them, so by then -- 3 k-steps, ~2.7 us -- they must have landed.  With too few k-steps for that
+        // they go out at the start of the last four k-steps instead (nothing is requested behind them there).
+        const int xg_at = 1 + wave;
+        const bool mid = xg_at + 3 + 4 <= nk;
+        if (mid) {
+            for (; kt < xg_at; ++kt) kstep(T{}, IC<2 * NP>{}, T{}, kt);
+            load_epilogue_operands();
+            kstep(T{}, IC<2 * NP + NXG>{}, T{}, kt);
+            kstep(T{}, IC<2 * NP + NXG>{}, T{}, kt + 1);
+            kstep(T{}, IC<2 * NP + NXG>{}, T{}, kt + 2);
+            kt += 3;
+        }
         for (; kt + 4 < nk; ++kt) kstep(T{}, IC<2 * NP>{}, T{}, kt);       // steady state: stages kt+1 .. kt+4 exist
         JLM_GT_T(5);
-        // the last four k-steps: nothing left to request for the ring; the epilogue's operands go out now, younger than
-        // the two stages still in flight, so the waits below let them (NXG loads) stay in flight as well
-        load_epilogue_operands();
-        kstep(T{}, IC<2 * NP + NXG>{}, F{}, kt);
-        kstep(T{}, IC<NP + NXG>{}, F{}, kt + 1);
-        kstep(T{}, IC<NXG>{}, F{}, kt + 2);
-        kstep(F{}, IC<0>{}, F{}, kt + 3);
+        // the last four k-steps: nothing left to request for the ring
+        if (mid) {
+            kstep(T{}, IC<2 * NP>{}, F{}, kt);
+            kstep(T{}, IC<NP>{}, F{}, kt + 1);
+            kstep(T{}, IC<0>{}, F{}, kt + 2);
+            kstep(F{}, IC<0>{}, F{}, kt + 3);
+        } else {
+            load_epilogue_operands();
+            kstep(T{}, IC<2 * NP + NXG>{}, F{}, kt);
+            kstep(T{}, IC<NP + NXG>{}, F{}, kt + 1);
+            kstep(T{}, IC<NXG>{}, F{}, kt + 2);
+            kstep(F{}, IC<0>{}, F{}, kt + 3);
+        }
     } else {
         // short contractions (H < 128): everything requested up front, plain waits
         load_epilogue_operands();
