@@ -204,7 +204,12 @@ int jlm_pack_split_f16_col(const float *v, int rows, float scale, void *dst, int
  * b2[word] * 2^eB_i -- the kernel then feeds 1.0 at that position of every T
  * row and the bias costs nothing in the fold; bias_col[i] = -1: b2 is added in
  * the fold.  Same partial-slice contract and return value as
- * jlm_vocab_lse_stationary. */
+ * jlm_vocab_lse_stationary.  The vocabulary is cut into COLUMNS of equal cost
+ * (one workgroup per column and 256-row tile), at most 256 / row tiles of them;
+ * a column that crosses a segment boundary writes one slice per segment it
+ * touches, so a launch writes at most columns + n_segs - 1 slices, and
+ * max_parts (the capacity of `part` in slices) bounds the column count to
+ * max_parts - (n_segs - 1). */
 int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale,
                         const int *bias_col, int n_segs, const float *b2,
                         const float *T, int ldt, const int *rows,

@@ -164,7 +164,8 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 if (p->lse_cu_share_pct > 0 && p->lse_cu_share_pct < 100) {
                     const int n_ptiles = (bound + 255) / 256;
                     int c = 256 * p->lse_cu_share_pct / 100 / n_ptiles;
-                    if (c < m->n_segs) c = m->n_segs;
+                    if (c < 1) c = 1;
+                    c += m->n_segs - 1;            // slices = columns + the segment boundaries columns straddle
                     if (c < cap) cap = c;
                 }
                 int r = m->split_segs

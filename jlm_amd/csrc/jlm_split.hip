@@ -131,19 +131,27 @@ struct SplitChunks {
     static constexpr int start(int c) { return c * (NS / NC) + (c < NS % NC ? c : NS % NC); }
 };
 
+#define LSES_MAX_PARTS 96
+#define LSES_MAX_SUB (LSES_MAX_PARTS + JLM_MAX_SEGMENTS)
+
+// The vocabulary is cut into n_cols COLUMNS of equal cost (the launcher's cost model); a column is one workgroup per row tile.
+// A column that straddles a segment boundary walks two (or more) SUB-RANGES, one per segment it touches; every sub-range
+// produces its own slice of (max, sum exp) partials.
 struct LseSplitArgs {
-    int n_parts, n_segs;
+    int n_cols, n_sub, n_segs;
     jlm_segment seg[JLM_MAX_SEGMENTS];          // B = split rows, ldb in 4-byte units
     const float *bias[JLM_MAX_SEGMENTS];
     float t_scale[JLM_MAX_SEGMENTS];            // log2(e) * 2^eT: applied to T before it is split
     float descale[JLM_MAX_SEGMENTS];            // 2^-(eT + eB): accumulator -> base-2 logit
-    short part_first[JLM_MAX_SEGMENTS + 1];
     short bias_col[JLM_MAX_SEGMENTS];           // >= 0: the segment's bias is column bias_col of its split rows
+    unsigned char col_first[LSES_MAX_PARTS + 1];        // column c walks sub-ranges [col_first[c], col_first[c + 1])
+    unsigned char sub_seg[LSES_MAX_SUB];
+    unsigned short sub_t0[LSES_MAX_SUB], sub_t1[LSES_MAX_SUB];      // vocabulary tiles [t0, t1) of the segment
 };
 
 JLM_PROF_READER(jlm_prof_read_split)
 #if defined(JLM_PROFILE) || defined(JLM_WGTIME)
-// per-workgroup timeline (-DJLM_WGTIME: these stamps only, none of JLM_PROFILE's probes inside the loops) (constant 100 MHz clock): start, end, segment, row tile
+// per-workgroup timeline (-DJLM_WGTIME: these stamps only, none of JLM_PROFILE's probes inside the loops) (constant 100 MHz clock): start, end, segment (of the last sub-range), shader-clock cycles in between
 static __device__ unsigned long long jlm_prof_wg[1024][4];
 extern "C" int jlm_prof_read_wg(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof_wg), sizeof(jlm_prof_wg)) == hipSuccess ? 0 : -1;
@@ -178,7 +186,7 @@ extern "C" int jlm_tile_trace_read(unsigned long long *out) {
 // in one go) and stages no bias through LDS.  Needs a spare column (k % 16 != 0).
 template <int NS, int MT, bool BG, int NW>
 __device__ __forceinline__ void lse_split_body(
-    const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int p_in_seg, int parts_in_seg, int pt,
+    const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int vt0, int vt1, int pt,
     int n_paths, const float *__restrict__ T, int ldt, const int *__restrict__ rows, float2 *__restrict__ part_row,
     float *smem) {
     using CH = SplitChunks<NS>;
@@ -187,12 +195,12 @@ __device__ __forceinline__ void lse_split_body(
     constexpr int NINST = BMV / (4 * NW);          // LDS-DMA instructions per wave per chunk (4 rows each, NW waves)
     constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
     JLM_PROF_DECL();
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                 // per call: nothing derived from the lane id is hoisted over the sub-range loop
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // an SGPR: LDS-DMA destinations (M0) stay scalar
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
-    const int ntiles = (n_vocab + BMV - 1) / BMV;
-    const int vt0 = (int)((long)ntiles * p_in_seg / parts_in_seg), vt1 = (int)((long)ntiles * (p_in_seg + 1) / parts_in_seg);
     const float *__restrict__ Bp = sg.B;
     // 1. this lane's row operands: for step s the lane half h owns k = 16 s + 8 h .. + 7, both planes
     const int prow = pt * (32 * NW) + wave * 32 + li;
@@ -301,7 +309,7 @@ __device__ __forceinline__ void lse_split_body(
     int tt_n = 0;
     const int tt_cls = NS <= 4 ? 2 : (NS <= 7 ? 1 : 0);
     // the first range of each segment, row tile 0: any workgroup whose pis == 0 && pt == 0
-    const bool tt_wg = (p_in_seg == 0 && pt == 0 && wave == 0);
+    const bool tt_wg = (vt0 == 0 && pt == 0 && wave == 0);
 #endif
     for (int t = vt0; t < vt1; ++t) {
 #ifdef JLM_TILETRACE
@@ -450,8 +458,6 @@ __device__ __forceinline__ void lse_split_body(
     if (h == 0 && row_ok) part_row[prow] = make_float2(m, s);
 }
 
-#define LSES_MAX_PARTS 96
-
 template <int NW>
 __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, const float *__restrict__ T, int ldt,
                                                      const int *__restrict__ rows, float2 *__restrict__ part, int ld_part,
@@ -465,37 +471,43 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
     // n_parts = 8 q + r: the first 8 q ranges are dealt to the XCDs (block b runs on XCD b % 8), range p on XCD p % 8 with
     // all of its row tiles; the r < 8 ranges left over follow linearly -- their few workgroups land one or two per XCD, on the
     // CUs the 8 q ranges leave idle (10 row tiles: 3 x 10 = 30 of an XCD's 32 CUs)
-    const int nb8 = (a.n_parts & ~7) * n_ptiles;
+    const int nb8 = (a.n_cols & ~7) * n_ptiles;
     if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
-    else { const int bb = b - nb8; p = (a.n_parts & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
-    if (p >= a.n_parts || pt * (32 * NW) >= n_paths) return;
-    int si = 0;
-    while (si + 1 < a.n_segs && p >= a.part_first[si + 1]) ++si;
-    const jlm_segment sg = a.seg[si];
-    const float *bias = a.bias[si];
-    const float ts = a.t_scale[si], ds = a.descale[si];
-    const int pis = p - a.part_first[si], npis = a.part_first[si + 1] - a.part_first[si];
-    float2 *prow = part + (size_t)p * ld_part;
-    const int ns = (sg.k + 15) >> 4;
+    else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
+    if (p >= a.n_cols || pt * (32 * NW) >= n_paths) return;
 #if defined(JLM_PROFILE) || defined(JLM_WGTIME)
-    const unsigned long long wg_t0 = wall_clock64();
+    const unsigned long long wg_t0 = wall_clock64(), wg_c0 = clock64();
+    int si_last = 0;
 #endif
 #define JLM_LSE_CASE(NS_, MT_)                                                                                           \
     do {                                                                                                                 \
-        if (bg) lse_split_body<NS_, MT_, true, NW>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);  \
-        else lse_split_body<NS_, MT_, false, NW>(sg, bias, ts, ds, pis, npis, pt, n_paths, T, ldt, rows, prow, smem);    \
+        if (bg) lse_split_body<NS_, MT_, true, NW>(sg, bias, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);   \
+        else lse_split_body<NS_, MT_, false, NW>(sg, bias, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);     \
     } while (0)
-    const bool bg = a.bias_col[si] >= 0;
-    if (ns <= 2) JLM_LSE_CASE(2, 4);
-    else if (ns <= 4) JLM_LSE_CASE(4, 4);
-    else if (ns <= 7) JLM_LSE_CASE(7, 4);
-    else if (ns <= 10) JLM_LSE_CASE(10, 4);
-    else if (ns <= 13) JLM_LSE_CASE(13, 4);
-    else JLM_LSE_CASE(16, 2);
+    for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
+        const int si = a.sub_seg[r];
+        const jlm_segment sg = a.seg[si];
+        const float *bias = a.bias[si];
+        const float ts = a.t_scale[si], ds = a.descale[si];
+        const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
+        float2 *prow = part + (size_t)r * ld_part;
+        const int ns = (sg.k + 15) >> 4;
+        const bool bg = a.bias_col[si] >= 0;
+        if (r != a.col_first[p]) __syncthreads();          // the previous sub-range's last fold may still read its staged biases
+        if (ns <= 2) JLM_LSE_CASE(2, 4);
+        else if (ns <= 4) JLM_LSE_CASE(4, 4);
+        else if (ns <= 7) JLM_LSE_CASE(7, 4);
+        else if (ns <= 10) JLM_LSE_CASE(10, 4);
+        else if (ns <= 13) JLM_LSE_CASE(13, 4);
+        else JLM_LSE_CASE(16, 2);
+#if defined(JLM_PROFILE) || defined(JLM_WGTIME)
+        si_last = si;
+#endif
+    }
 #undef JLM_LSE_CASE
 #if defined(JLM_PROFILE) || defined(JLM_WGTIME)
     if (threadIdx.x == 0 && b < 1024) {
-        jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si; jlm_prof_wg[b][3] = pt;
+        jlm_prof_wg[b][0] = wg_t0; jlm_prof_wg[b][1] = wall_clock64(); jlm_prof_wg[b][2] = si_last; jlm_prof_wg[b][3] = clock64() - wg_c0;
     }
 #endif
 }
@@ -528,8 +540,9 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     // alone runs 3 % faster), but the 16 CUs the multiple of 8 leaves idle are where the other batch in flight runs its
     // small kernels meanwhile: the decode is 2.8 % slower with them taken (2.59 vs 2.52 ms per step, tools/ab_engine.py)
     if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
-    long work[JLM_MAX_SEGMENTS], total = 0;
     int ntiles[JLM_MAX_SEGMENTS];
+    double ctile[JLM_MAX_SEGMENTS], total = 0.0;
+    long n_tiles_all = 0;
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
         const int ns = (sg.k + 15) / 16;
@@ -543,45 +556,88 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         a.descale[i] = descale[i];
         const int bmv = ns > 13 ? 64 : 128;
         ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
-        // Cost of a vocabulary row ~ (k-steps + c0): the MFMAs plus a per-row constant (fold, staging).
+        if (ntiles[i] > 65535) return -2;
+        // Cost of a vocabulary tile ~ (k-steps + c0): the MFMAs plus a per-tile constant (fold, staging).
         // The per-workgroup timeline of the mixed launch (tools/probes/lse_wg_timeline.py on a -DJLM_WGTIME
         // build) gives 9.0 / 5.4 / 3.76 us per 128-word tile at 13 / 7 / 4 k-steps = 0.58 (k-steps + 2.5).
-        work[i] = (long)(sg.v_end - sg.v_start) * (2 * ns + c0x2);
-        total += work[i];
+        ctile[i] = (2 * ns + c0x2) * (bmv / 128.0);
+        total += ctile[i] * ntiles[i];
+        n_tiles_all += ntiles[i];
     }
     static int nw = -1;
     if (nw < 0) { const char *e = getenv("JLM_LSE_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }
     const int n_ptiles = (n_rows_max + 32 * nw - 1) / (32 * nw);
-    int cap = max_parts < LSES_MAX_PARTS ? max_parts : LSES_MAX_PARTS;
-    if (cap < n_segs) return -1;
+    int cap = max_parts < LSES_MAX_SUB ? max_parts : LSES_MAX_SUB;
+    cap -= n_segs - 1;                          // slices: one per column + one per segment boundary a column straddles
+    if (cap > LSES_MAX_PARTS) cap = LSES_MAX_PARTS;
+    if (cap < 1) return -1;
     int np = ((nw == 8 ? 1 : 2) * 256) / n_ptiles; // one resident round: 2 four-wave / 1 eight-wave workgroup per CU
-    if (np < n_segs) np = n_segs;
+    if (np < 1) np = 1;
     if (np > cap) np = cap;
     if (np >= 8 && np8) np &= ~7;
-    // JLM_LSE_NP=<ranges> for launches that would use >= 8 (read on every call: tools/ab_np.py changes it in-process)
+    // JLM_LSE_NP=<columns> for launches that would use >= 8 (read on every call: tools/ab_np.py changes it in-process)
     int np_force = 0;
     { const char *e = getenv("JLM_LSE_NP"); np_force = e ? atoi(e) : 0; }
     if (np_force > 0 && np_force <= cap) np = np_force;
-    if (np < n_segs) np = n_segs;
-    int given = 0, k[JLM_MAX_SEGMENTS];
-    for (int i = 0; i < n_segs; ++i) {
-        k[i] = (int)((work[i] * np + total / 2) / total);
-        if (k[i] < 1) k[i] = 1;
-        if (k[i] > ntiles[i]) k[i] = ntiles[i];
-        given += k[i];
-    }
-    for (int guard = 0; given != np && guard < 4 * LSES_MAX_PARTS; ++guard) {
-        int best = -1;
-        for (int i = 0; i < n_segs; ++i) {
-            if (given < np) { if (k[i] < ntiles[i] && (best < 0 || work[i] * k[best] > work[best] * k[i])) best = i; }
-            else { if (k[i] > 1 && (best < 0 || work[i] * k[best] < work[best] * k[i])) best = i; }
+    if (np > n_tiles_all) np = (int)n_tiles_all;
+    // Min-max cuts of the concatenated segments: the smallest column budget M (bisection) with which a greedy fill -- a
+    // column takes whole tiles while they fit; at a segment's end it goes on in the next one when what is left pays for the
+    // second prologue (the T operands of the other segment: ~0.7 of a tile, JLM_LSE_PRO) and one tile -- needs <= np
+    // columns.  A column is one sub-range per segment it touches.
+    static double pro = -1.0;
+    if (pro < 0) { const char *e = getenv("JLM_LSE_PRO"); pro = e ? atof(e) : 0.7; }
+    int n_sub = 0, n_cols = 0;
+    auto fill = [&](double M, bool emit) -> int {
+        int seg = 0, t = 0, cols = 0;
+        n_sub = 0;
+        while (seg < n_segs) {
+            if (emit) { if (cols >= LSES_MAX_PARTS) return -1; a.col_first[cols] = (unsigned char)n_sub; }
+            double budget = M;
+            bool first = true;
+            while (seg < n_segs) {
+                if (!first) {
+                    if (budget < (pro + 1.0) * ctile[seg]) break;
+                    budget -= pro * ctile[seg];
+                }
+                const int avail = ntiles[seg] - t;
+                int take = (int)(budget / ctile[seg] + 1e-9);
+                if (take > avail) take = avail;
+                if (take < 1) { if (!first) break; take = 1; }
+                if (emit) {
+                    if (n_sub >= LSES_MAX_SUB) return -1;
+                    a.sub_seg[n_sub] = (unsigned char)seg;
+                    a.sub_t0[n_sub] = (unsigned short)t;
+                    a.sub_t1[n_sub] = (unsigned short)(t + take);
+                }
+                ++n_sub;
+                budget -= take * ctile[seg];
+                first = false;
+                t += take;
+                if (t < ntiles[seg]) break;
+                ++seg;
+                t = 0;
+            }
+            ++cols;
         }
-        if (best < 0) break;
-        if (given < np) { ++k[best]; ++given; } else { --k[best]; --given; }
+        if (emit) a.col_first[cols] = (unsigned char)n_sub;
+        return cols;
+    };
+    {
+        double cmax = 0.0;
+        for (int i = 0; i < n_segs; ++i) cmax = ctile[i] > cmax ? ctile[i] : cmax;
+        double lo = total / np, hi = total / np + 2.0 * cmax * (1.0 + pro) * n_segs + 1.0;
+        for (int it = 0; it < 32; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid, false) <= np) hi = mid; else lo = mid;
+        }
+        n_cols = fill(hi, true);
+        if (n_cols < 1 || n_cols > np) return -4;
     }
-    a.part_first[0] = 0;
-    for (int i = 0; i < n_segs; ++i) a.part_first[i + 1] = (short)(a.part_first[i] + k[i]);
-    a.n_parts = given;
+    np = n_cols;
+    a.n_cols = np;
+    a.n_sub = n_sub;
+    const int given = n_sub;
+    if (given > max_parts) return -1;
     const int lds = (2 * 128 * 64 + 3 * 128) * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -592,7 +648,7 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
             return -3;
         attr_set = true;
     }
-    const int grid = given * n_ptiles;
+    const int grid = np * n_ptiles;
     if (nw == 8)
         hipLaunchKernelGGL(vocab_lse_split8_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
                            reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);

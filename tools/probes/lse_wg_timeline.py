@@ -37,5 +37,7 @@ for sgi in range(3):
     m = a[:, 2] == sgi
     print("seg %d: %3d WGs  start %.1f..%.1f us  duration mean %.1f  min %.1f  max %.1f  end max %.1f" % (
         sgi, m.sum(), st[m].min(), st[m].max(), (en - st)[m].mean(), (en - st)[m].min(), (en - st)[m].max(), en[m].max()))
+print("shader clock while the workgroups ran: mean %.3f GHz (min %.3f, max %.3f)" % tuple(
+    f((a[:, 3] / ((a[:, 1] - a[:, 0]) * 10.0))) for f in (np.mean, np.min, np.max)))
 late = st > 5
 print("WGs starting later than 5 us:", int(late.sum()), " their starts:", np.sort(st[late])[:12])
