@@ -184,6 +184,20 @@ extern "C" int jlm_tile_trace_read(unsigned long long *out) {
 // BG: the bias rides in the GEMM -- column sg.k of the split rows holds bias * 2^eB and the row operand
 // gets 1.0 there -- so the fold is max3 / fma / exp / add per logit (the fma forms acc * 2^-(eT+eB) - max
 // in one go) and stages no bias through LDS.  Needs a spare column (k % 16 != 0).
+// -DJLM_ABL=<bits>: measurement builds only (tools/probes/lse_ablate.sh): 1 = no fold, 2 = no MFMAs, 4 = no fragment reads from LDS,
+// 8 = no LDS-DMA.  Results are wrong by construction; the point is the time and the shader clock of what is left.
+#ifndef JLM_LSE_HALF
+#define JLM_LSE_HALF 1          // bias-column segments: the fold rides between the MFMAs (lse_split_body_h)
+#endif
+#ifndef JLM_ABL
+#define JLM_ABL 0
+#endif
+#if JLM_ABL & 2
+static __device__ __forceinline__ f32x16 lse_mfma_off(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+#define LSE_MFMA(a, b, c) lse_mfma_off(a, b, c)
+#else
+#define LSE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 template <int NS, int MT, bool BG, int NW>
 __device__ __forceinline__ void lse_split_body(
     const jlm_segment &sg, const float *__restrict__ bias, float t_scale, float descale, int vt0, int vt1, int pt,
@@ -256,6 +270,7 @@ __device__ __forceinline__ void lse_split_body(
     const unsigned lane_row_b = (unsigned)lrow * (unsigned)ldb * 4u;
     const unsigned row4_b = 16u * (unsigned)ldb;                   // bytes between the rows of consecutive pieces
     auto issue = [&](int t, int c_start, int buf) {                // chunk = steps [c_start, ...)
+        if (JLM_ABL & 8) return;
         int g0 = dma_g0;
         asm volatile("" : "+v"(g0));               // keep the per-chunk offsets out of the loop-invariant registers
         unsigned voff[4];
@@ -336,7 +351,10 @@ __device__ __forceinline__ void lse_split_body(
             const int csz = CH::size(c), cst = CH::start(c);
             auto load_plane = [&](f16x8 (&dst)[MT], int j, int p) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const f16x8 *>(bs + mt * 32 * 64 + goff[j][p]);
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (JLM_ABL & 4) { asm volatile("" : "=v"(dst[mt])); continue; }
+                    dst[mt] = *reinterpret_cast<const f16x8 *>(bs + mt * 32 * 64 + goff[j][p]);
+                }
             };
             // (steps past the segment's own k, when NS is rounded up, multiply zero T operands: no
             //  run-time guards in here, they would split the chunk into basic blocks)
@@ -350,17 +368,17 @@ __device__ __forceinline__ void lse_split_body(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt], 0, 0, 0);
+                    acc[mt] = LSE_MFMA(al[mt], thi[st], (c == 0 && j == 0) ? zero16 : acc[mt]);
                 if (j + 1 < 4 && more) {           // both planes of step j+1 (lo refilled in place: behind the lo.hi group)
                     load_plane(al, j + 1 < 4 ? j + 1 : 0, 1);
                     load_plane(ah[(j + 1) & 1], j + 1 < 4 ? j + 1 : 0, 0);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], tlo[st], acc[mt], 0, 0, 0);
+                    acc[mt] = LSE_MFMA(ah[j & 1][mt], tlo[st], acc[mt]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mt], thi[st], acc[mt], 0, 0, 0);
+                    acc[mt] = LSE_MFMA(ah[j & 1][mt], thi[st], acc[mt]);
                 // issue order: the MT lo.hi MFMAs, then ONE fragment read behind every following MFMA (tools/probes/gate_loop.hip:
                 // reads grouped in front of an MFMA group cost 12 % of the k-step, interleaved 1:1 they are free)
                 __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
@@ -393,7 +411,11 @@ __device__ __forceinline__ void lse_split_body(
 #endif
         JLM_PROF_MARK(p_x);
         // fold this tile's 16*MT logits of the lane's row into (m, s), base-2 units
-        if (BG) {
+        if (JLM_ABL & 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(acc[mt]));     // every accumulator stays live
+            s += acc[0][0];
+        } else if (BG) {
             if ((t + 1) * BMV > n_vocab) {         // the segment's last, partial tile: rows past it re-read its last row
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -458,6 +480,236 @@ __device__ __forceinline__ void lse_split_body(
     if (h == 0 && row_ok) part_row[prow] = make_float2(m, s);
 }
 
+// The same with the fold INSIDE the MFMA stream (bias-column segments).  A tile's MT blocks are walked as two halves:
+// within a chunk first every k-step of blocks [0, MT/2), then every k-step of blocks [MT/2, MT).  Once a tile's last chunk
+// has finished the first half, those accumulators are final: their fold (max3 / fma / exp / add per logit) is issued between
+// the MFMAs of the second half; the second half's fold rides between the first-half MFMAs of the NEXT tile's first chunk.
+// Same registers, same LDS layout, same DMA as lse_split_body -- only the order differs.  Why: folding after the tile, all
+// eight waves at once, leaves the matrix pipe idle for 1 250 cycles per tile (19.5 cycles per logit and wave); between a
+// wave's own MFMAs the same VALU work costs 4.4 SIMD cycles per logit (tools/probes/mfma_valu_inwave.hip).
+template <int NS, int MT, int NW>
+__device__ __forceinline__ void lse_split_body_h(
+    const jlm_segment &sg, float t_scale, float descale, int vt0, int vt1, int pt, int n_paths, const float *__restrict__ T, int ldt,
+    const int *__restrict__ rows, float2 *__restrict__ part_row, float *smem) {
+    using CH = SplitChunks<NS>;
+    constexpr int NC = CH::NC;
+    constexpr int HM = MT / 2;                     // blocks per half
+    constexpr int BMV = 32 * MT;                   // vocabulary rows per tile
+    constexpr int NINST = BMV / (4 * NW);          // LDS-DMA instructions per wave per chunk (4 rows each, NW waves)
+    constexpr int NE = 16 * HM;                    // logits per lane and half
+    constexpr float LN2 = 0.6931471805599453f;
+    static_assert(MT % 2 == 0, "two halves");
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                 // per call: nothing derived from the lane id is hoisted over the sub-range loop
+    const int tid = tid_, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // an SGPR: LDS-DMA destinations (M0) stay scalar
+    const int h = lane >> 5, li = lane & 31;
+    const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
+    const float *__restrict__ Bp = sg.B;
+    const int prow = pt * (32 * NW) + wave * 32 + li;
+    const bool row_ok = prow < n_paths;
+    const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
+    f16x8 thi[NS], tlo[NS];
+    {   // as in lse_split_body: the lane's row operands, the constant 1.0 of the bias column at k == K
+        constexpr int NG = (NS + 3) / 4;
+        f32x4 xb[2][4][2];
+        auto load_group = [&](int g, int par) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = 16 * (4 * g + j) + 8 * h + 4 * q;
+                    xb[par][j][q] = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
+                }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int st = 4 * g + j;
+                if (st >= NS) break;
+                float x[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * st + 8 * h + 4 * q + e;
+                        x[4 * q + e] = (row_ok && k < K) ? xb[g & 1][j][q][e] : (row_ok && k == K) ? 1.0f : 0.0f;
+                    }
+                split8(x, t_scale, thi[st], tlo[st]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float *Bs = smem;                              // [2][BMV][64]
+    const int lrow = lane >> 4, pslot = lane & 15;
+    const int dma_g0 = pslot ^ ((wave * NINST * 4 + lrow) & 15);
+    const unsigned lane_row_b = (unsigned)lrow * (unsigned)ldb * 4u;
+    const unsigned row4_b = 16u * (unsigned)ldb;
+    auto issue = [&](int t, int c_start, int buf) {                // as in lse_split_body
+        int g0 = dma_g0;
+        asm volatile("" : "+v"(g0));
+        unsigned voff[4];
+#pragma unroll
+        for (int q = 0; q < 4 && q < NINST; ++q)
+            voff[q] = lane_row_b + 4u * (unsigned)min(c_start * 16 + ((g0 ^ (4 * q)) << 2), ldb - 4);
+        const int row0 = t * BMV + wave * NINST * 4;
+        if (row0 + NINST * 4 <= n_vocab) {
+            const char *sbase = reinterpret_cast<const char *>(Bp) + (size_t)row0 * ldb * 4;
+#pragma unroll
+            for (int i = 0; i < NINST; ++i)
+                GLDS16(sbase + (size_t)i * row4_b + voff[i & 3], Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) {
+                const int vrow = min(row0 + 4 * i + lrow, n_vocab - 1);
+                const unsigned off = (unsigned)vrow * (unsigned)ldb * 4u + (voff[i & 3] - lane_row_b);
+                GLDS16(reinterpret_cast<const char *>(Bp) + off, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+            }
+        }
+    };
+    float m = JLM_NEG_BIG, s = 0.0f;
+    f32x16 acc[MT];
+    // the first tile's first half folds "the previous tile's second half": finite, far below any logit -- whatever it leaves in
+    // (m, s) is scaled by 2^(m - max) = 0 at the first real fold
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = -1.0e30f;
+    int goff[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) goff[j][p] = li * 64 + (((4 * j + 2 * h + p) ^ (li & 15)) * 4);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // rows of the segment's last, partial tile that lie past its end re-read the last row: their logits are struck out
+    auto mask_half = [&](int hf, int t) {
+        if ((t + 1) * BMV > n_vocab) {
+#pragma unroll
+            for (int q = 0; q < HM; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * BMV + (hf * HM + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= n_vocab) acc[hf * HM + q][r] = JLM_NEG_BIG;
+        }
+    };
+    // the fold of one half, cut into `parts` slices that are issued between the MFMAs of `parts` consecutive k-steps:
+    // slice 0 also finds the half's maximum and the new running maximum, the last slice closes the running sum
+    float f_nmn = 0.0f, f_sc = 0.0f, f_a0 = 0.0f, f_a1 = 0.0f;
+    auto fold_slice = [&](int hf, int i, int parts) {
+        if (i == 0) {
+            float tmax = JLM_NEG_BIG;
+#pragma unroll
+            for (int q = 0; q < HM; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, acc[hf * HM + q][r]), acc[hf * HM + q][r + 1]);
+            const float mn = fmaxf(m, tmax * descale);             // descale > 0
+            f_sc = __builtin_amdgcn_exp2f(m - mn);
+            f_nmn = -mn;
+            f_a0 = f_a1 = 0.0f;
+            m = mn;
+        }
+        const int e0 = NE * i / parts, e1 = NE * (i + 1) / parts;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (e < e0 || e >= e1) continue;
+            const float x = __builtin_amdgcn_exp2f(fmaf(acc[hf * HM + (e >> 4)][e & 15], descale, f_nmn));
+            if (e & 1) f_a1 += x; else f_a0 += x;
+        }
+        if (i == parts - 1) s = s * f_sc + (f_a0 + f_a1);
+    };
+    issue(vt0, 0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = vt0; t < vt1; ++t) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool last_c = (c == NC - 1);
+            if (last_c) issue(t + 1, 0, buf ^ 1);                    // past the range: harmless (next range / last row)
+            else issue(t, CH::start(c + 1 < NC ? c + 1 : 0), buf ^ 1);
+            const float *bs = Bs + buf * BMV * 64;
+            f16x8 ah[2][HM], al[HM];
+            const int csz = CH::size(c), cst = CH::start(c);
+            auto load_plane = [&](f16x8 (&dst)[HM], int hf, int j, int p) {
+#pragma unroll
+                for (int q = 0; q < HM; ++q) dst[q] = *reinterpret_cast<const f16x8 *>(bs + (hf * HM + q) * 32 * 64 + goff[j][p]);
+            };
+            // stages of the chunk: (half 0, steps 0 .. csz-1), (half 1, steps 0 .. csz-1); the fragments of stage i+1 are
+            // requested behind the first MFMA group of stage i
+            load_plane(al, 0, 0, 1);
+            load_plane(ah[0], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i >= 2 * csz) break;                       // compile-time bound
+                const int hf = i >= csz ? 1 : 0, j = hf ? i - csz : i;
+                const int st = cst + j;
+                const bool more = (i + 1 < 2 * csz);
+                if (hf == 1 && j == 0 && last_c) mask_half(0, t);   // (uniform, rare) the first half is final here
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < HM; ++q)
+                    acc[hf * HM + q] = LSE_MFMA(al[q], thi[st], (c == 0 && j == 0) ? zero16 : acc[hf * HM + q]);
+                if (more) {
+                    const int hn = (i + 1) >= csz ? 1 : 0, jn = hn ? i + 1 - csz : i + 1;
+                    load_plane(al, hn, jn, 1);
+                    load_plane(ah[(i + 1) & 1], hn, jn, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < HM; ++q) acc[hf * HM + q] = LSE_MFMA(ah[i & 1][q], tlo[st], acc[hf * HM + q]);
+#pragma unroll
+                for (int q = 0; q < HM; ++q) acc[hf * HM + q] = LSE_MFMA(ah[i & 1][q], thi[st], acc[hf * HM + q]);
+                // the fold slice that rides in this stage
+                const bool f_prev = (c == 0 && hf == 0), f_cur = (last_c && hf == 1);
+                if (f_prev) fold_slice(1, j, csz);
+                if (f_cur) fold_slice(0, j, csz);
+                // issue order: one fragment read and a share of the fold behind every MFMA
+                constexpr int VPM = (3 * NE + 24) / 3 / (3 * HM) + 1;      // VALU per MFMA when a 3-step chunk carries a fold
+                if (f_prev || f_cur) {
+#pragma unroll
+                    for (int g = 0; g < HM; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 2 * HM; ++g) {
+                        if (more) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, HM, 0);
+                    if (more) {
+#pragma unroll
+                        for (int g = 0; g < 2 * HM; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * HM, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        mask_half(1, t);                                           // (uniform, rare: the range's last tile at most)
+    }
+    // the last tile's second half
+    if (vt1 > vt0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fold_slice(1, i, 2);
+    }
+    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+    {
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm * LN2;
+    }
+    if (h == 0 && row_ok) part_row[prow] = make_float2(m, s);
+}
+
 template <int NW>
 __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, const float *__restrict__ T, int ldt,
                                                      const int *__restrict__ rows, float2 *__restrict__ part, int ld_part,
@@ -481,7 +733,8 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
 #endif
 #define JLM_LSE_CASE(NS_, MT_)                                                                                           \
     do {                                                                                                                 \
-        if (bg) lse_split_body<NS_, MT_, true, NW>(sg, bias, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);   \
+        if (bg && JLM_LSE_HALF) lse_split_body_h<NS_, MT_, NW>(sg, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);  \
+        else if (bg) lse_split_body<NS_, MT_, true, NW>(sg, bias, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem); \
         else lse_split_body<NS_, MT_, false, NW>(sg, bias, ts, ds, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);     \
     } while (0)
     for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
@@ -535,7 +788,7 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     LseSplitArgs a;
     a.n_segs = n_segs;
     static int c0x2 = -1, np8 = -1;            // cost constant in half k-steps; JLM_LSE_NP8=1: range count a multiple of 8
-    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 5; }
+    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 2; }
     // JLM_LSE_NP8=0 lets the range count use every CU (25 ranges x 10 row tiles = 250 workgroups instead of 240: the kernel
     // alone runs 3 % faster), but the 16 CUs the multiple of 8 leaves idle are where the other batch in flight runs its
     // small kernels meanwhile: the decode is 2.8 % slower with them taken (2.59 vs 2.52 ms per step, tools/ab_engine.py)
@@ -557,9 +810,10 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
         const int bmv = ns > 13 ? 64 : 128;
         ntiles[i] = (sg.v_end - sg.v_start + bmv - 1) / bmv;
         if (ntiles[i] > 65535) return -2;
-        // Cost of a vocabulary tile ~ (k-steps + c0): the MFMAs plus a per-tile constant (fold, staging).
-        // The per-workgroup timeline of the mixed launch (tools/probes/lse_wg_timeline.py on a -DJLM_WGTIME
-        // build) gives 9.0 / 5.4 / 3.76 us per 128-word tile at 13 / 7 / 4 k-steps = 0.58 (k-steps + 2.5).
+        // Cost of a vocabulary tile ~ (k-steps + c0): the MFMAs plus a per-tile constant (barrier, what the fold costs between
+        // the MFMAs).  The per-workgroup timeline of the mixed launch (tools/probes/lse_wg_timeline.py on a -DJLM_WGTIME
+        // build) gives 8.15 / 4.62 / 2.95 us per 128-word tile at 13 / 7 / 4 k-steps = 0.58 (k-steps + 1.1); a sweep of the
+        // constant (JLM_LSE_C0 = 0.5 .. 2) is flat within the noise between 1 and 2.
         ctile[i] = (2 * ns + c0x2) * (bmv / 128.0);
         total += ctile[i] * ntiles[i];
         n_tiles_all += ntiles[i];
@@ -582,10 +836,11 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (np > n_tiles_all) np = (int)n_tiles_all;
     // Min-max cuts of the concatenated segments: the smallest column budget M (bisection) with which a greedy fill -- a
     // column takes whole tiles while they fit; at a segment's end it goes on in the next one when what is left pays for the
-    // second prologue (the T operands of the other segment: ~0.7 of a tile, JLM_LSE_PRO) and one tile -- needs <= np
-    // columns.  A column is one sub-range per segment it touches.
+    // second start (the last fold, the T operands of the other segment, the first chunk's exposed latency: ~9 us = 17
+    // k-steps in the timeline, JLM_LSE_PRO) and one tile -- needs <= np columns.  A column is one sub-range per segment
+    // it touches.
     static double pro = -1.0;
-    if (pro < 0) { const char *e = getenv("JLM_LSE_PRO"); pro = e ? atof(e) : 0.7; }
+    if (pro < 0) { const char *e = getenv("JLM_LSE_PRO"); pro = 2.0 * (e ? atof(e) : 17.0); }
     int n_sub = 0, n_cols = 0;
     auto fill = [&](double M, bool emit) -> int {
         int seg = 0, t = 0, cols = 0;
@@ -596,8 +851,8 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
             bool first = true;
             while (seg < n_segs) {
                 if (!first) {
-                    if (budget < (pro + 1.0) * ctile[seg]) break;
-                    budget -= pro * ctile[seg];
+                    if (budget < pro + ctile[seg]) break;
+                    budget -= pro;
                 }
                 const int avail = ntiles[seg] - t;
                 int take = (int)(budget / ctile[seg] + 1e-9);
@@ -625,7 +880,7 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     {
         double cmax = 0.0;
         for (int i = 0; i < n_segs; ++i) cmax = ctile[i] > cmax ? ctile[i] : cmax;
-        double lo = total / np, hi = total / np + 2.0 * cmax * (1.0 + pro) * n_segs + 1.0;
+        double lo = total / np, hi = total / np + (2.0 * cmax + pro) * n_segs + 1.0;
         for (int it = 0; it < 32; ++it) {
             const double mid = 0.5 * (lo + hi);
             if (fill(mid, false) <= np) hi = mid; else lo = mid;

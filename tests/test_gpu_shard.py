@@ -72,6 +72,19 @@ def test_two_ranks_on_one_gpu_equal_one_rank(fx):
     from jlm_amd.decoder import Decoder
     one = Decoder(1).decode_batch(sents, beam_width=10)
     assert len(merged) == len(one) == len(sents)
+    # the two runs cut the batch differently (512- vs 1 024-sentence device batches: other vocabulary ranges, other
+    # summation order in the last float32 bits), so the order may differ only between hypotheses that tie at 1e-6
+    n_reordered = 0
     for si, (x, y) in enumerate(zip(merged, one)):
-        assert [w for _, w in x] == [w for _, w in y], si
+        assert len(x) == len(y), si
+        assert x[0][1] == y[0][1], ("1-best differs", si)
         np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=0, atol=2e-5)
+        if [w for _, w in x] == [w for _, w in y]:
+            continue
+        n_reordered += 1
+        yscore = {tuple(w): v for v, w in y}
+        for i, (_v, w) in enumerate(x):
+            if w != y[i][1]:
+                ref = yscore.get(tuple(w), y[-1][0])
+                assert abs(ref - y[i][0]) <= 1e-6 * max(1.0, abs(y[i][0])), ("order differs beyond a tie", si, i, ref, y[i][0])
+    assert n_reordered <= len(sents) // 50, n_reordered

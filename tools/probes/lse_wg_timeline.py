@@ -10,6 +10,7 @@ L.jlm_vocab_lse_split.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_voi
     ctypes.c_void_p, ctypes.c_void_p]
 L.jlm_pack_split_f16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                  ctypes.c_int, ctypes.c_void_p]
+L.jlm_pack_split_f16_col.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 L.jlm_prof_read_wg.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 bounds, widths, R = [0, 12000, 30000, 50000], [200, 100, 50], 2560
@@ -22,8 +23,13 @@ for i, k in enumerate(widths):
     assert L.jlm_pack_split_f16(Bm.data_ptr(), nv, kp, kp, 1024.0, Bs.data_ptr(), k16, None) == 0
     keep += [Bm, Bs]; segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bs.data_ptr(), k16); off += kp
 T, b2 = torch.randn(R, off, device=dev), torch.randn(50000, device=dev) * 0.05
+# the bias as a GEMM column (what the decode uses for these widths); BCOL=0: the bias added in the fold
+bcol = (ctypes.c_int * n)(*[(w + 3) // 4 * 4 for w in widths]) if os.environ.get("BCOL", "1") != "0" else None
+if bcol is not None:
+    for i in range(n):
+        assert L.jlm_pack_split_f16_col(b2.data_ptr() + 4 * bounds[i], bounds[i + 1] - bounds[i], 1024.0, segs[i].B, segs[i].ldb, bcol[i], None) == 0
 part = torch.empty((96, R, 2), device=dev)
-f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, None, n, b2.data_ptr(), T.data_ptr(), off, None, part.data_ptr(), R, 96, R, None, None)
+f = lambda: L.jlm_vocab_lse_split(segs, ts, ds, bcol, n, b2.data_ptr(), T.data_ptr(), off, None, part.data_ptr(), R, 96, R, None, None)
 for _ in range(5): npart = f()
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
