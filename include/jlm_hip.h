@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 4
+#define JLM_ABI_VERSION 5
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
 int jlm_device_arch(int dev, char *buf, int buflen);
@@ -246,6 +246,23 @@ int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const float *b2,
                      float *run_max, double *run_sum, double *lse,
                      int merge, int beam, int n_groups, void *stream);
 
+/* jlm_edge_logits / jlm_wordlist_lse with the weight row and the bias of a list position taken from DIFFERENT words:
+ * position i uses the weight row of word wl_w[i] and the bias of word wl[i] (wl_w == NULL: the plain forms).  This is
+ * what the reference computes in DynamicDecoder on D-softmax / D-softmax* models, where project() returns the
+ * columns of a vocabulary subset segment-major and the caller reads them in list order (model.py:152-158,168-179
+ * under decoder_dynamic.py:130) -- reproduced behind DynamicDecoder.compat_quirks. */
+int jlm_edge_logits_perm(const jlm_segment *segs_host, int n_segs, const float *b2,
+                         const float *T, int ldt,
+                         const int *g0, const int *cnt, const int *cnt_idx,
+                         const int *wl, const int *wl_w, const int *wl_off, const int *wl_idx, int wl_base,
+                         const int *wl_out, float *edge, int beam, int n_groups, void *stream);
+int jlm_wordlist_lse_perm(const jlm_segment *segs_host, int n_segs, const float *b2,
+                          const float *T, int ldt,
+                          const int *g0, const int *cnt, const int *cnt_idx,
+                          const int *wl, const int *wl_w, const int *wl_off, const int *wl_idx, int wl_base,
+                          float *run_max, double *run_sum, double *lse,
+                          int merge, int beam, int n_groups, void *stream);
+
 /* jlm_wordlist_lse on split rows, single-segment models (seg->B = split rows scaled by 2^eB,
  * t_scale = 2^eT, descale = 2^-(eT+eB) as for jlm_vocab_lse_split; b2 is added in the fold).
  * max_words = longest word list among the groups (<= 4064).  Returns -2 when the shape is outside
@@ -383,6 +400,12 @@ typedef struct {
      * behind it: 2.61 -> 2.33 ms per step at BASELINE configs[1] with 16 instead of 24 vocabulary ranges (tools/ab_np.py) */
     int lse_cu_share_pct;
     int *out_nodes; int *out_len; double *out_score; int stride;    /* jlm_backtrace outputs */
+    /* kind 2 with a SEGMENTED projection, reference-compatibility mode (both NULL otherwise).  The reference's project()
+     * returns a vocabulary subset's columns segment-major while DynamicDecoder indexes them -- and adds the bias -- in list
+     * order (decoder_dynamic.py:76,130,172 over model.py:152-158,168-179), so list position j of a cell's first
+     * vocabulary pairs the weight row of word di_wwords[j] with the bias and the identity of word di_words[j]; sg_wword[e]
+     * is the word whose weight row the reference reads for lattice edge e (parallel to sg_word). */
+    const int *di_wwords, *sg_wword;
 } jlm_decode_plan;
 
 /* Returns 0 or a hipError_t.  st_host->lse_part / n_parts are managed by the call.  A full-vocabulary

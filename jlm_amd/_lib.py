@@ -56,7 +56,8 @@ class DecodePlan(Structure):
                 ("di_words", c_void_p), ("di_off", c_void_p), ("di_idx", c_void_p), ("di_max", c_int),
                 ("dd_words", c_void_p), ("dd_off", c_void_p), ("dd_max", c_int),
                 ("run_max", c_void_p), ("run_sum", c_void_p), ("part", c_void_p), ("max_parts", c_int), ("lse_cu_share_pct", c_int),
-                ("out_nodes", c_void_p), ("out_len", c_void_p), ("out_score", c_void_p), ("stride", c_int)]
+                ("out_nodes", c_void_p), ("out_len", c_void_p), ("out_score", c_void_p), ("stride", c_int),
+                ("di_wwords", c_void_p), ("sg_wword", c_void_p)]
 
 
 P = c_void_p
@@ -81,6 +82,9 @@ _SIGS = {
     "jlm_edge_logits": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
     "jlm_wordlist_lse": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
                          c_int),
+    "jlm_edge_logits_perm": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, c_int, c_int, P], c_int),
+    "jlm_wordlist_lse_perm": ([POINTER(Segment), c_int, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P, c_int, c_int, c_int, P],
+                              c_int),
     "jlm_wordlist_lse_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, P, P, P, P, P, c_int, c_int, P, P, P,
                                c_int, c_int, c_int, P], c_int),
     "jlm_wordlist_merge_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_int,
@@ -116,7 +120,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 4:
+        if l.jlm_abi_version() != 5:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

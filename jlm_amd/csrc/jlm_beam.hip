@@ -20,9 +20,9 @@ template <int MODE>   // 0: edge logits, 1: log-sum-exp over the list
 __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
     SegTable segs, const float *__restrict__ b2, const float *__restrict__ T, int ldt,
     const int *__restrict__ g0v, const int *__restrict__ cnt, const int *__restrict__ cnt_idx,
-    const int *__restrict__ wl, const int *__restrict__ wl_off, const int *__restrict__ wl_idx, int wl_base,
-    const int *__restrict__ wl_out, float *__restrict__ edge, float *__restrict__ run_max, double *__restrict__ run_sum,
-    double *__restrict__ lse, int merge, int beam) {
+    const int *__restrict__ wl, const int *__restrict__ wl_w, const int *__restrict__ wl_off, const int *__restrict__ wl_idx,
+    int wl_base, const int *__restrict__ wl_out, float *__restrict__ edge, float *__restrict__ run_max,
+    double *__restrict__ run_sum, double *__restrict__ lse, int merge, int beam) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int j = blockIdx.x;
     const int nrows = min(cnt[cnt_idx[j]], beam);
@@ -48,14 +48,16 @@ __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
             const int wi = wb + slot;
             const bool valid = wi < nw;
             const int w = valid ? wl[w0 + wi] : -1;
+            // wl_w (the *_perm entry points): the weight row is word wl_w[i]'s, the bias word wl[i]'s
+            const int ww = (valid && wl_w) ? wl_w[w0 + wi] : w;
             int K4 = 0, toff = 0;
             const f32x4 *brow = nullptr;
             if (valid) {
                 for (int si = 0; si < segs.n; ++si)
-                    if (w >= segs.s[si].v_start && w < segs.s[si].v_end) {
+                    if (ww >= segs.s[si].v_start && ww < segs.s[si].v_end) {
                         K4 = segs.s[si].k >> 2;
                         toff = segs.s[si].t_off;
-                        brow = reinterpret_cast<const f32x4 *>(segs.s[si].B + (size_t)(w - segs.s[si].v_start) * segs.s[si].ldb);
+                        brow = reinterpret_cast<const f32x4 *>(segs.s[si].B + (size_t)(ww - segs.s[si].v_start) * segs.s[si].ldb);
                     }
             }
             float acc[WL_ROWS];
@@ -175,6 +177,14 @@ extern "C" int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const f
                                const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
                                const int *wl_idx, int wl_base, const int *wl_out, float *edge, int beam, int n_groups,
                                void *stream) {
+    return jlm_edge_logits_perm(segs_host, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, nullptr, wl_off, wl_idx, wl_base, wl_out,
+                                edge, beam, n_groups, stream);
+}
+
+extern "C" int jlm_edge_logits_perm(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
+                                    const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_w,
+                                    const int *wl_off, const int *wl_idx, int wl_base, const int *wl_out, float *edge, int beam,
+                                    int n_groups, void *stream) {
     SegTable t;
     if (seg_table(segs_host, n_segs, t) || ldt % 4) return -1;
     if (n_groups <= 0) return 0;
@@ -188,7 +198,7 @@ extern "C" int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const f
         attr = lds;
     }
     hipLaunchKernelGGL(wordlist_kernel<0>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
-                       g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, wl_out, edge, nullptr, nullptr, nullptr, 0, beam);
+                       g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, wl_out, edge, nullptr, nullptr, nullptr, 0, beam);
     JLM_LAUNCH_CHECK();
     return 0;
 }
@@ -203,12 +213,20 @@ extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const 
                                 const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
                                 const int *wl_idx, int wl_base, float *run_max, double *run_sum, double *lse, int merge,
                                 int beam, int n_groups, void *stream) {
+    return jlm_wordlist_lse_perm(segs_host, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, nullptr, wl_off, wl_idx, wl_base, run_max,
+                                 run_sum, lse, merge, beam, n_groups, stream);
+}
+
+extern "C" int jlm_wordlist_lse_perm(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
+                                     const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_w,
+                                     const int *wl_off, const int *wl_idx, int wl_base, float *run_max, double *run_sum,
+                                     double *lse, int merge, int beam, int n_groups, void *stream) {
     SegTable t;
     if (seg_table(segs_host, n_segs, t) || ldt % 4) return -1;
     if (n_groups <= 0) return 0;
     static int use_mfma = -1;
     if (use_mfma < 0) { const char *e = getenv("JLM_WORDLIST_MFMA"); use_mfma = e ? atoi(e) : 1; }
-    if (use_mfma && n_segs == 1 && beam <= 32 && segs_host[0].k <= 256) {
+    if (!wl_w && use_mfma && n_segs == 1 && beam <= 32 && segs_host[0].k <= 256) {
         int r = jlm_wordlist_lse_mfma(segs_host, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum,
                                       lse, merge, beam, n_groups, stream);
         if (r != -2) return r;
@@ -223,7 +241,7 @@ extern "C" int jlm_wordlist_lse(const jlm_segment *segs_host, int n_segs, const 
         attr = lds;
     }
     hipLaunchKernelGGL(wordlist_kernel<1>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
-                       g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, nullptr, nullptr, run_max, run_sum, lse, merge, beam);
+                       g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, nullptr, nullptr, run_max, run_sum, lse, merge, beam);
     JLM_LAUNCH_CHECK();
     return 0;
 }

@@ -75,6 +75,8 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         return jlm_wordlist_lse(m->segs, m->n_segs, m->b2, p->T, m->ldt, g0, st.cnt, cidx, words, off, idx, base,
                                 p->run_max, p->run_sum, st.lse, merge, beam, n_groups, stream);
     };
+    // reference-compatibility mode of the incremental decoder on segmented models (jlm_decode_plan.di_wwords)
+    const bool perm = dynamic && p->di_wwords && p->sg_wword;
 
     for (int f = 0; f < F; ++f) {
         if (join) {
@@ -128,15 +130,19 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_HIP(hipStreamWaitEvent(side_s, fork, 0));
             est = side_stream;
         }
-        JLM_TRY(jlm_edge_logits(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell, p->sg_word,
-                                p->sg_off, p->sidx, cell, p->sg_node, p->edge, beam, B, est));
+        JLM_TRY(jlm_edge_logits_perm(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell, p->sg_word,
+                                     perm ? p->sg_wword : nullptr, p->sg_off, p->sidx, cell, p->sg_node, p->edge, beam, B, est));
         if (side_s) {
             JLM_HIP(g_events.get(&join));
             JLM_HIP(hipEventRecord(join, side_s));
         }
         JLM_TRY(stamp(f, 4));
         if (!m->self_norm) {
-            if (dynamic)
+            if (perm)
+                JLM_TRY(jlm_wordlist_lse_perm(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell,
+                                              p->di_words, p->di_wwords, p->di_off, p->di_idx, 2 * cell, p->run_max, p->run_sum,
+                                              st.lse, 0, beam, B, stream));
+            else if (dynamic)
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, p->di_idx, 2 * cell, 0, B, p->di_max));
             else if (select)
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, p->sidx, 0, 0, B, p->vs_max));

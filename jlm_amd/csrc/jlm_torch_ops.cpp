@@ -174,6 +174,9 @@ struct JlmPlan : torch::CustomClassHolder {
         p.vs_words = at_off("off_vs_words"); p.vs_off = at_off("off_vs_off");
         p.di_words = at_off("off_di_words"); p.di_off = at_off("off_di_off"); p.di_idx = at_off("off_sidx2");
         p.dd_words = at_off("off_dd_words"); p.dd_off = at_off("off_dd_off");
+        // reference-compatibility lists of the incremental decoder on segmented models: present only in such plans
+        p.di_wwords = i.find("off_di_wwords") != i.end() ? at_off("off_di_wwords") : nullptr;
+        p.sg_wword = i.find("off_sg_wword") != i.end() ? at_off("off_sg_wword") : nullptr;
         p.run_max = tptr<float>(tensors, "run_max"); p.run_sum = tptr<double>(tensors, "run_sum");
         p.part = tptr<float>(tensors, "part"); p.max_parts = (int)geti(i, "max_parts");
         p.out_nodes = tptr<int>(tensors, "out_nodes"); p.out_len = tptr<int>(tensors, "out_len");

@@ -68,6 +68,7 @@ class _Plan:
         torch, m, dev = eng.torch, eng.m, eng.device
         self.key, self.caps = key, dict(caps)
         kind, vmode, B, beam, F = key[:5]
+        perm = bool(key[6]) if len(key) > 6 else False       # reference-compatibility lists (dynamic x segmented, see submit)
         self.B, self.beam, self.F = B, beam, F
         rmax, ncell = B * beam, F * B
         G = F * rmax
@@ -76,11 +77,14 @@ class _Plan:
                      sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell, sidx2=ncell,
                      vs_words=caps["vs"], vs_off=B + 1, di_words=caps["di"], di_off=2 * ncell, dd_words=caps["dd"],
                      dd_off=ncell + 1)
+        names = self.INT_ARRAYS + (("di_wwords", "sg_wword") if perm else ())
+        if perm:
+            sizes.update(di_wwords=caps["di"], sg_wword=caps["nodes"])
         off, self.ioff = 0, {}
-        for n in self.INT_ARRAYS:
+        for n in names:
             self.ioff[n] = off
             off += _round_up(max(sizes[n], 1), 4)
-        self.isize = {n: sizes[n] for n in self.INT_ARRAYS}
+        self.isize = {n: sizes[n] for n in names}
         self.host_ints = torch.zeros(off + 4, dtype=torch.int32)
         if dev.type == "cuda":
             self.host_ints = self.host_ints.pin_memory()
@@ -178,12 +182,12 @@ class DecodeEngine:
         return self.m._ctx()
 
     # ------------------------------------------------------------------ plans
-    def _plan_for(self, kind, vmode, lat, need, size_class=()):
+    def _plan_for(self, kind, vmode, lat, need, size_class=(), perm=False):
         # Buffers are sized for the frame count rounded up to 8 so that ragged inputs (every chunk has its own longest
         # sentence) share plans instead of allocating ~1 GB of state rows and pinned staging per distinct length; the
         # frame loop runs lat.n_frames.
         fkey = _round_up(lat.n_frames, 8)
-        key = (kind, vmode, lat.n_sent, lat.beam, fkey, size_class)
+        key = (kind, vmode, lat.n_sent, lat.beam, fkey, size_class, bool(perm))
         for i, p in enumerate(self.plans):
             if p.key == key and p.fits(need) and not p.busy:
                 self.plans.append(self.plans.pop(i))
@@ -241,7 +245,10 @@ class DecodeEngine:
                          di=int((dyn_lists[1][1::2] - dyn_lists[1][0::2]).max()) if dynamic else 0,
                          dd=longest(dyn_lists[3]) if dynamic else 0)
         size_class = tuple((v < 128, v <= 128, v <= 4064) for v in (max_words["vs"], max_words["di"], max_words["dd"]))
-        p = self._plan_for(kind, vmode, lat, need, size_class)
+        # dyn_lists[4:6] (optional): the weight-row words of the reference-compatibility mode (DynamicDecoder.compat_quirks on
+        # D-softmax / D-softmax* models): per init-list position and per lattice edge (include/jlm_hip.h, jlm_decode_plan)
+        perm = dynamic and len(dyn_lists) >= 6 and dyn_lists[4] is not None
+        p = self._plan_for(kind, vmode, lat, need, size_class, perm)
         p.busy = True
         assert lat.n_frames <= p.F
         p._set("sent_len", lat.sent_len)
@@ -259,6 +266,9 @@ class DecodeEngine:
             p._set("di_off", dyn_lists[1])
             p._set("dd_words", dyn_lists[2])
             p._set("dd_off", dyn_lists[3])
+            if perm:
+                p._set("di_wwords", dyn_lists[4])
+                p._set("sg_wword", dyn_lists[5])
         p.dev_ints.copy_(p.host_ints, non_blocking=True)
         p.cnt.zero_()
         p.n_live.zero_()

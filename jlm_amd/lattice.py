@@ -331,6 +331,61 @@ class BatchLattice:
         dw, do = _csr(delta)
         return np.asarray(seq, dtype=np.int32), rng, dw, do, _LazyFinal(self, extra)
 
+    def dynamic_vocab_compat(self, seg_starts, samples=0, top_sampling=False, random_sampling=False, vocab_len=None):
+        """dynamic_vocab() for DynamicDecoder.compat_quirks on a SEGMENTED model (D-softmax / D-softmax*): the lists in
+        the reference's own order plus the words whose weight rows the reference actually reads.
+
+        The reference's ``project(state, vocab)`` returns the columns of a vocabulary subset segment by segment
+        (model.py:152-158,168-179) while ``DynamicDecoder`` indexes them -- and the model adds the bias -- in list order
+        (decoder_dynamic.py:76,130,172).  The list a frame's rows are first normalised over is
+        ``L = lattice_vocab[k] + sorted(new words of frame k+1)`` (decoder_dynamic.py:30-46,112-127): position j of it
+        gets the weight row of ``P[j]``, P = L stably partitioned by segment, and the bias of ``L[j]``.  Words appended
+        at later frames come from ``project(state, sorted(missing))`` -- sorted = segment-major: those are consistent.
+
+        -> (init_words, init_range, delta_words, delta_off, lv_final, init_weight_words, edge_weight_words): init list of
+        cell c = init_words[init_range[2c] : init_range[2c+1]] (bias / identity) beside init_weight_words (weight row);
+        edge_weight_words is parallel to ``sg_word``.  Host-side Python, sentence by sentence: a compatibility mode."""
+        import bisect
+        B, F = self.n_sent, self.n_frames
+        extra = None
+        if samples:
+            if random_sampling:
+                extra = [[int(x) for x in np.random.randint(vocab_len, size=samples)] for _ in range(B)]
+            elif top_sampling:
+                extra = [list(range(samples))] * B
+        starts = list(seg_starts)
+        seg_of = lambda w: bisect.bisect_right(starts, w) - 1
+        di, diw = [], []
+        rng = np.zeros(2 * F * B, dtype=np.int32)
+        delta = [[] for _ in range(F * B)]
+        sg_word, sg_off = np.asarray(self.sg_word), np.asarray(self.sg_off)
+        sgw = sg_word.astype(np.int32).copy()
+        for s in range(B):
+            lv, d = self._dyn_lists_python(s, extra[s] if extra else [])
+            L = int(self.sent_len[s])
+            for i in range(1, L + 1):
+                delta[i * B + s] = d[i]
+            for k in range(L):
+                Lk = [int(w) for w in lv[k]] + d[k + 1]
+                by_seg = [[] for _ in starts]
+                for w in Lk:
+                    by_seg[seg_of(w)].append(w)
+                Pk = [w for seg in by_seg for w in seg]
+                c = k * B + s
+                rng[2 * c] = len(di)
+                di += Lk
+                diw += Pk
+                rng[2 * c + 1] = len(di)
+                first = {}
+                for j, w in enumerate(Lk):
+                    first.setdefault(w, j)                    # list.index: the first occurrence
+                for e in range(int(sg_off[c]), int(sg_off[c + 1])):
+                    j = first.get(int(sg_word[e]))
+                    if j is not None:
+                        sgw[e] = Pk[j]
+        dw, do = _csr(delta)
+        return (np.asarray(di, dtype=np.int32), rng, dw, do, _LazyFinal(self, extra), np.asarray(diw, dtype=np.int32), sgw)
+
     def dynamic_init_list(self, dyn, k, s):
         """The init list of cell (k, s) out of dynamic_vocab()'s result (tests, debugging)."""
         c = k * self.n_sent + s

@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 4
+        return 5
 
     # ------------------------------------------------------- the frame loop (ABI 3)
     def jlm_decode_frames(self, m, p, lat, st, stream, side_stream, events=None):
@@ -110,12 +110,18 @@ class FakeLib:
                 if r:
                     return r
             cell = f * B
-            r = self.jlm_edge_logits(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
-                                     p.sg_word, p.sg_off, p.sidx, cell, p.sg_node, p.edge, beam, B, stream)
+            perm = dynamic and bool(p.di_wwords) and bool(p.sg_wword)
+            r = self.jlm_edge_logits_perm(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
+                                          p.sg_word, p.sg_wword if perm else None, p.sg_off, p.sidx, cell, p.sg_node, p.edge,
+                                          beam, B, stream)
             if r:
                 return r
             if not m.self_norm:
-                if dynamic:
+                if perm:
+                    r = self.jlm_wordlist_lse_perm(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
+                                                   p.di_words, p.di_wwords, p.di_off, p.di_idx, 2 * cell, p.run_max, p.run_sum,
+                                                   st.lse, 0, beam, B, stream)
+                elif dynamic:
                     r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.di_words, p.di_off, p.di_idx, 2 * cell, 0, B, p.di_max)
                 elif select:
                     r = wl_lse(off(p.g0, cell), off(p.cidx, cell), p.vs_words, p.vs_off, p.sidx, 0, 0, B, p.vs_max)
@@ -471,11 +477,12 @@ class FakeLib:
     def _segs(self, segs, n_segs):
         return [segs[i] for i in range(n_segs)]
 
-    def _word_logits(self, segs, b2, T, ldt, g0, nrows, words):
-        """[len(words), nrows] float32 logits of hypothesis rows g0.. for the words."""
+    def _word_logits(self, segs, b2, T, ldt, g0, nrows, words, wwords=None):
+        """[len(words), nrows] float32 logits of hypothesis rows g0.. for the words (wwords: the words whose weight rows are
+        used, the bias stays the list word's -- the *_perm entry points)."""
         out = np.zeros((len(words), nrows), dtype=np.float32)
-        for i, w in enumerate(words):
-            w = int(w)
+        for i, w0 in enumerate(words):
+            w = int(wwords[i]) if wwords is not None else int(w0)
             for sg in segs:
                 if sg.v_start <= w < sg.v_end:
                     brow = view(sg.B + 4 * (w - sg.v_start) * sg.ldb, sg.k, np.float32).astype(np.float64)
@@ -483,7 +490,7 @@ class FakeLib:
                         t = view(_p(T) + 4 * ((g0 + k) * ldt + sg.t_off), sg.k, np.float32).astype(np.float64)
                         out[i, k] = np.float32(np.dot(brow, t))
                     break
-            out[i] += view(_p(b2) + 4 * int(w), 1, np.float32)[0]
+            out[i] += view(_p(b2) + 4 * int(w0), 1, np.float32)[0]
         return out
 
     def _groups(self, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
@@ -499,11 +506,17 @@ class FakeLib:
 
     def jlm_edge_logits(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, wl_out, edge,
                         beam, n_groups, stream):
+        return self.jlm_edge_logits_perm(segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, None, wl_off, wl_idx, wl_base, wl_out,
+                                         edge, beam, n_groups, stream)
+
+    def jlm_edge_logits_perm(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, wl_out, edge,
+                             beam, n_groups, stream):
         sg = self._segs(segs, n_segs)
         for gb, nrows, a, words in self._groups(g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
             if nrows <= 0 or len(words) == 0:
                 continue
-            y = self._word_logits(sg, b2, T, ldt, gb, nrows, words)
+            ww = view(_p(wl_w) + 4 * a, len(words), np.int32) if wl_w else None
+            y = self._word_logits(sg, b2, T, ldt, gb, nrows, words, ww)
             outs = view(_p(wl_out) + 4 * a, len(words), np.int32)
             for i, n in enumerate(outs):
                 view(_p(edge) + 4 * int(n) * beam, nrows, np.float32)[:] = y[i]
@@ -511,6 +524,11 @@ class FakeLib:
 
     def jlm_wordlist_lse(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max,
                          run_sum, lse, merge, beam, n_groups, stream):
+        return self.jlm_wordlist_lse_perm(segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, None, wl_off, wl_idx, wl_base, run_max,
+                                          run_sum, lse, merge, beam, n_groups, stream)
+
+    def jlm_wordlist_lse_perm(self, segs, n_segs, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, run_max,
+                              run_sum, lse, merge, beam, n_groups, stream):
         sg = self._segs(segs, n_segs)
         for gb, nrows, a, words in self._groups(g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, n_groups, beam):
             if nrows <= 0:
@@ -519,7 +537,8 @@ class FakeLib:
             rs = view(_p(run_sum) + 8 * gb, nrows, np.float64)
             ls = view(_p(lse) + 8 * gb, nrows, np.float64)
             if len(words):
-                y = self._word_logits(sg, b2, T, ldt, gb, nrows, words).astype(np.float64)
+                ww = view(_p(wl_w) + 4 * a, len(words), np.int32) if wl_w else None
+                y = self._word_logits(sg, b2, T, ldt, gb, nrows, words, ww).astype(np.float64)
                 m = y.max(axis=0)
                 s = np.exp(y - m[None, :]).sum(axis=0)
             else:
@@ -780,6 +799,8 @@ class _FakePlan:
         d.vs_words, d.vs_off = at("vs_words"), at("vs_off")
         d.di_words, d.di_off, d.di_idx = at("di_words"), at("di_off"), at("sidx2")
         d.dd_words, d.dd_off = at("dd_words"), at("dd_off")
+        d.di_wwords = at("di_wwords") if "off_di_wwords" in i else None
+        d.sg_wword = at("sg_wword") if "off_sg_wword" in i else None
         d.run_max, d.run_sum, d.part, d.max_parts = ptr("run_max"), ptr("run_sum"), ptr("part"), i["max_parts"]
         d.out_nodes, d.out_len, d.out_score, d.stride = ptr("out_nodes"), ptr("out_len"), ptr("out_score"), i["stride"]
         self.timed_frames = 0

@@ -47,15 +47,27 @@ DECODE_CASES = [
     ("small-tied/dynamic-top", "small-tied", "dynamic",
      dict(beam_width=10, vocab_select=True, samples=20, top_sampling=True), ("ragged", 6, 2, 14, 5)),
     ("small-tied-sn/dynamic", "small-tied-sn", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 7)),
+    # the incremental decoder on SEGMENTED models: the reference pairs weight rows and biases of different words there
+    # (SURVEY 8 a16); jlm_amd reproduces it with DynamicDecoder.compat_quirks = True (the "-quirk" cases set it)
+    ("small-vtable/dynamic-quirk", "small-vtable", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 10)),
+    ("small-dsoftmax/dynamic-quirk", "small-dsoftmax", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 9)),
+    ("small-vtable/dynamic-quirk-top", "small-vtable", "dynamic",
+     dict(beam_width=5, vocab_select=True, samples=20, top_sampling=True), ("ragged", 6, 2, 14, 5)),
     # BASELINE.json configs[0]: 100 sentences, beam 10, V=50k, tied softmax
     ("mid-tied/static", "mid-tied", "static", dict(beam_width=10), ("fixed", 100, 20, 99)),
     ("mid-tied/static-vs", "mid-tied", "static", dict(beam_width=10, vocab_select=True), ("fixed", 24, 20, 98)),
     ("mid-tied/dynamic", "mid-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 24, 20, 98)),
     ("mid-vtable/static", "mid-vtable", "static", dict(beam_width=10), ("fixed", 24, 20, 97)),
+    ("mid-vtable/dynamic-quirk", "mid-vtable", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 8, 20, 94)),
     ("big-tied/static-b20", "big-tied", "static", dict(beam_width=20), ("fixed", 4, 20, 96)),
     # untied projection (model.py:189-191) at BASELINE size: V=50k, k = H = 512 (the tile-form normaliser inside the frame loop)
     ("mid-untied/static", "mid-untied", "static", dict(beam_width=10), ("fixed", 8, 20, 95)),
 ]
+
+def is_quirk_case(name):
+    """cases that need ``compat_quirks = True`` on the jlm_amd decoder"""
+    return name.split("/")[1].startswith("dynamic-quirk")
+
 
 RANDOM_SAMPLING_SEED = 123
 TRACE_SENTENCES = 4          # per case: frame-by-frame beams kept for the first few sentences

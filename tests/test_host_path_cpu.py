@@ -60,6 +60,7 @@ def test_decoders_match_reference_golden(case, fx, fake, golden_decode):
     name, fixture, kind, kwargs, spec = case
     f = fx(fixture)
     dec = _decoder(f, kind)
+    dec.compat_quirks = gc.is_quirk_case(name)
     sents = gc.case_sentences(spec, f["alphabet"])
     gold = golden_decode[name]
     if kwargs.get("random_sampling"):
@@ -70,7 +71,7 @@ def test_decoders_match_reference_golden(case, fx, fake, golden_decode):
     else:
         outs = dec.decode_batch(sents, **kwargs)          # ragged batch in one go
     dyn_seg = kind == "dynamic" and fixture.split("-")[1] in ("dsoftmax", "vtable")
-    assert not dyn_seg
+    assert dyn_seg == gc.is_quirk_case(name)          # the reference's result on segmented models needs the quirk mode
     for si, out in enumerate(outs):
         g = gold[si]["nbest"]
         assert len(out) == len(g), (name, si)

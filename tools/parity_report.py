@@ -43,6 +43,7 @@ def main():
         jconfig.set_root(f["root"])
         dec = (DynamicDecoder if kind == "dynamic" else Decoder)(1)
         dec.perf_timing = False
+        dec.compat_quirks = gc.is_quirk_case(name)
         sents = gc.case_sentences(spec, f["alphabet"])
         if kwargs.get("random_sampling"):
             outs = []
