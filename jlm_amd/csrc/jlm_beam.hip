@@ -226,7 +226,7 @@ extern "C" int jlm_wordlist_lse_perm(const jlm_segment *segs_host, int n_segs, c
     if (n_groups <= 0) return 0;
     static int use_mfma = -1;
     if (use_mfma < 0) { const char *e = getenv("JLM_WORDLIST_MFMA"); use_mfma = e ? atoi(e) : 1; }
-    if (!wl_w && use_mfma && n_segs == 1 && beam <= 32 && segs_host[0].k <= 256) {
+    if (!wl_w && use_mfma && n_segs == 1 && beam <= 64 && segs_host[0].k <= 256) {
         int r = jlm_wordlist_lse_mfma(segs_host, b2, T, ldt, g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum,
                                       lse, merge, beam, n_groups, stream);
         if (r != -2) return r;

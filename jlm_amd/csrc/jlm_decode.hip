@@ -45,7 +45,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
     const int rmax = B * beam;
     const bool dynamic = p->kind == 2, select = p->kind == 1, full = p->kind == 0;
     const int mode = m->self_norm ? 1 : (dynamic ? 2 : 0);
-    const bool wl_split = m->split_segs != nullptr && m->n_segs == 1 && beam <= 32;
+    const bool wl_split = m->split_segs != nullptr && m->n_segs == 1 && beam <= 64;
     // a segment with k > 256 (untied models: k = H) is outside the rows-stationary normalisers: one tile GEMM per segment
     // with a per-tile log-sum-exp epilogue (jlm_vocab_lse_partials), its slices folded by the next frame's beam step
     bool tile_form = false;

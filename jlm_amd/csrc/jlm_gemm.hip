@@ -1155,9 +1155,10 @@ __global__ __launch_bounds__(256) void wordlist_lse_mfma_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     const int j = blockIdx.x;
-    const int nrows = min(cnt[cnt_idx[j]], min(beam, 32));
+    // beams above 32: a group's rows are taken by ceil(beam / 32) workgroups (blockIdx.y), 32 rows each
+    const int nrows = min(min(cnt[cnt_idx[j]], beam) - 32 * (int)blockIdx.y, 32);
     if (nrows <= 0) return;
-    const int gbase = g0v[j];
+    const int gbase = g0v[j] + 32 * (int)blockIdx.y;
     const int lid = wl_base + wl_idx[j];
     const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1305,12 +1306,12 @@ extern "C" int jlm_wordlist_lse_mfma(const jlm_segment *seg_host, const float *b
                                      int merge, int beam, int n_groups, void *stream) {
     const jlm_segment sg = *seg_host;
     const int nk = (sg.k + BK - 1) / BK;
-    if (nk < 1 || nk > 8 || sg.k % 4 || sg.ldb % 4 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (nk < 1 || nk > 8 || sg.k % 4 || sg.ldb % 4 || sg.t_off % 4 || ldt % 4 || beam > 64) return -2;
     if (n_groups <= 0) return 0;
     const int lds = 4 * (2 * 32 * 32 + 2 * 32) * 4;
     hipStream_t st = (hipStream_t)stream;
 #define JLM_WL_LAUNCH(N)                                                                                              \
-    hipLaunchKernelGGL(wordlist_lse_mfma_kernel<N>, dim3(n_groups), dim3(256), lds, st, sg, b2, T, ldt, g0, cnt, cnt_idx, \
+    hipLaunchKernelGGL(wordlist_lse_mfma_kernel<N>, dim3(n_groups, (beam + 31) / 32), dim3(256), lds, st, sg, b2, T, ldt, g0, cnt, cnt_idx, \
                        wl, wl_off, wl_idx, wl_base, run_max, run_sum, lse, merge, beam)
     switch (nk) {
         case 1: JLM_WL_LAUNCH(1); break;

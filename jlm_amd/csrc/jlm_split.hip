@@ -918,7 +918,7 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
 // ---------------------------------------------------------------------------------------------
 // Word-list log-sum-exp on split rows (selected / incremental vocabulary, single-segment models):
 // the split-f16 form of wordlist_lse_mfma_kernel (jlm_gemm.hip).  One workgroup per (sentence, frame)
-// group, its <= 32 hypothesis rows stationary in registers; the group's word list is walked in
+// group (beams above 32: one per 32 of its rows), its <= 32 hypothesis rows stationary in registers; the word list is walked in
 // 32-word tiles, wave w taking tiles w, w+4, ...; a tile's split rows are GATHERED row by row into
 // the wave's private LDS ring by the DMA (per-lane source = the word's row).  Per group that is
 // ~600 words x 1 KB = 0.6 MB of scattered rows -- the kernel is bound by how many of those requests
@@ -940,9 +940,10 @@ __global__ __launch_bounds__(256) void wordlist_lse_split_kernel(
     constexpr int NC = CH::NC;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     const int j = blockIdx.x;
-    const int nrows = min(cnt[cnt_idx[j]], min(beam, 32));
+    // beams above 32: a group's rows are taken by ceil(beam / 32) workgroups (blockIdx.y), 32 rows each
+    const int nrows = min(min(cnt[cnt_idx[j]], beam) - 32 * (int)blockIdx.y, 32);
     if (nrows <= 0) return;
-    const int gbase = g0v[j];
+    const int gbase = g0v[j] + 32 * (int)blockIdx.y;
     const int lid = wl_base + wl_idx[j];
     const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1090,7 +1091,7 @@ extern "C" int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale
                                       double *run_sum, double *lse, int merge, int beam, int n_groups, void *stream) {
     const jlm_segment sg = *seg_host;
     const int ns = (sg.k + 15) / 16;
-    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 64) return -2;
     if (max_words > WLS_MAX_WORDS - 32) return -2;
     if (n_groups <= 0) return 0;
     const int lds = (4 * WLS_RING * 32 * 64 + 2 * WLS_MAX_WORDS) * 4;
@@ -1104,7 +1105,7 @@ extern "C" int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale
                 return -3;                                                                                                 \
             attr = true;                                                                                                   \
         }                                                                                                                  \
-        hipLaunchKernelGGL(wordlist_lse_split_kernel<N>, dim3(n_groups), dim3(256), lds, st, sg, t_scale, descale, b2, T, ldt, \
+        hipLaunchKernelGGL(wordlist_lse_split_kernel<N>, dim3(n_groups, (beam + 31) / 32), dim3(256), lds, st, sg, t_scale, descale, b2, T, ldt, \
                            g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum, lse, merge, beam);             \
     } while (0)
     if (ns <= 2) JLM_WLS_LAUNCH(2);
@@ -1250,7 +1251,7 @@ extern "C" int jlm_wordlist_merge_split(const jlm_segment *seg_host, float t_sca
                                         double *run_sum, double *lse, void *stream) {
     const jlm_segment sg = *seg_host;
     const int ns = (sg.k + 15) / 16;
-    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 32) return -2;
+    if (ns < 1 || ns > 16 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4 || ldt % 4 || beam > 64) return -2;
     if (max_words > WLM_MAX_WORDS) return -2;
     if (n_sent <= 0 || n_old_frames <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;

@@ -54,7 +54,7 @@ class FakeLib:
         dynamic, select, full = p.kind == 2, p.kind == 1, p.kind == 0
         mode = 1 if m.self_norm else (2 if dynamic else 0)
         split = bool(m.split_segs)
-        wl_split = split and m.n_segs == 1 and beam <= 32
+        wl_split = split and m.n_segs == 1 and beam <= 64
         tile_form = full and not m.self_norm and any(m.segs[i].k > 256 for i in range(m.n_segs))
         off = lambda base, n: (base or 0) + 4 * n
 
@@ -558,7 +558,7 @@ class FakeLib:
                                max_words, run_max, run_sum, lse, merge, beam, n_groups, stream):
         """jlm_wordlist_lse for one segment whose matrix is given as split rows"""
         sg = seg._obj if hasattr(seg, "_obj") else (seg[0] if not hasattr(seg, "k") else seg)
-        if sg.k > 256 or sg.ldb % 16 or beam > 32 or max_words > 4096 - 32:
+        if sg.k > 256 or sg.ldb % 16 or beam > 64 or max_words > 4096 - 32:
             return -2
         nv = sg.v_end - sg.v_start
         Bfull = self._split_read(sg.B, nv, sg.ldb)[:, :sg.k]
@@ -592,7 +592,7 @@ class FakeLib:
                                  wl_base, max_words, run_max, run_sum, lse, stream):
         """every older row of every sentence merges the sentence's new words (jlm_wordlist_lse merge=1 per cell)"""
         sg = seg._obj if hasattr(seg, "_obj") else (seg[0] if not hasattr(seg, "k") else seg)
-        if sg.k > 256 or sg.ldb % 16 or beam > 32 or max_words > 128:
+        if sg.k > 256 or sg.ldb % 16 or beam > 64 or max_words > 128:
             return -2
         nv = sg.v_end - sg.v_start
         Bfull = self._split_read(sg.B, nv, sg.ldb)[:, :sg.k]

@@ -28,12 +28,13 @@ def _same(got, want, tag):
     np.testing.assert_allclose([s for s, _ in got], [s for s, _ in want], rtol=1e-5, atol=1e-3, err_msg=str(tag))
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic"])
+@pytest.mark.parametrize("kind", ["static", "static-vs", "dynamic"])
 @pytest.mark.parametrize("beam,topN", [(1, 10), (2, 1), (64, 10), (33, 40)])
 def test_beam_extremes(kind, beam, topN, fx):
+    """(beams above 32 take two row blocks per group in the word-list kernels: static-vs and dynamic)"""
     f = fx("small-tied")
-    d, o = _pair(f, kind)
-    kw = dict(vocab_select=True) if kind == "dynamic" else {}
+    d, o = _pair(f, "dynamic" if kind == "dynamic" else "static")
+    kw = dict(vocab_select=True) if kind != "static" else {}
     sents = synth.make_ragged_sentences(7, 1, 14, seed=beam + 3, alphabet=f["alphabet"])
     got = d.decode_batch(sents, beam_width=beam, topN=topN, **kw)
     for s, g in zip(sents, got):

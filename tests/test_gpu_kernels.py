@@ -546,7 +546,7 @@ def test_edge_logits(L, widths, beam, ng, mw):
 
 @pytest.mark.parametrize("widths,beam,ng,mw,merge", [([32], 10, 20, 40, 0), ([200, 100, 50], 10, 64, 90, 1),
                                                      ([256], 20, 9, 700, 0), ([256], 20, 9, 700, 1),
-                                                     ([32, 16, 8], 3, 30, 5, 1)])
+                                                     ([32, 16, 8], 3, 30, 5, 1), ([256], 48, 7, 300, 1), ([128], 64, 5, 200, 0)])
 def test_wordlist_lse(L, widths, beam, ng, mw, merge):
     rng = np.random.default_rng(sum(widths) + beam + ng + merge)
     P = _wordlist_problem(rng, 3000, widths, beam, ng, mw, dup=True)
@@ -573,7 +573,8 @@ def test_wordlist_lse(L, widths, beam, ng, mw, merge):
 
 
 @pytest.mark.parametrize("width,beam,ng,mw,merge", [(32, 10, 20, 40, 0), (256, 20, 9, 700, 0), (256, 20, 9, 700, 1),
-                                                    (100, 10, 64, 300, 1), (200, 32, 5, 2500, 0), (48, 1, 7, 33, 0)])
+                                                    (100, 10, 64, 300, 1), (200, 32, 5, 2500, 0), (48, 1, 7, 33, 0),
+                                                    (256, 48, 6, 400, 1), (100, 64, 4, 300, 0), (64, 33, 9, 150, 1)])
 def test_wordlist_lse_split(L, width, beam, ng, mw, merge):
     """split-f16 word-list LSE (deep gather ring) against the f64 restatement on the original f32 operands"""
     rng = np.random.default_rng(width + beam + ng + merge)
@@ -601,7 +602,8 @@ def test_wordlist_lse_split(L, width, beam, ng, mw, merge):
     np.testing.assert_allclose(lg[fin], lc[fin], rtol=1e-6, atol=3e-5)
 
 
-@pytest.mark.parametrize("width,beam,B,nf,mw", [(256, 10, 7, 6, 40), (100, 20, 3, 19, 128), (32, 3, 20, 2, 5), (200, 10, 64, 12, 70)])
+@pytest.mark.parametrize("width,beam,B,nf,mw", [(256, 10, 7, 6, 40), (100, 20, 3, 19, 128), (32, 3, 20, 2, 5), (200, 10, 64, 12, 70),
+                                                (256, 48, 5, 4, 60), (100, 64, 3, 5, 100)])
 def test_wordlist_merge_split(L, width, beam, B, nf, mw):
     """per-sentence merge of a frame's new words into all older rows against its numpy restatement"""
     rng = np.random.default_rng(width + beam + B + nf)
