@@ -154,6 +154,7 @@ class _Plan:
 
 
 class DecodeEngine:
+    _stream_pool = {}              # device index -> launch streams shared by all engines of the process
     MAX_PLANS = 4                  # plans kept regardless of their size (two or three are in flight at a time)
     MAX_PLANS_SMALL = 48           # ... and as many more as fit PLAN_BYTES of device memory
     PLAN_BYTES = 4 << 30
@@ -219,8 +220,14 @@ class DecodeEngine:
         with self._ctx():
             if self.device.type != "cuda" or self.n_streams < 2 or timing:
                 return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
-            if not self._streams:
-                self._streams = [torch.cuda.Stream(self.device) for _ in range(self.n_streams)]
+            if len(self._streams) != self.n_streams:
+                # the launch streams are shared by every engine on the device: each also gets a side stream inside the op, and
+                # streams beyond the GPU's hardware queues (GPU_MAX_HW_QUEUES, jlm_amd/__init__.py) serialise one another --
+                # a second Decoder in the process (bench.py's configs[4] leg) must not double them
+                pool = DecodeEngine._stream_pool.setdefault(self.device.index or 0, [])
+                while len(pool) < self.n_streams:
+                    pool.append(torch.cuda.Stream(self.device))
+                self._streams = pool[:self.n_streams]
             strm = self._streams[self._rr]
             self._rr = (self._rr + 1) % self.n_streams
             cur = torch.cuda.current_stream(self.device)
