@@ -89,7 +89,10 @@ class Decoder():
         self.last_lattice = None
         self._pool = None                # worker threads that build the lattices of upcoming chunks
         from . import usable_cpus
-        self.prefetch_workers = max(1, min(3, usable_cpus() // 4))    # each build uses up to 4 threads itself
+        # lattice builds running ahead of the GPU: two keep it fed even when each build is single-threaded (tools/probes/
+        # e2e_threads.py: 2 workers x 1 thread = 3 x 4 = 2.8-3.0 ms per step, 1 worker x 1..4 threads 3.4-3.9), three when the
+        # process has CPUs to spare
+        self.prefetch_workers = 3 if usable_cpus() >= 12 else 2
         self._pool1 = None
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20

@@ -85,7 +85,9 @@ class LatticeBuilder:
         self._native = None
         self._native_lock = threading.Lock()          # decode_batch's prefetch threads all ask for the trie on first use
         from . import usable_cpus
-        self.n_threads = min(4, usable_cpus())     # per build; decode_batch runs several builds side by side
+        # threads per build (decode_batch runs several builds side by side): one when the process has few CPUs (one rank of
+        # eight on a 16-CPU quota), up to four otherwise
+        self.n_threads = 1 if usable_cpus() < 8 else min(4, usable_cpus() // 4)
         self.use_native = os.environ.get("JLM_NATIVE_LATTICE", "1") != "0"
 
     def native(self):

@@ -11,7 +11,7 @@ sents = synth.make_sentences(256, 20, seed=4242, alphabet=al)
 dec.decode_batch(sents * 6, beam_width=10)
 N = 40
 res = {}
-variants = [(3, 4), (3, 2), (3, 1), (2, 2), (2, 4), (4, 1)]
+variants = [tuple(int(v) for v in x.split(",")) for x in sys.argv[1:]] or [(3, 4), (3, 2), (3, 1), (2, 2), (2, 4), (4, 1)]
 for rnd in range(4):
     for (w, nt) in variants:
         dec.prefetch_workers = w; dec._pool = None; dec._pool1 = None
