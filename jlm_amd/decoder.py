@@ -87,6 +87,7 @@ class Decoder():
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.plan_budget_bytes = 6 << 30  # state rows of one batch (frames x sentences x beam x (2 H + ldt) x 4 B): see _chunks
         self.last_lattice = None
+        self.collector_thread = os.environ.get("JLM_COLLECTOR", "0") == "1"      # _run_pipeline: finish chunks on their own thread
         self._pool = None                # worker threads that build the lattices of upcoming chunks
         from . import usable_cpus
         # lattice builds running ahead of the GPU: two keep it fed even when each build is single-threaded (tools/probes/
@@ -155,28 +156,91 @@ class Decoder():
             words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
             return idx, lat, (words, off), lists
 
-        out, inflight = [None] * len(inputs), deque()
+        out = [None] * len(inputs)
 
-        def finish(item):
-            idx, ticket = item
+        def finish(idx, ticket):
             for j, r in zip(idx, self._engine.collect(ticket)):
                 out[j] = r
             self._log_perf()
 
-        workers = 1 if (samples and random_sampling) else self.prefetch_workers
-        for idx, lat, vocab, lists in self._prefetched(prepare, chunks, workers):
+        def submit(item):
+            idx, lat, vocab, lists = item
             self.last_lattice = lat
             if vocab_select and (len(inputs) - 1) in idx:
                 self.lattice_vocab = lists[idx.index(len(inputs) - 1)]      # the reference leaves the LAST sentence's list behind
-            inflight.append((idx, self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)))
-            # two chunks stay in flight (the engine alternates streams); the strings of chunk i-2 are
-            # built while the GPU decodes chunks i-1 and i
-            if len(inflight) > self.pipeline_depth:
-                finish(inflight.popleft())
-        while inflight:
-            finish(inflight.popleft())
+            return idx, self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
+
+        workers = 1 if (samples and random_sampling) else self.prefetch_workers
+        self._run_pipeline(self._prefetched(prepare, chunks, workers), len(chunks), submit, finish)
         self.perf_sen += len(inputs)
         return out
+
+    def _run_pipeline(self, prepared, n_chunks, submit, finish):
+        """The device pipeline of decode_batch: ``submit`` every prepared chunk (enqueue upload + frame loop + read-back: no
+        waiting), ``finish`` them in order (wait for the batch, build its n-best lists).  ``pipeline_depth`` + 1 chunks are in
+        flight at most (the engine alternates streams; a chunk owns its plan's buffers until finished).
+
+        ``collector_thread`` (JLM_COLLECTOR=1, off by default): the finishing runs on its own thread -- the submitting thread
+        spends most of a chunk inside the frame-loop op and the finishing thread inside the event wait, both without the GIL.
+        It takes the calling thread from 92-97 % to 47 % busy (tools/probes/host_threads_cpu.py) but the decode is GPU bound
+        once the collector pause below is in: 2.87 vs 2.80 ms per chunk (tools/probes/e2e_collector.py) -- kept for hosts
+        slower than the ones measured."""
+        # The n-best lists are ~8 k acyclic containers per 256-sentence chunk: left on, the cyclic collector runs a dozen
+        # young collections per chunk and, as the result list grows, full collections over everything decoded so far (4.0 vs
+        # 2.9 ms per chunk at 200 vs 40 chunks per call).  Nothing allocated in here can form a cycle: collection is paused.
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._run_pipeline_nogc(prepared, n_chunks, submit, finish)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish):
+        if n_chunks <= 2 or not self.collector_thread:
+            inflight = deque()
+            for item in prepared:
+                inflight.append(submit(item))
+                if len(inflight) > self.pipeline_depth:
+                    finish(*inflight.popleft())
+            while inflight:
+                finish(*inflight.popleft())
+            return
+        import queue
+        import threading
+        q, slots, failed = queue.Queue(), threading.Semaphore(self.pipeline_depth + 1), []
+
+        def collector():
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                try:
+                    if not failed:
+                        finish(*item)
+                except BaseException as e:          # re-raised on the calling thread; keep draining so it never blocks
+                    failed.append(e)
+                finally:
+                    slots.release()
+
+        th = threading.Thread(target=collector, name="jlm-collect", daemon=True)
+        th.start()
+        try:
+            for item in prepared:
+                slots.acquire()
+                if failed:
+                    slots.release()
+                    break
+                try:
+                    q.put(submit(item))
+                except BaseException:
+                    slots.release()
+                    raise
+        finally:
+            q.put(None)
+            th.join()
+        if failed:
+            raise failed[0]
 
     def _chunks(self, inputs, beam_width, reorder=True):
         """Index lists of the device batches of one decode_batch call.  A batch's frame loop and buffers run to its LONGEST
