@@ -139,6 +139,7 @@ def main():
         sents5 = synth.make_sentences(CONFIG5_SENTENCES, args.length, seed=5555, alphabet=alphabet5)   # the same set on every rank
         dec5.max_batch = 1024
         idx, _res = shard.decode_sharded(dec5, sents5, rank, world, beam_width=args.beam)             # untimed pass (plans, streams)
+        del _res
         barrier()
         t0 = time.perf_counter()
         for _ in range(passes):
@@ -288,6 +289,7 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
+        del out        # ~300 k list objects: kept alive they make every later full garbage collection (the loops below) slower
         total_chars_per_step = sum_over_ranks(float(chars_per_step))
         value = total_chars_per_step * args.steps / dt
         steps_ms = dt / args.steps * 1e3
