@@ -90,8 +90,8 @@ class Decoder():
         self.collector_thread = os.environ.get("JLM_COLLECTOR", "0") == "1"      # _run_pipeline: finish chunks on their own thread
         self._pool = None                # worker threads that build the lattices of upcoming chunks
         from . import usable_cpus
-        # lattice builds running ahead of the GPU: two keep it fed even when each build is single-threaded (tools/probes/
-        # e2e_threads.py: 2 workers x 1 thread = 3 x 4 = 2.8-3.0 ms per step, 1 worker x 1..4 threads 3.4-3.9), three when the
+        # lattice builds (single-threaded, 1.4 ms per 256-sentence chunk) running ahead of the GPU: two workers keep it fed
+        # (tools/probes/e2e_threads.py: 2 workers x 1 thread = 3 x 4 = 2.8-3.0 ms per step, 1 worker 3.4-3.9), three when the
         # process has CPUs to spare
         self.prefetch_workers = 3 if usable_cpus() >= 12 else 2
         self._pool1 = None
@@ -137,7 +137,7 @@ class Decoder():
             # decoder.py:176: `if self.lattice_vocab:` is still true after an earlier vocab_select call, so the full-vocabulary
             # call indexes the OLD list: ValueError for a word outside it, else the old list is what the rows are normalised over
             return [self._decode_stale_vocab(x, topN, beam_width) for x in inputs]
-        if any(len(x) == 0 for x in inputs):
+        if not all(inputs):        # (an empty string / list is falsy)
             # the reference's loop over an empty input leaves the <eos> path alone: [(0.0, [])] (decoder.py:220-241)
             keep = [i for i, x in enumerate(inputs) if len(x)]
             sub = self.decode_batch([inputs[i] for i in keep], topN, beam_width, vocab_select, samples, top_sampling,
@@ -249,20 +249,30 @@ class Decoder():
         ranks -- and a batch closes at ``max_batch`` sentences or when its state rows would exceed ``plan_budget_bytes``: one
         200-kana input costs its own small batch, not 12 GB for the 1 023 short sentences that happened to follow it.
         reorder=False keeps the caller's order (random_sampling draws from the global RNG sentence by sentence)."""
+        import numpy as np
         n = len(inputs)
-        order = list(range(n))
-        if reorder and n > self.max_batch:
-            order.sort(key=lambda i: -len(inputs[i]))
         m = self.model.dev
         row_bytes = (2 * m.H + (m.ldt if (m.mode != "untied" or m.split_lstm) else 0)) * 4 + 64
+        fits = lambda longest: max(1, min(self.max_batch, self.plan_budget_bytes // (((longest + 1 + 7) // 8 * 8) * beam_width * row_bytes)))
+        lens = np.fromiter(map(len, inputs), dtype=np.int64, count=n)
+        if reorder and n > self.max_batch:
+            # longest first: a chunk's frame count is its FIRST sentence's, so its size is one division -- no per-sentence
+            # Python work (a 10 240-sentence call spent 9 ms here, before the first launch, as a loop)
+            order = np.argsort(-lens, kind="stable")
+            chunks, i = [], 0
+            while i < n:
+                k = fits(int(lens[order[i]]))
+                chunks.append(order[i:i + k].tolist())
+                i += k
+            return chunks
         chunks, cur, longest = [], [], 0
-        for i in order:
-            frames = (max(longest, len(inputs[i])) + 1 + 7) // 8 * 8
-            if cur and (len(cur) >= self.max_batch or frames * (len(cur) + 1) * beam_width * row_bytes > self.plan_budget_bytes):
+        for i in range(n):
+            li = int(lens[i])
+            if cur and len(cur) >= fits(max(longest, li)):
                 chunks.append(cur)
                 cur, longest = [], 0
             cur.append(i)
-            longest = max(longest, len(inputs[i]))
+            longest = max(longest, li)
         if cur:
             chunks.append(cur)
         return chunks

@@ -84,10 +84,10 @@ class LatticeBuilder:
                     self.max_len = len(reading)
         self._native = None
         self._native_lock = threading.Lock()          # decode_batch's prefetch threads all ask for the trie on first use
-        from . import usable_cpus
-        # threads per build (decode_batch runs several builds side by side): one when the process has few CPUs (one rank of
-        # eight on a 16-CPU quota), up to four otherwise
-        self.n_threads = 1 if usable_cpus() < 8 else min(4, usable_cpus() // 4)
+        # threads per build: ONE.  A 256 x 20-kana batch is 1.44 ms single-threaded on the GPU box and 1.8-2.4 ms with 2-16
+        # threads (tools/probes/lattice_build_time.py: the walk over a batch is shorter than spawning and joining the threads);
+        # decode_batch runs several builds side by side instead.  JLM_LATTICE_THREADS overrides.
+        self.n_threads = max(1, int(os.environ.get("JLM_LATTICE_THREADS", "1")))
         self.use_native = os.environ.get("JLM_NATIVE_LATTICE", "1") != "0"
 
     def native(self):
