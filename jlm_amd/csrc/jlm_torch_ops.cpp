@@ -22,7 +22,9 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <array>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -143,6 +145,9 @@ struct JlmPlan : torch::CustomClassHolder {
     jlm_decode_plan p{};
     int frames_cap = 0;
     std::vector<hipEvent_t> events;         // JLM_EVENTS_PER_FRAME per frame, created on first timed decode
+    // JLM_GRAPH=1: the launch sequence of a decode shape, captured on its second use and replayed (decode_frames)
+    std::map<std::array<long, 8>, hipGraphExec_t> graphs;
+    std::set<std::array<long, 8>> seen;
     int timed_frames = 0;                   // frames of the last timed decode (0: the last decode was not timed)
     int device = -1;
 
@@ -187,6 +192,7 @@ struct JlmPlan : torch::CustomClassHolder {
     }
     ~JlmPlan() override {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
     }
 };
 
@@ -220,6 +226,40 @@ int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intr
         }
         ev = reinterpret_cast<void *const *>(pl.events.data());
         pl.timed_frames = (int)n_frames;
+    }
+    // JLM_GRAPH=1: the ~130 launches and events of a batch cost the calling thread ~0.75 ms; a decode shape (frames, list
+    // maxima, CU share, side stream, launch stream) seen for the second time on this plan is captured into a hipGraph and
+    // replayed from then on -- every pointer in it belongs to the plan or the model, nothing in the sequence depends on host
+    // data of the batch.  The first use runs eagerly (one-time kernel attributes, shape checks).
+    // Measured (ROCm 7.2, MI355X, tools/probes/host_threads_cpu.py): correct (the GPU decode suite passes with it) and SLOWER --
+    // 3.52-3.58 vs 2.58-2.71 ms per 256-sentence chunk, the calling thread 3.4 instead of 2.4 ms busy: hipGraphLaunch of this
+    // 130-node, two-branch graph costs more than the launches it replaces, and the two batches in flight no longer overlap.
+    // Left off.
+    static const bool use_graph = [] { const char *e = getenv("JLM_GRAPH"); return e && atoi(e) == 1; }();
+    if (use_graph && !timed) {
+        const std::array<long, 8> key = {(long)n_frames, (long)vs_max, (long)di_max, (long)dd_max, (long)lse_cu_share_pct,
+                                         (long)(side_s != nullptr), (long)(intptr_t)main.stream(), (long)(intptr_t)&model->m};
+        auto it = pl.graphs.find(key);
+        if (it == pl.graphs.end() && pl.seen.count(key)) {
+            hipGraph_t graph = nullptr;
+            jlm_check((int)hipStreamBeginCapture(main.stream(), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+            const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, nullptr);
+            const hipError_t e = hipStreamEndCapture(main.stream(), &graph);
+            if (rc == 0 && e == hipSuccess && graph) {
+                hipGraphExec_t exec = nullptr;
+                jlm_check((int)hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+                (void)hipGraphDestroy(graph);
+                it = pl.graphs.emplace(key, exec).first;
+            } else {
+                if (graph) (void)hipGraphDestroy(graph);
+                TORCH_CHECK(false, "jlm.decode_frames: graph capture failed (rc ", rc, ", ", hipGetErrorString(e), ")");
+            }
+        }
+        if (it != pl.graphs.end()) {
+            jlm_check((int)hipGraphLaunch(it->second, main.stream()), "hipGraphLaunch");
+            return 0;
+        }
+        pl.seen.insert(key);
     }
     const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, ev);
     if (rc == -2) return -2;
