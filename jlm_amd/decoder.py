@@ -60,8 +60,20 @@ class Node():
         return str((self.start_idx, self.word))
 
 
+class _CellTooLarge(Exception):
+    """raised by a chunk's preparation: these input indices have a lattice cell the device beam step cannot hold"""
+
+    def __init__(self, sentences):
+        Exception.__init__(self, sentences)
+        self.sentences = list(sentences)
+
+
 class Decoder():
     dynamic = False
+    # jlm_beam_step keeps the candidates of one (frame, sentence) cell -- nodes ending there x beam -- in one wave's LDS: 12 bytes
+    # each of 160 KB.  Sentences with a larger cell (hundreds of homophones at a wide beam) take the host-side search
+    # (_decode_unpruned with the beam) instead of failing the batch.
+    CAND_LIMIT = 13000
 
     def __init__(self, experiment_id=0, comp=0, device=None):
         self.config = _config.load_config_dict(experiment_id)
@@ -151,6 +163,7 @@ class Decoder():
         def prepare(idx):
             """host side of one chunk: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
             lat = BatchLattice(self._builder, [inputs[j] for j in idx], beam_width)
+            self._check_cells(lat, idx, beam_width)
             if not vocab_select:
                 return idx, lat, None, None
             words, off, lists = lat.static_vocab(samples, top_sampling, random_sampling, len(self.w2i))
@@ -171,9 +184,33 @@ class Decoder():
             return idx, self._engine.submit(lat, "static", vocab=vocab, topN=topN, timing=self.perf_timing)
 
         workers = 1 if (samples and random_sampling) else self.prefetch_workers
-        self._run_pipeline(self._prefetched(prepare, chunks, workers), len(chunks), submit, finish)
+        try:
+            self._run_pipeline(self._prefetched(prepare, chunks, workers), len(chunks), submit, finish)
+        except _CellTooLarge as e:
+            # the sentences named take the host-side beam search, everything else goes through the device again
+            heavy = set(e.sentences)
+            rest = [i for i in range(len(inputs)) if i not in heavy]
+            sub = self.decode_batch([inputs[i] for i in rest], topN, beam_width, vocab_select, samples, top_sampling,
+                                    random_sampling) if rest else []
+            out = [None] * len(inputs)
+            for i, r in zip(rest, sub):
+                out[i] = r
+            lv_last = self.lattice_vocab
+            for i in sorted(heavy):
+                out[i] = self._decode_unpruned(inputs[i], topN, vocab_select, samples, top_sampling, random_sampling,
+                                               beam_width=beam_width)
+            if (len(inputs) - 1) not in heavy:
+                self.lattice_vocab = lv_last      # (the reference leaves the LAST sentence's list behind)
+            return out
         self.perf_sen += len(inputs)
         return out
+
+    def _check_cells(self, lat, idx, beam_width):
+        if lat.max_cands <= self.CAND_LIMIT or lat.n_sent == 0:
+            return
+        import numpy as np
+        per_sentence = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0)
+        raise _CellTooLarge([idx[k] for k in range(lat.n_sent) if int(per_sentence[k]) * beam_width > self.CAND_LIMIT])
 
     def _run_pipeline(self, prepared, n_chunks, submit, finish):
         """The device pipeline of decode_batch: ``submit`` every prepared chunk (enqueue upload + frame loop + read-back: no
@@ -199,12 +236,20 @@ class Decoder():
     def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish):
         if n_chunks <= 2 or not self.collector_thread:
             inflight = deque()
-            for item in prepared:
-                inflight.append(submit(item))
-                if len(inflight) > self.pipeline_depth:
+            try:
+                for item in prepared:
+                    inflight.append(submit(item))
+                    if len(inflight) > self.pipeline_depth:
+                        finish(*inflight.popleft())
+                while inflight:
                     finish(*inflight.popleft())
-            while inflight:
-                finish(*inflight.popleft())
+            except BaseException:
+                while inflight:                      # chunks already on the device: wait for them, their plans are released
+                    try:
+                        self._engine.collect(inflight.popleft()[1])
+                    except Exception:
+                        pass
+                raise
             return
         import queue
         import threading

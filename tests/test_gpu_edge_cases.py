@@ -239,3 +239,21 @@ def test_kmeans_compressed_model_on_device(mode, tmp_path):
     sents = synth.make_ragged_sentences(10, 2, 14, seed=4, alphabet=10)
     for s, g in zip(sents, d.decode_batch(sents, beam_width=6)):
         _same(g, o.decode(s, beam_width=6), (mode, s))
+
+
+def test_oversized_lattice_cells_take_the_host_path(fx, monkeypatch):
+    """sentences with a (frame, sentence) cell above the device beam step's LDS capacity: host-side beam search over the GPU
+    predict kernels for those, the device frame loop for the rest -- both as the oracle"""
+    f = fx("small-vtable")
+    d, o = _pair(f, "static")
+    sents = synth.make_ragged_sentences(9, 2, 10, seed=21, alphabet=f["alphabet"])
+    from jlm_amd.decoder import Decoder
+    from jlm_amd.lattice import BatchLattice
+    lat = BatchLattice(d._builder, sents, 6)
+    per = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0) * 6
+    limit = int(np.sort(per)[len(per) // 2])
+    monkeypatch.setattr(Decoder, "CAND_LIMIT", limit)
+    assert 0 < int((per > limit).sum()) < len(sents)
+    got = d.decode_batch(sents, beam_width=6)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=6), ("oversized", s))

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from jlm_amd import config as jconfig
+from jlm_amd import config as jconfig, synth
 from oracle import jlm_oracle as orc
 from tests import fake_hip
 from tests import golden_cases as gc
@@ -228,3 +228,34 @@ def test_decode_batch_chunks_by_length_and_memory_budget(fx, fake):
     for a, b in zip(got, want):
         assert [w for _, w in a] == [w for _, w in b]
         np.testing.assert_allclose([x for x, _ in a], [x for x, _ in b], rtol=1e-9, atol=1e-6)
+
+
+def test_oversized_lattice_cells_take_the_host_path(fx, fake, monkeypatch):
+    """a cell with more candidates than the device beam step keeps in LDS: those sentences go through the host-side beam search
+    (Decoder._decode_unpruned with the beam), the rest of the batch through the device, results as the oracle's"""
+    f = fx("small-tied")
+    dec = _decoder(f, "static")
+    sents = synth.make_ragged_sentences(9, 2, 10, seed=21, alphabet=f["alphabet"])
+    want = dec.decode_batch(sents, beam_width=6)
+    from jlm_amd.decoder import Decoder
+    from jlm_amd.lattice import BatchLattice
+    import numpy as np
+    lat = BatchLattice(dec._builder, sents, 6)
+    per = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0) * 6
+    limit = int(np.sort(per)[len(per) // 2])          # about half of the sentences are "too large"
+    monkeypatch.setattr(Decoder, "CAND_LIMIT", limit)
+    assert 0 < int((per > limit).sum()) < len(sents)
+    got = dec.decode_batch(sents, beam_width=6)
+    for g, w in zip(got, want):
+        assert [x for _, x in g] == [x for _, x in w]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-5, atol=1e-4)
+    got_vs = dec.decode_batch(sents, beam_width=6, vocab_select=True)
+    monkeypatch.setattr(Decoder, "CAND_LIMIT", 13000)
+    want_vs = dec.decode_batch(sents, beam_width=6, vocab_select=True)
+    for g, w in zip(got_vs, want_vs):
+        assert [x for _, x in g] == [x for _, x in w]
+    from jlm_amd.decoder_dynamic import DynamicDecoder
+    dyn = _decoder(f, "dynamic")
+    monkeypatch.setattr(DynamicDecoder, "CAND_LIMIT", limit)
+    with pytest.raises(ValueError):
+        dyn.decode_batch(sents, beam_width=6, vocab_select=True)
