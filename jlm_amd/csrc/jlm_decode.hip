@@ -78,6 +78,14 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
     // reference-compatibility mode of the incremental decoder on segmented models (jlm_decode_plan.di_wwords)
     const bool perm = dynamic && p->di_wwords && p->sg_wword;
 
+#ifdef JLM_PROBE_SKIP
+    // measurement builds only (tools/probes/skip_kernel.sh): JLM_SKIP=<bits> leaves launches out -- 1 edge logits, 2 T projection,
+    // 4 LSTM step, 8 beam step, 16 vocabulary kernel.  Results are wrong; the step time says what is on the critical path.
+    static const int skip = [] { const char *e = getenv("JLM_SKIP"); return e ? atoi(e) : 0; }();
+#define JLM_SKIPPED(bit) (skip & (bit))
+#else
+#define JLM_SKIPPED(bit) 0
+#endif
     for (int f = 0; f < F; ++f) {
         if (join) {
             JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
@@ -97,13 +105,14 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
         st.lse_part = pending_parts ? p->part : nullptr;
         st.ld_part = rmax;
         st.n_parts = pending_parts;
-        JLM_TRY(jlm_beam_step(lat, &st, f, mode, p->max_cands, stream));
+        if (!JLM_SKIPPED(8)) JLM_TRY(jlm_beam_step(lat, &st, f, mode, p->max_cands, stream));
         JLM_TRY(stamp(f, 2));
         pending_parts = 0;
         if (f == F - 1) break;
         const int *rows = st.live + (size_t)f * rmax;
         const int *ndev = st.n_live + f;
-        if (m->split_lstm && m->wt8)
+        if (JLM_SKIPPED(4)) {
+        } else if (m->split_lstm && m->wt8)
             JLM_TRY(jlm_lstm_step_xg(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, m->wt8, m->xgate8, m->H,
                                      m->gate_descale, m->h_scale, m->untied ? p->T : nullptr, rmax, ndev, stream));
         else if (m->split_lstm)
@@ -113,7 +122,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_TRY(jlm_lstm_step((const float *)p->h, p->c, m->H, (float *)p->h, p->c, rows, st.bp, st.word, m->emb,
                                   m->ld_emb, m->wt, m->gate_bias, m->kpad, m->H, m->E, rmax, ndev, stream));
         JLM_TRY(stamp(f, 3));
-        if (!m->untied) {
+        if (!m->untied && !JLM_SKIPPED(2)) {
             if (m->split_lstm)
                 JLM_TRY(jlm_gemm_nt_split(p->h, m->H, rows, m->pmt_split, m->H, nullptr, p->T, m->ldt, rows, nullptr,
                                           m->t_descale, rmax, m->n_t, m->H, ndev, stream));
@@ -130,14 +139,14 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_HIP(hipStreamWaitEvent(side_s, fork, 0));
             est = side_stream;
         }
-        JLM_TRY(jlm_edge_logits_perm(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell, p->sg_word,
+        if (!JLM_SKIPPED(1)) JLM_TRY(jlm_edge_logits_perm(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell, p->sg_word,
                                      perm ? p->sg_wword : nullptr, p->sg_off, p->sidx, cell, p->sg_node, p->edge, beam, B, est));
         if (side_s) {
             JLM_HIP(g_events.get(&join));
             JLM_HIP(hipEventRecord(join, side_s));
         }
         JLM_TRY(stamp(f, 4));
-        if (!m->self_norm) {
+        if (!m->self_norm && !JLM_SKIPPED(16)) {
             if (perm)
                 JLM_TRY(jlm_wordlist_lse_perm(m->segs, m->n_segs, m->b2, p->T, m->ldt, p->g0 + cell, st.cnt, p->cidx + cell,
                                               p->di_words, p->di_wwords, p->di_off, p->di_idx, 2 * cell, p->run_max, p->run_sum,

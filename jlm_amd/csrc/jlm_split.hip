@@ -115,8 +115,8 @@ extern "C" int jlm_dequant_u8(const uint8_t *code, int rows, int k, int ld_code,
 // ---------------------------------------------------------------------------------------------
 // Rows-stationary vocabulary log-sum-exp, split-f16 form.  Same structure as
 // vocab_lse_stationary_kernel (jlm_gemm.hip): a workgroup keeps 128 hypothesis rows' operands in
-// registers (32 rows per wave, both planes, the whole contraction) and streams a range of
-// vocabulary tiles (32*MT rows) past them; per row and range one (max, sum exp) partial.
+// registers (32 rows per wave, both planes, the whole contraction) and streams a sub-range of
+// vocabulary tiles (32*MT rows) past them; per row and sub-range one (max, sum exp) partial.
 //
 // NS = k-steps of 16 the contraction is split into (k <= 16 NS); a tile is consumed in
 // NC = ceil(NS / 4) chunks of <= 4 steps (64 k-values, 256 bytes per vocabulary row), one workgroup
@@ -323,7 +323,7 @@ __device__ __forceinline__ void lse_split_body(
 #ifdef JLM_TILETRACE
     int tt_n = 0;
     const int tt_cls = NS <= 4 ? 2 : (NS <= 7 ? 1 : 0);
-    // the first range of each segment, row tile 0: any workgroup whose pis == 0 && pt == 0
+    // the first sub-range of each segment, row tile 0
     const bool tt_wg = (vt0 == 0 && pt == 0 && wave == 0);
 #endif
     for (int t = vt0; t < vt1; ++t) {
@@ -510,15 +510,18 @@ __device__ __forceinline__ void lse_split_body_h(
     const bool row_ok = prow < n_paths;
     const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
     f16x8 thi[NS], tlo[NS];
-    {   // as in lse_split_body: the lane's row operands, the constant 1.0 of the bias column at k == K
-        constexpr int NG = (NS + 3) / 4;
-        f32x4 xb[2][4][2];
+    {   // the lane's row operands (the constant 1.0 of the bias column at k == K).  Every load of the row is requested before
+        // any is used -- one memory round trip; in groups of four k-steps (lse_split_body) the prologue was four of them, 5 us
+        // of an 85-us workgroup -- the accumulators are not live yet, the registers are there (16-step form: two groups of 8)
+        constexpr int GS = NS <= 13 ? NS : 8;
+        constexpr int NG = (NS + GS - 1) / GS;
+        f32x4 xb[NG > 1 ? 2 : 1][GS][2];
         auto load_group = [&](int g, int par) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < GS; ++j)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int k = 16 * (4 * g + j) + 8 * h + 4 * q;
+                    const int k = 16 * (GS * g + j) + 8 * h + 4 * q;
                     xb[par][j][q] = *reinterpret_cast<const f32x4 *>(trow + (k < K ? k : 0));
                 }
         };
@@ -527,8 +530,8 @@ __device__ __forceinline__ void lse_split_body_h(
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int st = 4 * g + j;
+            for (int j = 0; j < GS; ++j) {
+                const int st = GS * g + j;
                 if (st >= NS) break;
                 float x[8];
 #pragma unroll
@@ -536,7 +539,7 @@ __device__ __forceinline__ void lse_split_body_h(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int k = 16 * st + 8 * h + 4 * q + e;
-                        x[4 * q + e] = (row_ok && k < K) ? xb[g & 1][j][q][e] : (row_ok && k == K) ? 1.0f : 0.0f;
+                        x[4 * q + e] = (row_ok && k < K) ? xb[NG > 1 ? (g & 1) : 0][j][q][e] : (row_ok && k == K) ? 1.0f : 0.0f;
                     }
                 split8(x, t_scale, thi[st], tlo[st]);
             }
@@ -717,12 +720,12 @@ __device__ __forceinline__ void vocab_lse_split_main(const LseSplitArgs &a, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
     // XCD-aware order, as in vocab_lse_stationary_kernel: with n_parts a multiple of 8 one XCD walks
-    // all row tiles of its vocabulary ranges, which stay in its L2
+    // all row tiles of its vocabulary columns, which stay in its L2
     const int b = blockIdx.x;
     int p, pt;
-    // n_parts = 8 q + r: the first 8 q ranges are dealt to the XCDs (block b runs on XCD b % 8), range p on XCD p % 8 with
-    // all of its row tiles; the r < 8 ranges left over follow linearly -- their few workgroups land one or two per XCD, on the
-    // CUs the 8 q ranges leave idle (10 row tiles: 3 x 10 = 30 of an XCD's 32 CUs)
+    // n_cols = 8 q + r: the first 8 q columns are dealt to the XCDs (block b runs on XCD b % 8), column p on XCD p % 8 with
+    // all of its row tiles; the r < 8 columns left over follow linearly -- their few workgroups land one or two per XCD, on the
+    // CUs the 8 q columns leave idle (10 row tiles: 3 x 10 = 30 of an XCD's 32 CUs)
     const int nb8 = (a.n_cols & ~7) * n_ptiles;
     if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
     else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_split8_kernel(LseSplitArgs a
     vocab_lse_split_main<8>(a, T, ldt, rows, part, ld_part, n_rows_max, n_dev, n_ptiles);
 }
 
-// Host side: ranges per segment in proportion to their cost, one resident round of workgroups.
+// Host side: equal-cost columns over the concatenated segments, one resident round of workgroups.
 // Returns the number of partial slices written (fold them with jlm_lse_combine), or <0.
 extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_scale, const float *descale,
                                    const int *bias_col, int n_segs, const float *b2, const float *T, int ldt, const int *rows,
@@ -787,9 +790,9 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
     LseSplitArgs a;
     a.n_segs = n_segs;
-    static int c0x2 = -1, np8 = -1;            // cost constant in half k-steps; JLM_LSE_NP8=1: range count a multiple of 8
+    static int c0x2 = -1, np8 = -1;            // cost constant in half k-steps; JLM_LSE_NP8=1: column count a multiple of 8
     if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 2; }
-    // JLM_LSE_NP8=0 lets the range count use every CU (25 ranges x 10 row tiles = 250 workgroups instead of 240: the kernel
+    // JLM_LSE_NP8=0 lets the column count use every CU (25 columns x 10 row tiles = 250 workgroups instead of 240: the kernel
     // alone runs 3 % faster), but the 16 CUs the multiple of 8 leaves idle are where the other batch in flight runs its
     // small kernels meanwhile: the decode is 2.8 % slower with them taken (2.59 vs 2.52 ms per step, tools/ab_engine.py)
     if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
