@@ -278,11 +278,15 @@ def main():
             while inflight:
                 eng.collect(inflight.popleft())
 
-        # untimed: the requested warm-up steps, and at least 12 decode calls in total (plans for both
-        # streams and both pipeline slots exist before the clock starts)
+        # untimed: the requested warm-up steps (plans for every stream and pipeline slot exist afterwards), then two settle calls
+        # of the timed call's own size: a fresh process runs its first K-batch call 20-25 % slower than the third
+        # (tools/probes/idle_probe.py: 2.96 / 2.52 / 2.39 ms per batch -- the Python heap and the lattice buffers of a call of
+        # that size are faulted in for the first time; an idle second does not bring it back).  The rate reported is the
+        # steady state of a running service, as for any warm-up.
         if args.warmup:
             dec.decode_batch(sents * args.warmup, beam_width=args.beam, **dkw)
-        dec.decode_batch(sents * max(4, 12 - args.warmup), beam_width=args.beam, **dkw)
+        for _ in range(2):
+            dec.decode_batch(sents * max(args.steps, 12 - args.warmup, 4), beam_width=args.beam, **dkw)
         barrier()
         t0 = time.perf_counter()
         out = dec.decode_batch(sents * args.steps, beam_width=args.beam, **dkw)      # K steps = K pipelined 256-sentence batches
@@ -305,9 +309,8 @@ def main():
         line_extra["device_resident_note"] = ("same K steps with the batch's lattice (CSR) already resident in HBM: launch sequence "
                                               "+ n-best traces back on the host, no lattice build / upload / string read-out")
         roofline, gate_obj = measure_kernels(dec, lat, ekind, ekw, min(args.steps, 20), full_vocab=(args.decoder == "static"))
-        # diagnostic: does this box overlap the two batches in flight?  The same pipelined loop with one
-        # stream and with the engine's two (on some boxes the two are equal: the queues of the two streams
-        # are not run side by side there).
+        # diagnostic: does this box overlap the batches in flight?  The same pipelined loop with one stream and with the
+        # engine's own (on some boxes the two are equal: the queues of the streams are not run side by side there).
         if eng.n_streams >= 2:
             def timed_ms(n):
                 barrier()
@@ -315,15 +318,15 @@ def main():
                 run_device_steps(n)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n * 1e3
-            keep = eng.n_streams
-            two = timed_ms(12)
-            eng.n_streams = 1
+            keep = (eng.n_streams, eng.use_side)
+            many = timed_ms(12)
+            eng.n_streams, eng.use_side = 1, False
             run_device_steps(3)
             one = timed_ms(12)
-            eng.n_streams = keep
+            eng.n_streams, eng.use_side = keep
             eng._rr = 0
-            line_extra["stream_overlap"] = {"one_stream_ms_per_step": round(one, 3), "two_streams_ms_per_step": round(two, 3),
-                                            "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
+            line_extra["stream_overlap"] = {"one_stream_ms_per_step": round(one, 3), "engine_streams_ms_per_step": round(many, 3),
+                                            "engine_streams": keep[0], "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
         workload = ("BASELINE configs[1]: LSTM h=512, D-softmax* segs=(200,100,50), V=50k, beam=10, batch=256 sentences x 20 kana "
                     "per GPU; strings in -> n-best strings out (SURVEY 8d)"
                     if (args.fixture == "mid-vtable" and args.decoder == "static" and args.batch == 256 and args.length == 20

@@ -4,11 +4,11 @@ import sys
 
 
 def _want_hw_queues(n=8):
-    """The decode engine keeps up to four HIP streams busy (two batches in flight, each with a side
-    stream for its edge logits).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4,
+    """The decode engine keeps three HIP streams busy (three batches in flight; JLM_STREAMS=2: two, each with a
+    side stream for its edge logits).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4,
     one of them the null stream's); streams that share a queue serialise, and with 4 queues a side
     stream lands on the other batch's queue -- the two-stream overlap is gone (3.8 instead of 2.8 ms per
-    step, tools/probes/streams_probe.py).  The variable is read when the HIP runtime initialises, so it
+    step, tools/probes/streams_probe.py; three streams on 4 queues: 2.28 vs 2.23 ms device-resident).  The variable is read when the HIP runtime initialises, so it
     can only be defaulted here if that has not happened yet; the engine asks hw_queues_ok() and falls
     back to running the edge logits on the batch's own stream."""
     cur = os.environ.get("GPU_MAX_HW_QUEUES")

@@ -175,7 +175,12 @@ class DecodeEngine:
         # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
         # (beam step, LSTM step, T projection: two thirds of the launches, a third of the time, most CUs
         # idle) fill in beside the vocabulary kernel of batch i.  JLM_STREAMS=1 keeps one stream.
-        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "2")))
+        # THREE batches in flight on three streams, edge logits on the batch's own stream: 2.14-2.22 ms per step against
+        # 2.32-2.36 with two streams + a side stream each (tools/ab_streams.py).  A frame of one batch is a chain of dependent
+        # launches (beam step, LSTM step, T projection, vocabulary kernel: every one of them on the critical path of the step,
+        # tools/probes/skip_kernel.sh) and the chains of three batches fill each other's gaps better than those of two; side
+        # streams on top (six streams, fork / join events across them) cost more than the overlap buys: 3.3 ms.
+        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "3")))
         self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
@@ -280,11 +285,11 @@ class DecodeEngine:
         p.dev_ints.copy_(p.host_ints, non_blocking=True)
         p.cnt.zero_()
         p.n_live.zero_()
-        # with two batches in flight a side stream per batch needs more hardware queues than ROCm's default
-        # (jlm_amd/__init__.py); without them the edge logits run on the batch's own stream (-4 %, not -30 %)
+        # side stream for the edge logits: with one stream, and with two when the hardware queues are there (ROCm's default of
+        # four is not enough: jlm_amd/__init__.py); with the default three streams they run on the batch's own stream
         from . import hw_queues_ok
         side = self.use_side and self.device.type == "cuda" and (
-            self.n_streams < 2 or hw_queues_ok() or os.environ.get("JLM_SIDE") == "1")
+            self.n_streams < 2 or (self.n_streams == 2 and hw_queues_ok()) or os.environ.get("JLM_SIDE") == "1")
         # the whole launch sequence of the batch: ONE op, no host synchronisation inside (csrc/jlm_decode.hip)
         # another batch in flight: this batch's vocabulary kernel takes LSE_SHARE_PCT of the CUs and the other batch's
         # latency-bound kernels the rest, side by side (include/jlm_hip.h, jlm_decode_plan.lse_cu_share_pct)

@@ -29,6 +29,10 @@ for rep in range(3):
     dec.decode_batch(sents * K, beam_width=10)
     t1 = time.perf_counter(); torch.cuda.synchronize()
     print("call of %d chunks: %.2f ms = %.3f ms per chunk" % (K, (t1 - t0) * 1e3, (t1 - t0) / K * 1e3))
+    if rep == 0:
+        cs = [b - t0 for n, a, b in ev if n == "collect"]
+        print("  first call, collect completions, ms:", " ".join("%.1f" % (c * 1e3) for c in cs))
+        print("  plans:", len(eng.plans))
     if rep == 2:
         for name in ("lattice", "submit", "collect"):
             xs = [(a - t0, b - t0) for n, a, b in ev if n == name]
