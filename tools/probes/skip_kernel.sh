@@ -5,6 +5,6 @@
 #     -o build_prof/libjlm_hip_skip.so jlm_amd/csrc/jlm_{gemm,beam,split,gate,decode}.hip
 cp jlm_amd/csrc/libjlm_hip.so /tmp/libjlm_hip.keep && cp build_prof/libjlm_hip_skip.so jlm_amd/csrc/libjlm_hip.so
 for s in 0 1 2 4 8 16 7 15 0; do
-  echo "JLM_SKIP=$s: $(JLM_SKIP=$s timeout 200 python tools/ab_streams.py 2,2,66 2>&1 | tail -1 | cut -c1-110)"
+  echo "JLM_SKIP=$s: $(JLM_SKIP=$s timeout 200 python tools/ab_streams.py ${CFG:-3,3,66} 2>&1 | tail -1 | cut -c1-110)"
 done
 cp /tmp/libjlm_hip.keep jlm_amd/csrc/libjlm_hip.so
