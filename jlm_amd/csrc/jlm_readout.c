@@ -6,6 +6,12 @@
  * much as the GPU needs for the whole batch, so this one call builds them with the C API.  Host logic only;
  * jlm_amd/engine.py keeps the equivalent numpy implementation (DecodeEngine._read_out_py) and the tests
  * compare the two.
+ *
+ * The containers built here hold strings, floats and each other -- they cannot be part of a reference cycle unless the caller
+ * later makes one through them -- and are taken out of the cyclic collector's lists (PyObject_GC_UnTrack, as CPython itself
+ * does for tuples and dicts of atomic contents): 8 k containers per 256-sentence batch otherwise make every collection of the
+ * caller's process scan the results decoded so far (2 ms per 40-batch call when the collector catches up; quadratic with the
+ * collector left on during the call).  Reference counting frees them as usual.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -59,12 +65,14 @@ static PyObject *nbest(PyObject *self, PyObject *args) {
             PyObject *lst = PyList_New(nr);
             if (!lst) goto fail;
             PyList_SET_ITEM(out, s, lst);
+            PyObject_GC_UnTrack(lst);
             for (int r = 0; r < nr; ++r) {
                 const Py_ssize_t row = s * beam + r;
                 const int k = pl[row] - 1;             /* the trace ends at the root (<eos>), which is dropped */
                 if (k >= stride) { PyErr_SetString(PyExc_ValueError, "nbest: trace longer than stride"); goto fail; }
                 PyObject *words = PyList_New(k);
                 if (!words) goto fail;
+                PyObject_GC_UnTrack(words);
                 for (int j = 0; j < k; ++j) {          /* traces run from the last word back */
                     const int32_t id = pn[row * stride + (k - 1 - j)];
                     PyObject *w;
@@ -88,6 +96,7 @@ static PyObject *nbest(PyObject *self, PyObject *args) {
                 PyObject *sc = PyFloat_FromDouble(ps[row]);
                 PyObject *tup = sc ? PyTuple_New(2) : NULL;
                 if (!tup) { Py_XDECREF(sc); Py_DECREF(words); goto fail; }
+                PyObject_GC_UnTrack(tup);
                 PyTuple_SET_ITEM(tup, 0, sc);
                 PyTuple_SET_ITEM(tup, 1, words);
                 PyList_SET_ITEM(lst, r, tup);
