@@ -125,18 +125,28 @@ struct TileMap {
 struct EpiStore {
     float *C; const int *c_map; int ldc; const float *bias;
     float scale = 1.0f;                    // split-f16 mainloop: 2^-(eA + eB); 1 (exact) for the f32 mainloop
-    template <class Cfg> struct Pre {};
-    template <class Cfg> __device__ void prepare(Pre<Cfg> &, int, int) const {}
-    template <class Cfg>
-    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
-                        int M, int N, float *, const Pre<Cfg> &) const {
+    // The storage rows of the lane's 16 x MT output rows, loaded at kernel start: behind the k-loop the index load is a
+    // memory round trip in front of every store (the T projection's epilogue: 3.3 of its 10 us, tools/probes/tproj_profile.py).
+    template <class Cfg> struct Pre { int r[Cfg::MT][16]; };
+    template <class Cfg> __device__ void prepare(Pre<Cfg> &pre, int m0, int M) const {
+        const int lane = threadIdx.x & 63, wm = (int)(threadIdx.x >> 6) / Cfg::WAVES_N;
 #pragma unroll
         for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (row >= M) continue;
-                int r = c_map ? c_map[row] : row;
+                const int row = m0 + (wm * Cfg::MT + mt) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                pre.r[mt][reg] = row < M ? (c_map ? c_map[row] : row) : -1;
+            }
+    }
+    template <class Cfg>
+    __device__ void run(f32x16 (&acc)[Cfg::MT][Cfg::NT], int m0, int n0, int wm, int wn, int lane,
+                        int M, int N, float *, const Pre<Cfg> &pre) const {
+#pragma unroll
+        for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = pre.r[mt][reg];
+                if (r < 0) continue;
                 float *crow = C + (size_t)r * ldc;
 #pragma unroll
                 for (int nt = 0; nt < Cfg::NT; ++nt) {
