@@ -164,8 +164,8 @@ def test_timed_frame_loop_equals_fast_frame_loop(fixture, kind, kw, fx):
 @pytest.mark.parametrize("fixture,kind,kw", [("small-vtable", "static", {}), ("small-tied", "static", {"vocab_select": True}),
                                              ("small-tied", "dynamic", {"vocab_select": True})])
 def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
-    """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- two streams, side
-    streams, frame-loop op, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
+    """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- three batches in flight
+    on three streams, frame-loop op, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
     a time on one stream, timed (no side stream either).  Same kernels, same operands: bit-identical results."""
     f = fx(fixture)
     dec = _decoder(f, kind)
