@@ -32,6 +32,8 @@
 #include "jlm_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #define GLDS16(gp, lp)                                                                          \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
@@ -41,8 +43,9 @@
 // 100 MHz wall clock at kernel start, after the index chains, when the first stage has landed, after the steady-state
 // k-steps, after the mainloop, at the end.
 #ifdef JLM_PROFILE
-static __device__ unsigned long long jlm_gate_time[2048][2][6];
-#define JLM_GT_T(i) do { if ((threadIdx.x & 255) == 0) jlm_gate_time[blockIdx.x & 2047][threadIdx.x >> 8][i] = wall_clock64(); } while (0)
+static __device__ unsigned long long jlm_gate_time[2048][2][8];   // [6], [7]: shader clock at stamps 2 and 3
+#define JLM_GT_T(i) do { if ((threadIdx.x & 255) == 0) { jlm_gate_time[blockIdx.x & 2047][threadIdx.x >> 8][i] = wall_clock64(); \
+    if ((i) == 2 || (i) == 3) jlm_gate_time[blockIdx.x & 2047][threadIdx.x >> 8][(i) == 2 ? 6 : 7] = clock64(); } } while (0)
 extern "C" int jlm_prof_read_gate(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_gate_time), sizeof(jlm_gate_time)) == hipSuccess ? 0 : -1;
 }
@@ -363,6 +366,307 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
 #endif
 }
 
+
+// ---- the same tile with the fragment reads a whole half step ahead ("refill in place"; H / 32 = NK k-steps, unrolled) ----
+// The form above reads the fragments of half step s + 1 behind the MFMAs of half step s and drains the LDS queue
+// (lgkmcnt(0)) at the end of every half step: the last read goes out one MFMA before the wait, so a full LDS round trip
+// (hundreds of cycles with 8 waves' reads and the DMA writes in the queue) is exposed twice per k-step and wave.  Here
+// the three products of a half step run in the order  lo.hi -> hi.hi -> hi.lo  so that the fragment registers die one
+// after the other -- A_lo behind the first group, B_hi[nb] behind MFMA nb of the second, B_lo[nb] behind MFMA nb of the
+// third, A_hi at the end -- and each register is REFILLED IN PLACE with its value of half step s + 2 right behind the
+// MFMA that read it last.  Two register sets (even / odd half steps), as before; every read now has >= 12 (NB = 3) / 8
+// (NB = 2) MFMAs = 380 / 250 cycles of cover, and the waits are the counted lgkmcnt(n) hipcc derives in straight-line
+// code (in-order LDS returns), never a drain.  Stage kt + 1 is read DURING k-step kt, so it must have landed at the
+// barrier at the START of k-step kt; the slot refilled behind that barrier is the one of stage kt - 1 (stage kt's last
+// reads are still in the queue there): three stages resident + one being filled, two k-steps of DMA lead.
+template <class F, int... I>
+__device__ __forceinline__ void gate_for_each_ic(F &&f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+
+template <int NB, int NP, int NK, int BS, int ABL>
+__device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0, const int n0, const int M, const int wave,
+                                               const int lane, float *smem) {
+    const int gb = wave & 3;
+    const int hb0 = (wave >> 2) ? 3 : 0;
+    const int li = lane & 31, hf = lane >> 5;
+    const int H = a.H, ld = a.ld;
+    const int u0 = (n0 >> 2) + 8 * gb + 4 * hf;
+    constexpr int NXG = 5 * NB;
+
+    JLM_GT_T(0);
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int eg[NB], ep[NB], ew[NB], pp[NP - 2];
+    bool eok[NB], pok[NP - 2];
+    int prow[NP - 2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int r = m0 + 32 * (hb0 + nb) + li;
+        eok[nb] = r < M;
+        const int rc = eok[nb] ? r : M - 1;
+        eg[nb] = a.rows ? a.rows[rc] : rc;
+    }
+#pragma unroll
+    for (int i = 0; i < NP - 2; ++i) {
+        const int pidx = (NP == 4) ? 2 * wave + i : 8 + 3 * (wave - 4) + i;
+        prow[i] = 8 * pidx;
+        const int r = m0 + prow[i] + lrow;
+        pok[i] = r < M;
+        const int rc = pok[i] ? r : M - 1;
+        pp[i] = a.rows ? a.rows[rc] : rc;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        ep[nb] = a.prev[eg[nb]];
+        ew[nb] = a.word[eg[nb]];
+    }
+#pragma unroll
+    for (int i = 0; i < NP - 2; ++i) pp[i] = a.prev[pp[i]];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        asm volatile("" : "+v"(ew[nb]));
+        asm volatile("" : "+v"(ep[nb]));
+    }
+#ifdef JLM_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    JLM_GT_T(1);
+#endif
+
+    // LDS-DMA pieces of this wave (2 of the gate matrix, NP - 2 of the gathered state rows), as BUFFER loads:
+    //   buffer_load_dwordx4 v[row index : byte offset], rsrc, s(128 * k-step) idxen offen lds
+    // address = base + index * stride + offset + soffset, computed by the texture unit in 64 bits: no per-k-step address
+    // arithmetic (the k-step is the scalar offset -- NOT the instruction's immediate offset, which a load to LDS also
+    // adds to the LDS address), two registers per piece for the whole kernel,
+    // and a row index at or above num_records reads zeros (rows past the edge, hypotheses without a predecessor).
+    // And, decisive for the pipeline below: hipcc treats global_load_lds (a FLAT encoding) as an access that may
+    // return through either counter and, while one is outstanding -- here always --, turns EVERY wait for an LDS
+    // read into s_waitcnt lgkmcnt(0); behind buffer_load ... lds it counts (lgkmcnt(n), in-order returns).
+    constexpr int OOB_ROW = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)(H * 4), 0x40000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
+    int vidx[NP], voff[NP];
+    int dst[NP];                                         // float offset inside a stage (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < 2) {
+            const int pr = 8 * (2 * wave + i);
+            const int row = pr + lrow;
+            vidx[i] = n0 + row;
+            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+            dst[i] = pr * 32;
+        } else {
+            const int row = prow[i - 2] + lrow;
+            const int p = pok[i - 2] ? pp[i - 2] : -1;
+            vidx[i] = p >= 0 ? p : OOB_ROW;
+            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+            dst[i] = (GT_BN + prow[i - 2]) * 32;
+        }
+    }
+    auto issue = [&](auto stage_c) {
+        constexpr int S = decltype(stage_c)::value;
+        float *base = smem + (S & 3) * GT_STAGE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(i < 2 ? rs_w : rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]),
+                                                        16, vidx[i], voff[i], S * 128, 0, 0);
+    };
+
+    f32x4 xg[NB][4], cp[NB];
+    if constexpr (ABL & 16) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            cp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xg[nb][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float *xrp[NB], *cpp[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        xrp[nb] = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * gb + 4 * hf;
+        cpp[nb] = a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+    }
+    auto load_epilogue_operands = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                         "global_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\t"
+                         "global_load_dwordx4 %3, %4, off offset:96"
+                         : "=&v"(xg[nb][0]), "=&v"(xg[nb][1]), "=&v"(xg[nb][2]), "=&v"(xg[nb][3]) : "v"(xrp[nb]) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cp[nb]) : "v"(cpp[nb]) : "memory");
+        }
+    };
+    auto wait_epilogue_operands = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xg[nb][0]), "+v"(xg[nb][1]), "+v"(xg[nb][2]), "+v"(xg[nb][3]), "+v"(cp[nb])::"memory");
+    };
+
+    int goff[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * hf + p) ^ ((li >> 1) & 7)) * 4);
+    const int w_off = gb * 32 * 32;
+    const int h_off = (GT_BN + hb0 * 32) * 32;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+    // fragment registers: plane 0 = hi, 1 = lo.  The A (gate matrix) fragments exist twice (even / odd half steps); the B
+    // (hypothesis) fragments twice where the registers allow it (BS = 2: the two-block waves) and once where they do not
+    // (BS = 1, the three-block waves: 24 registers less; B_hi then has 2 NB - 1 = 5 MFMAs of cover, B_lo 8).
+    f16x8 A[2][2], B[BS][NB][2];
+    // ABL (measurement builds, -DJLM_GATE_ABLATE): 1 no MFMAs, 2 no fragment reads in the loop, 4 no LDS-DMA in the loop,
+    // 8 no barrier, 16 no epilogue operand loads.  Results are wrong by construction; the time is the answer.
+    auto rdA = [&](int stage, int st, int p) {
+        if ((ABL & 2) && stage > 0) return;
+        A[st][p] = *reinterpret_cast<const f16x8 *>(smem + (stage & 3) * GT_STAGE_FLOATS + w_off + goff[st][p]);
+    };
+    auto rdB = [&](int stage, int st, int nb, int p) {
+        if ((ABL & 2) && (stage > 0 || st >= BS)) return;
+        B[st % BS][nb][p] = *reinterpret_cast<const f16x8 *>(smem + (stage & 3) * GT_STAGE_FLOATS + h_off + nb * 1024 + goff[st][p]);
+    };
+    auto mf = [&](int st, int pa, int nb, int pb) {
+        if constexpr (ABL & 1) asm volatile("" : "+v"(acc[nb]) : "v"(A[st][pa]), "v"(B[st % BS][nb][pb]));
+        else acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[st][pa], B[st % BS][nb][pb], acc[nb], 0, 0, 0);
+    };
+    // One half step (k-step kt, half st): 3 NB MFMAs; behind them the refills.
+    //   group 1  A_lo . B_hi[nb]     then A_lo is free
+    //   group 2  A_hi . B_hi[nb]     B_hi[nb] free behind MFMA nb
+    //   group 3  A_hi . B_lo[nb]     B_lo[nb] free behind MFMA nb, A_hi behind the last
+    // A is refilled with half st of k-step kt + 1; B with the same (BS = 2) or with the NEXT half step (BS = 1).
+    auto half = [&](auto kt_c, auto st_c, auto dma_c) {
+        constexpr int KT = decltype(kt_c)::value, ST = decltype(st_c)::value;
+        constexpr int DMA = decltype(dma_c)::value;      // stage to request behind the first MFMA (-1: none)
+        constexpr bool RA = KT + 1 < NK;                 // a next k-step exists
+        constexpr int BKT = (BS == 2) ? KT + 1 : (ST == 0 ? KT : KT + 1), BST = (BS == 2) ? ST : 1 - ST;
+        constexpr bool RB = BKT < NK;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            mf(ST, 1, nb, 0);
+            if constexpr (DMA >= 0 && !(ABL & 4)) { if (nb == 0) issue(IC<DMA>{}); }
+        }
+        if (RA) rdA(KT + 1, ST, 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            mf(ST, 0, nb, 0);
+            if (RB) rdB(BKT, BST, nb, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            mf(ST, 0, nb, 1);
+            if (RB) rdB(BKT, BST, nb, 1);
+        }
+        if (RA) rdA(KT + 1, ST, 0);
+        // pin the issue order: one MFMA, then the read(s) that follow it in the text above
+#pragma unroll
+        for (int i = 0; i < 3 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i == 0 && DMA >= 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+            if (i == NB - 1 && RA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i >= NB && RB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i == 3 * NB - 1 && RA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    static_assert(NK >= 4, "ring of four stages");
+    issue(IC<0>{}); issue(IC<1>{}); issue(IC<2>{});
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
+    JLM_GT_T(2);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        rdA(0, st, 1); rdA(0, st, 0);
+        if (st < BS) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { rdB(0, st, nb, 0); rdB(0, st, nb, 1); }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the epilogue's operands go out at k-step xg_at (1 + wave), behind that k-step's DMA request; the waits of the two
+    // k-steps behind it leave them in flight (they are younger than the stage waited for), the third one retires them
+    const int xg_at = 1 + wave;
+    gate_for_each_ic([&](auto ktc) {
+        constexpr int KT = decltype(ktc)::value;
+        if constexpr (KT + 1 < NK) {
+            constexpr int base = (KT + 2 < NK) ? NP : 0;
+            if constexpr (ABL & 8) {
+                if ((unsigned)(KT - 1 - xg_at) < 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(base + NXG) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(base) : "memory");
+            } else {
+                if ((unsigned)(KT - 1 - xg_at) < 2u) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(base + NXG) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(base) : "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KT == NK - 4) JLM_GT_T(5);
+        half(ktc, IC<0>{}, IC<(KT + 3 < NK) ? KT + 3 : -1>{});
+        if (!(ABL & 16) && KT == xg_at) load_epilogue_operands();
+        half(ktc, IC<1>{}, IC<-1>{});
+    }, std::make_integer_sequence<int, NK>{});
+    JLM_GT_T(3);
+    wait_epilogue_operands();
+
+    const float ds = a.descale;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int g = eok[nb] ? eg[nb] : -1;
+        if (g < 0) continue;
+        f32x4 cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
+            const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
+            cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
+            hn[e] = jlm_tanh(cn[e]) * go;
+        }
+        *reinterpret_cast<f32x4 *>(a.c_out + (size_t)g * ld + u0) = cn;
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 hi4, lo4;
+        jlm_split4(hn, a.h_scale, hi4, lo4);
+        _Float16 *blk = reinterpret_cast<_Float16 *>(a.h_out + (size_t)g * ld + (u0 & ~7)) + (u0 & 7);
+        *reinterpret_cast<f16x4 *>(blk) = hi4;
+        *reinterpret_cast<f16x4 *>(blk + 8) = lo4;
+        if (a.h_f32) *reinterpret_cast<f32x4 *>(a.h_f32 + (size_t)g * ld + u0) = hn;
+    }
+#ifdef JLM_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    JLM_GT_T(4);
+#endif
+}
+
+__device__ __forceinline__ bool gate_tile_of_block(const GateXgArgs &a, int &m0, int &n0, int &M) {
+    const int b = blockIdx.x;
+    int tm, tn;
+    if ((a.tiles_n & 7) == 0) {
+        const int x = b & 7, j = b >> 3, cpx = a.tiles_n >> 3;
+        tn = x * cpx + j % cpx;
+        tm = j / cpx;
+    } else {
+        tm = b / a.tiles_n;
+        tn = b % a.tiles_n;
+    }
+    if (tm >= a.tiles_m) return false;
+    M = a.ndev ? min(*a.ndev, a.nrows) : a.nrows;
+    m0 = tm * GT_BM; n0 = tn * GT_BN;
+    return m0 < M;
+}
+
+// H = 512 (16 k-steps), the refill-in-place pipeline
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void gate_xg_u16_kernel(GateXgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int m0, n0, M;
+    if (!gate_tile_of_block(a, m0, n0, M)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave < 4) gate_xg_body_u<3, 4, 16, 1, ABL>(a, m0, n0, M, wave, lane, smem);
+    else gate_xg_body_u<2, 5, 16, 2, ABL>(a, m0, n0, M, wave, lane, smem);
+}
+
 __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware tile order (block b runs on XCD b % 8, observed; speed only): when the gate tiles divide over the 8
@@ -389,6 +693,26 @@ __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
 
 }  // namespace
 
+// the kernel of the refill-in-place pipeline; measurement builds (-DJLM_GATE_ABLATE) carry ablated copies, picked by JLM_GATE_ABL
+static std::vector<const void *> gate_u16_variants() {
+    std::vector<const void *> v{reinterpret_cast<const void *>(gate_xg_u16_kernel<0>)};
+#ifdef JLM_GATE_ABLATE
+#define GV(n) v.push_back(reinterpret_cast<const void *>(gate_xg_u16_kernel<n>));
+    GV(1) GV(2) GV(4) GV(8) GV(6) GV(14) GV(5) GV(16) GV(22)
+#undef GV
+#endif
+    return v;
+}
+static const void *gate_u16_selected() {
+#ifdef JLM_GATE_ABLATE
+    static const int abl = getenv("JLM_GATE_ABL") ? atoi(getenv("JLM_GATE_ABL")) : 0;
+    static const int ids[] = {0, 1, 2, 4, 8, 6, 14, 5, 16, 22};
+    static const std::vector<const void *> v = gate_u16_variants();
+    for (size_t i = 0; i < v.size(); ++i) if (ids[i] == abl) return v[i];
+#endif
+    return reinterpret_cast<const void *>(gate_xg_u16_kernel<0>);
+}
+
 extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out, const int *rows,
                                 const int *prev, const int *word, const void *wt8, const float *xgate8, int H, float descale,
                                 float h_scale, float *h_f32_out, int n_rows_max, const int *n_dev, void *stream) {
@@ -399,6 +723,10 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gate_xg_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        for (const void *k : gate_u16_variants()) {
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_done = true;
     }
     GateXgArgs a;
@@ -409,7 +737,13 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     a.nrows = n_rows_max; a.ndev = n_dev;
     a.tiles_m = (n_rows_max + GT_BM - 1) / GT_BM;
     a.tiles_n = 4 * H / GT_BN;
-    hipLaunchKernelGGL(gate_xg_kernel, dim3(a.tiles_m * a.tiles_n), dim3(512), GT_LDS_BYTES, (hipStream_t)stream, a);
+    static const int variant = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : 1;
+    if (variant == 1 && H == 512) {
+        void *params[] = {&a};
+        hipError_t e = hipLaunchKernel(gate_u16_selected(), dim3(a.tiles_m * a.tiles_n), dim3(512), params, GT_LDS_BYTES, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    } else
+        hipLaunchKernelGGL(gate_xg_kernel, dim3(a.tiles_m * a.tiles_n), dim3(512), GT_LDS_BYTES, (hipStream_t)stream, a);
     JLM_LAUNCH_CHECK();
     return 0;
 }

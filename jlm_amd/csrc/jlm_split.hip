@@ -23,6 +23,20 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
+// LDS-DMA as a BUFFER load (buffer_load_dwordx4 ... offen lds): address = descriptor base + per-lane byte offset (one VGPR)
+// + scalar byte offset (SGPR).  Same data path as global_load_lds; what differs is hipcc's wait bookkeeping: it treats
+// global_load_lds (FLAT encoding) as possibly outstanding on BOTH counters and, while one is in flight -- in these
+// kernels always --, turns every wait for a fragment read into s_waitcnt lgkmcnt(0) (a drain); behind a buffer load it
+// counts (lgkmcnt(n), in-order LDS returns).  JLM_LSE_BUFDMA=0 keeps the FLAT form for A/B builds.
+#ifndef JLM_LSE_BUFDMA
+#define JLM_LSE_BUFDMA 1
+#endif
+#define BLDS16(rsrc, voff, soff, lp)                                                                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void *)(lp), 16, (int)(voff), (int)(soff), 0, 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t jlm_raw_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+}
+
 #define split8 jlm_split8
 #ifndef JLM_LSE_PRIO
 #define JLM_LSE_PRIO 0
@@ -216,6 +230,7 @@ __device__ __forceinline__ void lse_split_body(
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
     const float *__restrict__ Bp = sg.B;
+    const __amdgpu_buffer_rsrc_t rs_b = jlm_raw_rsrc(Bp);
     // 1. this lane's row operands: for step s the lane half h owns k = 16 s + 8 h .. + 7, both planes
     const int prow = pt * (32 * NW) + wave * 32 + li;
     const bool row_ok = prow < n_paths;
@@ -279,16 +294,26 @@ __device__ __forceinline__ void lse_split_body(
             voff[q] = lane_row_b + 4u * (unsigned)min(c_start * 16 + ((g0 ^ (4 * q)) << 2), ldb - 4);
         const int row0 = t * BMV + wave * NINST * 4;               // scalar: first row of this wave's pieces
         if (row0 + NINST * 4 <= n_vocab) {
+#if JLM_LSE_BUFDMA
+            const unsigned sb = (unsigned)row0 * (unsigned)ldb * 4u;                // scalar: < 2 GB per segment block (checked at launch)
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) BLDS16(rs_b, voff[i & 3], sb + (unsigned)i * row4_b, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#else
             const char *sbase = reinterpret_cast<const char *>(Bp) + (size_t)row0 * ldb * 4;
 #pragma unroll
             for (int i = 0; i < NINST; ++i)
                 GLDS16(sbase + (size_t)i * row4_b + voff[i & 3], Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < NINST; ++i) {
                 const int vrow = min(row0 + 4 * i + lrow, n_vocab - 1);
                 const unsigned off = (unsigned)vrow * (unsigned)ldb * 4u + (voff[i & 3] - lane_row_b);
+#if JLM_LSE_BUFDMA
+                BLDS16(rs_b, off, 0, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#else
                 GLDS16(reinterpret_cast<const char *>(Bp) + off, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#endif
             }
         }
     };
@@ -506,6 +531,7 @@ __device__ __forceinline__ void lse_split_body_h(
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, n_vocab = sg.v_end - sg.v_start, ldb = sg.ldb;
     const float *__restrict__ Bp = sg.B;
+    const __amdgpu_buffer_rsrc_t rs_b = jlm_raw_rsrc(Bp);
     const int prow = pt * (32 * NW) + wave * 32 + li;
     const bool row_ok = prow < n_paths;
     const float *trow = T + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt + sg.t_off;
@@ -560,16 +586,26 @@ __device__ __forceinline__ void lse_split_body_h(
             voff[q] = lane_row_b + 4u * (unsigned)min(c_start * 16 + ((g0 ^ (4 * q)) << 2), ldb - 4);
         const int row0 = t * BMV + wave * NINST * 4;
         if (row0 + NINST * 4 <= n_vocab) {
+#if JLM_LSE_BUFDMA
+            const unsigned sb = (unsigned)row0 * (unsigned)ldb * 4u;                // scalar: < 2 GB per segment block (checked at launch)
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) BLDS16(rs_b, voff[i & 3], sb + (unsigned)i * row4_b, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#else
             const char *sbase = reinterpret_cast<const char *>(Bp) + (size_t)row0 * ldb * 4;
 #pragma unroll
             for (int i = 0; i < NINST; ++i)
                 GLDS16(sbase + (size_t)i * row4_b + voff[i & 3], Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < NINST; ++i) {
                 const int vrow = min(row0 + 4 * i + lrow, n_vocab - 1);
                 const unsigned off = (unsigned)vrow * (unsigned)ldb * 4u + (voff[i & 3] - lane_row_b);
+#if JLM_LSE_BUFDMA
+                BLDS16(rs_b, off, 0, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#else
                 GLDS16(reinterpret_cast<const char *>(Bp) + off, Bs + (buf * BMV + (wave * NINST + i) * 4) * 64);
+#endif
             }
         }
     };
@@ -954,6 +990,7 @@ __global__ __launch_bounds__(256) void wordlist_lse_split_kernel(
     const int h = lane >> 5, li = lane & 31;
     const int K = sg.k, ldb = sg.ldb;
     const float *__restrict__ Bp = sg.B;
+    const __amdgpu_buffer_rsrc_t rs_b = jlm_raw_rsrc(Bp);
     const int ntiles = (nw + 31) >> 5;
     // LDS: [4 waves][WLS_RING][32][64] rings | word ids (padded to whole tiles) | biases (base-2 units)
     float *ring = smem + wave * (WLS_RING * 32 * 64);

@@ -40,9 +40,9 @@ for _ in range(50):
     f()
 torch.cuda.synchronize()
 print("R = %d: %.1f us per call (profiled build)" % (R, (time.perf_counter() - t0) / 50 * 1e6))
-buf = (ctypes.c_ulonglong * (2048 * 2 * 6))()
+buf = (ctypes.c_ulonglong * (2048 * 2 * 8))()
 assert L.jlm_prof_read_gate(buf) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 2, 6).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 2, 8).astype(np.int64)
 nwg = ((R + 159) // 160) * (4 * H // 128)
 a = a[:min(nwg, 2048)]
 t0 = a[:, :, 0].min()
@@ -54,6 +54,9 @@ for w, name in ((0, "wave 0 (3 blocks, requests first)"), (1, "wave 4 (2 blocks,
     for i, nm in enumerate(("index chains", "table rows + DMA prologue -> first stage landed", "main loop", "epilogue (incl. stores landed)")):
         print("   %-48s mean %6.2f  p10 %6.2f  p90 %6.2f us" % (nm, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
     print("   end            mean %6.2f  max %6.2f us" % (x[:, 4].mean(), x[:, 4].max()))
+    cyc = (a[:, w, 7] - a[:, w, 6]).astype(np.float64)
+    print("   main loop in shader cycles: mean %8.0f = %.3f GHz  (%.0f cycles per k-step at H = 512)" % (
+        cyc.mean(), (cyc / (d[:, 2] * 1e3)).mean(), cyc.mean() / 16))
     if a[:, w, 5].max() > 0:
         st = (a[:, w, 5] - a[:, w, 2]) / 100.0
         print("   of the main loop: steady-state k-steps (all but the last 4) %6.2f us, the last 4 %6.2f us" % (
