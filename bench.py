@@ -54,6 +54,21 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
+def self_launch(n):
+    """Re-run this command line as N ranks under torch.distributed.run (what the driver's N > 1 command does)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,9 +88,14 @@ def main():
                     help="static = Decoder full vocabulary (headline); static-vs = vocab_select; dynamic = DynamicDecoder (configs[3])")
     # debugging the N > 1 control flow on a one-GPU box: every rank on device 0, control-plane collectives over gloo
     ap.add_argument("--debug-shared-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-legs", action="store_true", help="config 2 only: skip the short configs[2] / configs[3] legs")
     args = ap.parse_args()
     if args.fixture is None:
         args.fixture = "mid-vtable" if args.config == 2 else "mid-tied"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1; torch.distributed is control plane only -- barrier and max/sum of the timings)
+        return self_launch(args.gpus)
 
     import numpy as np
     import torch
@@ -86,6 +106,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if rank == 0:
         ge.build()
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node == --gpus, or without a launcher: "
+                         "`python bench.py --gpus N` starts the ranks itself)" % (world, args.gpus))
+    if world > 1 and not args.debug_shared_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (--debug-shared-gpu runs every rank on device 0)" % (
+            world, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -98,7 +124,6 @@ def main():
         dist.barrier()
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
 
     from jlm_amd import config as jconfig, shard, synth
     from jlm_amd.decoder import Decoder
@@ -160,11 +185,13 @@ def main():
         secs = float(d[:n].sum()) * 1e-3
         return dict(launches=int(n), avg_ms=float(d[:n].mean()), tflops=flops / secs / 1e12, flops_per_launch=flops / n)
 
-    def measure_kernels(dec, lat, ekind, ekw, steps, full_vocab=True):
+    def measure_kernels(dec, lat, ekind, ekw, steps, full_vocab=True, fixture=None, decoder_name=None):
         """The same decode once more, timed: HIP events on the launching stream around the LSTM step and around the vocabulary
         kernel of every frame (same kernels, same arguments; kept out of the throughput loops so that the event records and
         the single stream do not perturb them)."""
         eng, m = dec._engine, dec.model.dev
+        fixture = fixture or args.fixture
+        decoder_name = decoder_name or args.decoder
         eng.keep_n_live = True
         n_live, durs = [], {"gate_gemm": [], "vocab_lse": []}
         for _ in range(steps):
@@ -194,14 +221,16 @@ def main():
             if split and m.stationary_ok and os.path.exists(tpath):
                 with open(tpath) as tf:
                     tj = json.load(tf)
-                if tj.get("source_sha256") == kernel_source_sha256() and tj.get("fixture") == args.fixture:
+                if tj.get("source_sha256") == kernel_source_sha256() and tj.get("fixture") == fixture:
                     traffic, traffic_note = tj["vocab_lse_hbm_bytes_per_call"], tj["note"]
                 else:
-                    traffic_note = "profiles/traffic_latest.json was measured on other kernel sources / another fixture: omitted"
+                    traffic_note = ("profiles/traffic_latest.json was measured on other kernel sources / another fixture: omitted "
+                                    "(its figure: %s bytes per call)" % tj.get("vocab_lse_hbm_bytes_per_call"))
             ex = v["tflops"] / m.flops_per_row_vocab * exec_per_row_vocab if split else v["tflops"]
             roofline = {"kernel": kname, "bound": "mfma", "achieved": round(v["tflops"], 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(v["tflops"] / peak, 4),
                         "frac_of_dense_f16": round(ex / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
+                        "frac_of_dense_f16_algorithmic": round(v["tflops"] / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
                         "executed_tflops": round(ex, 1),
                         "traffic": traffic, "traffic_source": traffic_note,
                         "avg_launch_ms": round(v["avg_ms"], 4), "launches": v["launches"],
@@ -213,10 +242,10 @@ def main():
             if not full_vocab:
                 # the vocabulary-selected / per-frame-deduplicated decoders run this kernel over a sub-problem whose size is
                 # decided on the device each frame: the full-vocabulary flop count does not apply, so nothing is priced
-                for k in ("achieved", "frac", "frac_of_dense_f16", "executed_tflops", "flops_per_launch", "traffic"):
+                for k in ("achieved", "frac", "frac_of_dense_f16", "frac_of_dense_f16_algorithmic", "executed_tflops", "flops_per_launch", "traffic"):
                     roofline[k] = None
                 roofline["note"] = ("decoder=%s works on a per-frame selected sub-problem (rows x columns decided on the device): "
-                                    "only the launch time is reported; the roofline is quoted on decoder=static" % args.decoder)
+                                    "only the launch time is reported; the roofline is quoted on decoder=static" % decoder_name)
         g = kernel_stats(durs, rows, "gate_gemm", 2.0 * H * 4 * H * (SPLIT_PASSES if gsplit else 1))
         gate_obj = None
         if g:
@@ -268,30 +297,51 @@ def main():
         elif args.decoder == "dynamic":
             ekind, ekw = "dynamic", dict(dyn_lists=lat.dynamic_vocab()[:4])
 
-        def run_device_steps(n):
-            """n steps with the lattice resident; the host read-out of step i overlaps the GPU work of step i+1."""
-            inflight = deque()                 # two steps in flight, as Decoder.decode_batch keeps its chunks
-            for _ in range(n):
-                inflight.append(eng.submit(lat, ekind, topN=10, **ekw))
-                if len(inflight) > dec.pipeline_depth:
-                    eng.collect(inflight.popleft())
-            while inflight:
-                eng.collect(inflight.popleft())
+        def run_device_steps(n, timing=False, sink=None):
+            """n steps with the lattice resident; the host read-out of step i overlaps the GPU work of step i+1.
+            timing="inflight": HIP events around the kernel groups on each batch's own stream (sink collects them)."""
+            inflight = deque()                 # pipeline_depth steps in flight, as Decoder.decode_batch keeps its chunks
+            eng.pipelined = True
+
+            def fin(t):
+                eng.collect(t)
+                if sink is not None:
+                    sink["n_live"].append(eng.last_n_live)
+                    for k in ("gate_gemm", "vocab_lse"):
+                        sink[k].extend(eng.last_kernel_ms[k])
+            try:
+                for _ in range(n):
+                    inflight.append(eng.submit(lat, ekind, topN=10, timing=timing, **ekw))
+                    if len(inflight) > dec.pipeline_depth:
+                        fin(inflight.popleft())
+                while inflight:
+                    fin(inflight.popleft())
+            finally:
+                eng.pipelined = False
 
         # untimed: the requested warm-up steps (plans for every stream and pipeline slot exist afterwards), then two settle calls
         # of the timed call's own size: a fresh process runs its first K-batch call 20-25 % slower than the third
         # (tools/probes/idle_probe.py: 2.96 / 2.52 / 2.39 ms per batch -- the Python heap and the lattice buffers of a call of
         # that size are faulted in for the first time; an idle second does not bring it back).  The rate reported is the
         # steady state of a running service, as for any warm-up.
+        settle = max(args.steps, 12 - args.warmup, 4)
         if args.warmup:
             dec.decode_batch(sents * args.warmup, beam_width=args.beam, **dkw)
         for _ in range(2):
-            dec.decode_batch(sents * max(args.steps, 12 - args.warmup, 4), beam_width=args.beam, **dkw)
+            dec.decode_batch(sents * settle, beam_width=args.beam, **dkw)
+        line_extra["untimed_steps"] = args.warmup + 2 * settle
+        line_extra["untimed_steps_note"] = ("everything run before the clock starts: --warmup steps + two settle calls of max(steps, "
+                                            "12 - warmup, 4) steps each (first-touch of the heap and buffers a call of that size needs)")
         barrier()
+        c0 = time.process_time()
         t0 = time.perf_counter()
         out = dec.decode_batch(sents * args.steps, beam_width=args.beam, **dkw)      # K steps = K pipelined 256-sentence batches
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        cpu_s = time.process_time() - c0
+        line_extra["host_cpu_ms_per_step"] = round(cpu_s / args.steps * 1e3, 3)
+        line_extra["host_cpu_note"] = ("process CPU time (all threads of this rank: calling thread, lattice workers, HIP runtime) per "
+                                       "step of the timed region; %.2f CPUs busy on average, %d usable" % (cpu_s / dt, jlm_amd.usable_cpus()))
         assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
         del out        # ~300 k list objects: kept alive they make every later full garbage collection (the loops below) slower
         total_chars_per_step = sum_over_ranks(float(chars_per_step))
@@ -309,6 +359,26 @@ def main():
         line_extra["device_resident_note"] = ("same K steps with the batch's lattice (CSR) already resident in HBM: launch sequence "
                                               "+ n-best traces back on the host, no lattice build / upload / string read-out")
         roofline, gate_obj = measure_kernels(dec, lat, ekind, ekw, min(args.steps, 20), full_vocab=(args.decoder == "static"))
+        # the same kernels inside the pipelined loop (three batches in flight): events on each batch's own stream
+        if roofline and args.decoder == "static" and eng.n_streams >= 2:
+            sink = {"n_live": [], "gate_gemm": [], "vocab_lse": []}
+            eng.keep_n_live = True
+            run_device_steps(3, timing="inflight")
+            run_device_steps(min(args.steps, 20), timing="inflight", sink=sink)
+            eng.keep_n_live = False
+            rows_p = np.concatenate([np.asarray(x[:-1], dtype=np.float64) for x in sink["n_live"]])
+            m_ = dec.model.dev
+            vp = kernel_stats(sink, rows_p, "vocab_lse", m_.flops_per_row_vocab / (1 if m_.stationary_ok else m_.n_segs))
+            gp = kernel_stats(sink, rows_p, "gate_gemm", 2.0 * m_.H * 4 * m_.H * (SPLIT_PASSES if getattr(m_, "split_lstm", False) else 1))
+            if vp:
+                roofline["frac_in_pipeline"] = round(vp["tflops"] / roofline["peak"], 4)
+                roofline["avg_launch_ms_in_pipeline"] = round(vp["avg_ms"], 4)
+                roofline["in_pipeline_note"] = ("the same launches timed inside the pipelined loop (%d batches in flight, the kernel on "
+                                                "%d%% of the CUs beside the other batches' kernels): events on each batch's own stream"
+                                                % (dec.pipeline_depth, eng.lse_share_pct or 100))
+            if gp and gate_obj:
+                gate_obj["mfma_util_pct_in_pipeline"] = round(100.0 * gp["tflops"] / gate_obj["peak"], 2)
+                gate_obj["avg_launch_ms_in_pipeline"] = round(gp["avg_ms"], 4)
         # diagnostic: does this box overlap the batches in flight?  The same pipelined loop with one stream and with the
         # engine's own (on some boxes the two are equal: the queues of the streams are not run side by side there).
         if eng.n_streams >= 2:
@@ -347,6 +417,43 @@ def main():
                 "note": "`python bench.py --gpus N --config 5` makes this leg the headline line"}
             del dec5
             jconfig.set_root(root)
+
+        # ---------------------------------------------- short legs: BASELINE configs[2] and configs[3] (one GPU, this process)
+        if not args.no_legs and args.decoder == "static" and world == 1:
+            def run_leg(fixture, kind, batch, beam, steps, kw, what):
+                root_, _cfg, alphabet_, dec_ = make_decoder(fixture, kind)
+                sents_ = synth.make_sentences(batch, args.length, seed=3131, alphabet=alphabet_)
+                dec_.max_batch = batch
+                for _ in range(2):                                                           # untimed: plans, streams, first touch
+                    dec_.decode_batch(sents_ * steps, beam_width=beam, **kw)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                out_ = dec_.decode_batch(sents_ * steps, beam_width=beam, **kw)
+                torch.cuda.synchronize()
+                dta = time.perf_counter() - ta
+                assert len(out_) == batch * steps and all(len(r) > 0 for r in out_)
+                del out_
+                lat_ = BatchLattice(dec_._builder, sents_, beam)
+                ekind_, ekw_ = ("dynamic", dict(dyn_lists=lat_.dynamic_vocab()[:4])) if kind == "dynamic" else ("static", {})
+                rf, gt = measure_kernels(dec_, lat_, ekind_, ekw_, 2, full_vocab=(kind == "static"), fixture=fixture, decoder_name=kind)
+                leg = {"workload": what, "value": round(sum(len(x) for x in sents_) * steps / dta, 1), "unit": "chars/s", "n_gpus": 1,
+                       "steps": steps, "untimed_steps": 2 * steps, "ms_per_step": round(dta / steps * 1e3, 3),
+                       "timed": "strings -> strings, one decode_batch call of `steps` pipelined batches"}
+                if rf:
+                    leg["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "frac", "achieved", "peak", "unit", "frac_of_dense_f16",
+                                                                     "avg_launch_ms", "note") if rf.get(k) is not None}
+                if gt:
+                    leg["gate_gemm"] = {k: gt[k] for k in ("mfma_util_pct", "avg_launch_ms")}
+                del dec_, lat_
+                jconfig.set_root(root)
+                return leg
+            line_extra["config3"] = run_leg(
+                "big-tied", "static", 1024, 20, 3, {},
+                "BASELINE configs[2]: tied softmax V=100k (h=512, e=256), beam=20, batch=1024 sentences x %d kana" % args.length)
+            line_extra["config4"] = run_leg(
+                "mid-tied", "dynamic", 256, args.beam, 10, dict(vocab_select=True),
+                "BASELINE configs[3]: DynamicDecoder (decoder_dynamic.py incremental vocabulary selection), tied softmax V=50k, "
+                "beam=%d, batch=256 sentences x %d kana" % (args.beam, args.length))
 
     if rank != 0:
         if dist is not None:
@@ -405,4 +512,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -110,8 +110,10 @@ class Decoder():
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20
         # batches (tools/probes/stall_probe.py).  Park them in the permanent generation.
-        gc.collect()
-        gc.freeze()
+        # Process-wide side effect, opt-out: JLM_NO_GC_FREEZE=1 (INTEGRATION.md "process-global knobs").
+        if os.environ.get("JLM_NO_GC_FREEZE", "0") != "1":
+            gc.collect()
+            gc.freeze()
 
     def _load_vocab(self):
         self.vocab = Vocab(self.config['vocab_size'])
@@ -226,11 +228,15 @@ class Decoder():
         # young collections per chunk and, as the result list grows, full collections over everything decoded so far (4.0 vs
         # 2.9 ms per chunk at 200 vs 40 chunks per call).  Nothing allocated in here can form a cycle: collection is paused.
         gc_was_on = gc.isenabled()
-        gc.disable()
+        pause_gc = gc_was_on and os.environ.get("JLM_NO_GC_PAUSE", "0") != "1"
+        if pause_gc:
+            gc.disable()
+        self._engine.pipelined = n_chunks > 1          # more than one batch in flight: the vocabulary kernel leaves CUs to the others
         try:
             self._run_pipeline_nogc(prepared, n_chunks, submit, finish)
         finally:
-            if gc_was_on:
+            self._engine.pipelined = False
+            if pause_gc:
                 gc.enable()
 
     def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish):

@@ -184,6 +184,7 @@ class DecodeEngine:
         self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
+        self.pipelined = False          # set by the caller around a pipelined sequence of submits (Decoder.decode_batch)
 
     def _ctx(self):
         return self.m._ctx()
@@ -221,10 +222,12 @@ class DecodeEngine:
         """Enqueue one batch (upload, the frame-loop op, asynchronous read-back) and return a
         ticket for :meth:`collect`.  Nothing here waits for the GPU.  Successive calls use
         alternating streams (see __init__); every ticket owns its plan's buffers until collected.
-        timing=True: HIP events around the kernel groups of every frame (one stream, no side stream)."""
+        timing=True: HIP events around the kernel groups of every frame (one stream, no side stream);
+        timing="inflight": the same events recorded on the batch's own stream of the PIPELINED submit -- a kernel's time
+        then includes what it loses to the other batches in flight (bench.py: `frac_in_pipeline`)."""
         torch = self.torch
         with self._ctx():
-            if self.device.type != "cuda" or self.n_streams < 2 or timing:
+            if self.device.type != "cuda" or self.n_streams < 2 or (timing and timing != "inflight"):
                 return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
             if len(self._streams) != self.n_streams:
                 # the launch streams are shared by every engine on the device: each also gets a side stream inside the op, and
@@ -263,6 +266,21 @@ class DecodeEngine:
         perm = dynamic and len(dyn_lists) >= 6 and dyn_lists[4] is not None
         p = self._plan_for(kind, vmode, lat, need, size_class, perm)
         p.busy = True
+        try:
+            done = self._enqueue(p, lat, vocab, dyn_lists, dynamic, perm, max_words, topN, timing)
+        except BaseException:
+            # nothing may keep the plan: launches already enqueued finish first, then its buffers are free again
+            if self.device.type == "cuda":
+                try:
+                    torch.cuda.current_stream(self.device).synchronize()
+                except Exception:
+                    pass
+            p.busy = False
+            raise
+        return (p, lat, topN, timing, done)
+
+    def _enqueue(self, p, lat, vocab, dyn_lists, dynamic, perm, max_words, topN, timing):
+        torch = self.torch
         assert lat.n_frames <= p.F
         p._set("sent_len", lat.sent_len)
         p._set("end_off", lat.end_off)
@@ -293,7 +311,10 @@ class DecodeEngine:
         # the whole launch sequence of the batch: ONE op, no host synchronisation inside (csrc/jlm_decode.hip)
         # another batch in flight: this batch's vocabulary kernel takes LSE_SHARE_PCT of the CUs and the other batch's
         # latency-bound kernels the rest, side by side (include/jlm_hip.h, jlm_decode_plan.lse_cu_share_pct)
-        share = self.lse_share_pct if (not timing and any(q.busy and q is not p for q in self.plans)) else 0
+        # The share is a property of the CALL (a pipelined sequence of batches: decode_batch with more than one chunk sets
+        # `pipelined`), not of what happens to be in flight at this moment: the share moves the column cuts of the vocabulary
+        # kernel, i.e. the grouping of its f32 partial sums, and a sentence's score must not depend on its chunk's position.
+        share = self.lse_share_pct if ((not timing or timing == "inflight") and self.pipelined) else 0
         rc = ops.backend().decode_frames(self.m.decode_model(), p.obj, lat.n_frames, max_words["vs"], max_words["di"],
                                          max_words["dd"], bool(side), bool(timing), int(share))
         if rc != 0:
@@ -309,7 +330,8 @@ class DecodeEngine:
             # (measured: no less CPU per step -- the runtime's own threads spin either way -- and 1-3 % more wall time: off)
             done = torch.cuda.Event(blocking=self.blocking_sync)
             done.record()
-        return (p, lat, topN, timing, done)
+        return done
+
 
     def collect(self, ticket):
         """Wait for a submitted batch and build its n-best lists."""
