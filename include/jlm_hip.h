@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 5
+#define JLM_ABI_VERSION 6
+#define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
 int jlm_device_arch(int dev, char *buf, int buflen);
@@ -327,9 +328,17 @@ typedef struct {
  * Ties keep candidate generation order (node order, then beam slot).  Rows of
  * a sentence's last frame are not listed in `live`: the reference steps them
  * too but never reads the result (decoder.py:233-237).
- * max_cands >= beam * (largest number of nodes ending at one (frame, sentence)). */
+ * max_cands >= beam * (largest number of nodes ending at one (frame, sentence)).
+ * 1 <= beam <= JLM_MAX_BEAM (the reference has no limit, decoder.py:227-229); a cell's candidates live in one wave's
+ * LDS: -1 when max_cands exceeds jlm_beam_step_max_cands(beam, n_frames, mode). */
 int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
                   int frame, int mode, int max_cands, void *stream);
+
+/* ABI 6: the largest max_cands (a multiple of 256, as the plans round it) jlm_beam_step accepts for this beam,
+ * frame count and mode -- the launcher's own LDS formula, so that callers can route sentences with a larger lattice
+ * cell to a host-side search (Decoder._decode_unpruned / DynamicDecoder._decode_host) instead of failing the batch.
+ * 0: no cell fits (beam or frame count too large).  Pure host function, no GPU needed. */
+int jlm_beam_step_max_cands(int beam, int n_frames, int mode);
 
 /* K10: n-best read-out.  For sentence s and rank r < cnt at its last frame:
  * out_nodes[(s*beam+r)*stride + d] = node ids from the LAST word back to the

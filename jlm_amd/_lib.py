@@ -90,6 +90,7 @@ _SIGS = {
     "jlm_wordlist_merge_split": ([POINTER(Segment), c_float, c_float, P, P, c_int, P, c_int, c_int, c_int, P, P, c_int, c_int,
                                  P, P, P, P], c_int),
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
+    "jlm_beam_step_max_cands": ([c_int, c_int, c_int], c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
     "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P, P], c_int),
@@ -120,7 +121,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 5:
+        if l.jlm_abi_version() != 6:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -32,15 +32,17 @@ __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
     const int w0 = wl_off[lid], nw = wl_off[lid + 1] - w0;
     if (MODE == 0 && nw == 0) return;
     const int tid = threadIdx.x;
-    {   // stage T[gbase .. gbase+nrows) (rows are consecutive in g)
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(T + (size_t)gbase * ldt);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(sm);
-        for (int i = tid; i < nrows * (ldt / 4); i += WL_THREADS) dst[i] = src[i];
-    }
-    __syncthreads();
-    float *red = sm + (size_t)beam * ldt;            // [4 waves][WL_ROWS][2] reduction scratch
+    float *red = sm + (size_t)WL_ROWS * ldt;         // [4 waves][WL_ROWS][2] reduction scratch
     const int sub = tid & 7, slot = tid >> 3;
     for (int rc = 0; rc < nrows; rc += WL_ROWS) {
+        {   // stage this pass's rows T[gbase + rc .. + WL_ROWS) (consecutive in g): LDS is WL_ROWS rows whatever the beam
+            if (rc) __syncthreads();
+            const int nr = min(WL_ROWS, nrows - rc);
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(T + (size_t)(gbase + rc) * ldt);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(sm);
+            for (int i = tid; i < nr * (ldt / 4); i += WL_THREADS) dst[i] = src[i];
+            __syncthreads();
+        }
         float rm[WL_ROWS], rs[WL_ROWS];
 #pragma unroll
         for (int r = 0; r < WL_ROWS; ++r) { rm[r] = JLM_NEG_BIG; rs[r] = 0.0f; }
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
 #pragma unroll
                 for (int r = 0; r < WL_ROWS; ++r) {
                     if (rc + r < nrows) {
-                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)(rc + r) * ldt + toff + kc * 4);
+                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)r * ldt + toff + kc * 4);
                         acc[r] = fmaf(bv[c8][0], tv[0], acc[r]);
                         acc[r] = fmaf(bv[c8][1], tv[1], acc[r]);
                         acc[r] = fmaf(bv[c8][2], tv[2], acc[r]);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(WL_THREADS) void wordlist_kernel(
 #pragma unroll
                 for (int r = 0; r < WL_ROWS; ++r) {
                     if (rc + r < nrows) {
-                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)(rc + r) * ldt + toff + kc * 4);
+                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(sm + (size_t)r * ldt + toff + kc * 4);
                         acc[r] = fmaf(bw[0], tv[0], acc[r]);
                         acc[r] = fmaf(bw[1], tv[1], acc[r]);
                         acc[r] = fmaf(bw[2], tv[2], acc[r]);
@@ -171,7 +173,7 @@ static int seg_table(const jlm_segment *segs_host, int n_segs, SegTable &t) {
     return 0;
 }
 
-static size_t wl_lds_bytes(int beam, int ldt) { return ((size_t)beam * ldt + 4 * WL_ROWS * 2) * sizeof(float); }
+static size_t wl_lds_bytes(int /*beam*/, int ldt) { return ((size_t)WL_ROWS * ldt + 4 * WL_ROWS * 2) * sizeof(float); }
 
 extern "C" int jlm_edge_logits(const jlm_segment *segs_host, int n_segs, const float *b2, const float *T, int ldt,
                                const int *g0, const int *cnt, const int *cnt_idx, const int *wl, const int *wl_off,
@@ -295,7 +297,7 @@ __device__ __forceinline__ void wave_argmin(double &v, int &i) {
 
 template <int MODE>
 __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam_state st, int frame, int max_cands) {
-    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] | MODE 2: [n_frames*beam] | int [max_cands] | [beam] | int [n_frames]
+    extern __shared__ __attribute__((aligned(16))) double keys[];   // [max_cands] | MODE 2: [n_frames*beam] | int [max_cands] | [beam] | int [n_frames] | winners: [beam] double, [beam] int
     const int s = blockIdx.x, lane = threadIdx.x;
     const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
     const int len = lat.sent_len[s];
@@ -308,12 +310,12 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
     int *gp_of = reinterpret_cast<int *>(Sarr + (MODE == 2 ? lat.n_frames * beam : 0));
     double *lse_new = reinterpret_cast<double *>(gp_of + ((max_cands + 1) & ~1));   // [beam]
     int *cnt_s = reinterpret_cast<int *>(lse_new + beam);                           // [n_frames] this sentence's counts
+    // the winners of the selection rounds, in rank order (beams above 64: a lane writes out several of them at the end)
+    double *win_v = reinterpret_cast<double *>(cnt_s + ((lat.n_frames + 1) & ~1));  // [beam]
+    int *win_i = reinterpret_cast<int *>(win_v + beam);                             // [beam]
     int K;
-    double win_v = 0.0;
-    int win_i = 0;
     if (frame == 0) {
         K = 1;
-        if (lane == 0) { win_v = 0.0; win_i = -1; }
     } else {
         // ---- fused fold of the previous frame's vocabulary partials (this sentence's rows)
         const bool fused = MODE == 0 && st.lse_part != nullptr;
@@ -356,15 +358,15 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
             // re-scored from the head (decoder_dynamic.py:150-175), frame by frame.
             for (int f = 0; f < frame; ++f) {
                 const int c = st.cnt[f * B + s];
-                if (lane < c) {
-                    const int g = f * rmax + s * beam + lane;
+                for (int l = lane; l < c; l += 64) {
+                    const int g = f * rmax + s * beam + l;
                     const int p = st.bp[g];
                     double S = 0.0;
                     if (p >= 0) {
                         const int pf = p / rmax, pk = p - pf * rmax - s * beam;
                         S = Sarr[pf * beam + pk] + st.lse[p];
                     }
-                    Sarr[f * beam + lane] = S;
+                    Sarr[f * beam + l] = S;
                 }
                 __syncthreads();
             }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
             double v = bv;
             int i = bi;
             wave_argmin(v, i);
-            if (lane == r) { win_v = v; win_i = i; }
+            if (lane == 0) { win_v[r] = v; win_i[r] = i; }
             if ((i & 63) == lane) {                        // the owner strikes the winner and rescans its own entries
                 const int jw = i >> 6;
                 if (jw >= NREG) keys[i] = INF;
@@ -450,11 +452,11 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
                 }
             }
         }
-        __syncthreads();                                   // gp_of of other lanes' candidates
+        __syncthreads();                                   // gp_of of other lanes' candidates, the winners
     }
-    // ---- the K surviving hypotheses, one lane each
-    if (lane < K) {
-        const int g = gout + lane;
+    // ---- the K surviving hypotheses, one lane each (beams above 64: lane l takes ranks l, l + 64, ...)
+    for (int r = lane; r < K; r += 64) {
+        const int g = gout + r;
         if (frame == 0) {
             st.score[g] = 0.0;
             if (st.ysum) st.ysum[g] = 0.0;
@@ -462,9 +464,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
             st.node[g] = nb;
             st.word[g] = lat.node_word[nb];
         } else {
-            const int n = nb + win_i / beam, k = win_i % beam;
-            const int gp = gp_of[win_i];
-            st.score[g] = win_v;
+            const int wi = win_i[r];
+            const int n = nb + wi / beam, k = wi % beam;
+            const int gp = gp_of[wi];
+            st.score[g] = win_v[r];
             if (MODE == 2) st.ysum[g] = st.ysum[gp] + (double)st.edge[(size_t)n * beam + k];
             st.bp[g] = gp;
             st.node[g] = n;
@@ -480,7 +483,29 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
         }
     }
     base = __shfl(base, 0);
-    if (frame < len && lane < K) st.live[(size_t)frame * rmax + base + lane] = gout + lane;
+    if (frame < len)
+        for (int r = lane; r < K; r += 64) st.live[(size_t)frame * rmax + base + r] = gout + r;
+}
+
+// LDS of one sentence's wave: keys [max_cands] f64 | mode 2: S [n_frames x beam] f64 | predecessor rows [max_cands] i32 |
+// folded log-normalisers [beam] f64 | the sentence's counts [n_frames] i32 | winners [beam] f64 + [beam] i32
+static size_t beam_step_lds_bytes(int beam, int n_frames, int mode, int max_cands) {
+    return (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)n_frames * beam * sizeof(double) : 0) +
+           (size_t)((max_cands + 1) & ~1) * sizeof(int) + (size_t)beam * sizeof(double) + (size_t)((n_frames + 1) & ~1) * sizeof(int) +
+           (size_t)beam * (sizeof(double) + sizeof(int)) + 8;
+}
+
+// Largest max_cands (candidates of one (frame, sentence) cell = nodes ending there x beam, as the plans round it: a
+// multiple of 256) that jlm_beam_step accepts for this beam / frame count / mode; 0: none.  Callers route sentences with a
+// larger cell to their host-side search instead of failing the batch (jlm_amd/decoder.py, decoder_dynamic.py).
+extern "C" int jlm_beam_step_max_cands(int beam, int n_frames, int mode) {
+    if (beam < 1 || beam > JLM_MAX_BEAM || n_frames < 1 || mode < 0 || mode > 2) return 0;
+    const size_t fixed = beam_step_lds_bytes(beam, n_frames, mode, 0);
+    if (fixed + 256 * 12 > 160 * 1024) return 0;
+    size_t c = (160 * 1024 - fixed) / 12;
+    c = c / 256 * 256;
+    while (c > 0 && beam_step_lds_bytes(beam, n_frames, mode, (int)c) > 160 * 1024) c -= 256;
+    return (int)c;
 }
 
 extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int frame, int mode,
@@ -490,12 +515,10 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     if (lat.n_sent <= 0) return 0;
     if (mode == 2 && !st.ysum) return -1;
     if (mode < 0 || mode > 2) return -1;
-    if (lat.beam < 1 || lat.beam > 64) return -1;      // one lane of the sentence's wave per surviving hypothesis
+    if (lat.beam < 1 || lat.beam > JLM_MAX_BEAM) return -1;
     if (st.lse_part && (!st.live_base || st.n_parts < 1 || mode != 0)) return -1;
     if (max_cands < 1) max_cands = 1;
-    size_t lds = (size_t)max_cands * sizeof(double) + (mode == 2 ? (size_t)lat.n_frames * lat.beam * sizeof(double) : 0) +
-                 (size_t)((max_cands + 1) & ~1) * sizeof(int) + (size_t)lat.beam * sizeof(double) +
-                 (size_t)lat.n_frames * sizeof(int);
+    const size_t lds = beam_step_lds_bytes(lat.beam, lat.n_frames, mode, max_cands);
     if (lds > 160 * 1024) return -1;
     const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
                    : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;

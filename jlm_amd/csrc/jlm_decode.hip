@@ -159,6 +159,8 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 int n_parts = 0;
                 for (int i = 0; i < m->n_segs; ++i) {
                     const jlm_segment &sg = m->segs[i];
+                    // capacity is checked BEFORE the launch that would write the slices (one per 128-word tile)
+                    if (n_parts + (sg.v_end - sg.v_start + 127) / 128 > p->max_parts) return -1;
                     int r = (m->untied && m->untied_split && m->split_lstm)
                                 ? jlm_vocab_lse_partials_split(m->untied_split, m->H, sg.v_end - sg.v_start, m->H, p->h, m->H, rows,
                                                                m->b2 + sg.v_start, m->untied_descale, p->part, rmax, n_parts,

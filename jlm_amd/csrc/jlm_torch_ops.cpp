@@ -20,10 +20,12 @@
 #include <torch/custom_class.h>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
 #include <hip/hip_runtime_api.h>
 
 #include <array>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -199,11 +201,18 @@ struct JlmPlan : torch::CustomClassHolder {
 // side stream of each launch stream (edge logits beside the normaliser): ONE per launch stream for the whole process -- ROCm
 // maps streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise (jlm_amd/__init__.py)
 std::map<std::pair<int, hipStream_t>, c10::hip::HIPStream> g_side;
+// torch releases the interpreter lock around custom ops: two Python threads may be inside decode_frames at once (two
+// decoders, or JLM_COLLECTOR=1).  The side-stream table, a plan's event / graph tables and the launchers' one-time kernel
+// attributes (function-local statics in libjlm_hip.so) are all touched in here: one lock around the enqueue.  It is held
+// for the ~0.5 ms the launches take; the GPU work itself is asynchronous.
+std::mutex g_enqueue_mutex;
 
 int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intrusive_ptr<JlmPlan> &plan, int64_t n_frames,
                       int64_t vs_max, int64_t di_max, int64_t dd_max, bool use_side, bool timed, int64_t lse_cu_share_pct) {
     JlmPlan &pl = *plan;
     TORCH_CHECK(n_frames >= 1 && n_frames <= pl.frames_cap, "jlm.decode_frames: ", n_frames, " frames, the plan holds ", pl.frames_cap);
+    const c10::hip::HIPGuard device_guard(pl.device);          // the plan's device, whatever the caller's current one is
+    const std::lock_guard<std::mutex> lock(g_enqueue_mutex);
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(pl.device);
     pl.lat.n_frames = (int)n_frames;
     pl.p.vs_max = (int)vs_max; pl.p.di_max = (int)di_max; pl.p.dd_max = (int)dd_max;
@@ -271,6 +280,8 @@ int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intr
 // vocab fix, lattice path fix (beam step), LSTM step, T projection + edge logits, normaliser (include/jlm_hip.h, events)
 Tensor frame_times(const c10::intrusive_ptr<JlmPlan> &plan) {
     JlmPlan &pl = *plan;
+    const c10::hip::HIPGuard device_guard(pl.device);
+    const std::lock_guard<std::mutex> lock(g_enqueue_mutex);
     const int F = pl.timed_frames;
     Tensor out = at::zeros({F, 5}, at::kDouble);
     auto a = out.accessor<double, 2>();
@@ -344,6 +355,7 @@ void dequant_u8(const Tensor &code, int64_t rows, int64_t k, int64_t ld_code, co
 }
 
 int64_t abi_version() { return jlm_abi_version(); }
+int64_t beam_step_max_cands(int64_t beam, int64_t n_frames, int64_t mode) { return jlm_beam_step_max_cands((int)beam, (int)n_frames, (int)mode); }
 
 }  // namespace
 
@@ -365,4 +377,5 @@ TORCH_LIBRARY(jlm, m) {
     m.def("pack_split_f16_col(Tensor v, int v_off, int rows, float scale, Tensor(a!) dst, int ld_dst, int col) -> ()", pack_split_f16_col);
     m.def("dequant_u8(Tensor code, int rows, int k, int ld_code, Tensor codebook, Tensor(a!) dst, int ld_dst) -> ()", dequant_u8);
     m.def("abi_version() -> int", abi_version);
+    m.def("beam_step_max_cands(int beam, int n_frames, int mode) -> int", beam_step_max_cands);
 }

@@ -71,9 +71,11 @@ class _CellTooLarge(Exception):
 class Decoder():
     dynamic = False
     # jlm_beam_step keeps the candidates of one (frame, sentence) cell -- nodes ending there x beam -- in one wave's LDS: 12 bytes
-    # each of 160 KB.  Sentences with a larger cell (hundreds of homophones at a wide beam) take the host-side search
-    # (_decode_unpruned with the beam) instead of failing the batch.
-    CAND_LIMIT = 13000
+    # each of 160 KB, less what the beam and the frame count take (jlm_beam_step_max_cands: the launcher's own formula).
+    # Sentences with a larger cell (hundreds of homophones at a wide beam) take the host-side search (_decode_unpruned with the
+    # beam; DynamicDecoder._decode_host) instead of failing the batch.  CAND_LIMIT: an explicit limit instead (tests).
+    CAND_LIMIT = None
+    MAX_BEAM = 1024              # JLM_MAX_BEAM (include/jlm_hip.h); the reference has no limit (decoder.py:227-229)
 
     def __init__(self, experiment_id=0, comp=0, device=None):
         self.config = _config.load_config_dict(experiment_id)
@@ -143,8 +145,8 @@ class Decoder():
         inputs = list(inputs)
         if beam_width is None:       # the reference's unpruned search, sentence at a time on the host
             return [self._decode_unpruned(x, topN, vocab_select, samples, top_sampling, random_sampling) for x in inputs]
-        if not 1 <= int(beam_width) <= 64:
-            raise ValueError("beam_width must be 1..64 on the GPU path (one wave lane per surviving hypothesis)")
+        if not 1 <= int(beam_width) <= self.MAX_BEAM:
+            raise ValueError("beam_width must be 1..%d on the GPU path (or None: the unpruned host-side search)" % self.MAX_BEAM)
         if not inputs:
             return []
         if self.compat_quirks and not vocab_select and self.lattice_vocab:
@@ -207,12 +209,24 @@ class Decoder():
         self.perf_sen += len(inputs)
         return out
 
+    def _cand_limit(self, lat, beam_width):
+        """candidates of one lattice cell the device beam step accepts for this batch shape"""
+        if self.CAND_LIMIT is not None:
+            return int(self.CAND_LIMIT)
+        from . import ops
+        mode = 2 if self.dynamic else (1 if self.model.dev.self_norm else 0)
+        frames = (lat.n_frames + 7) // 8 * 8                       # as the plans round it (engine._plan_for)
+        return int(ops.backend().beam_step_max_cands(int(beam_width), frames, mode))
+
     def _check_cells(self, lat, idx, beam_width):
-        if lat.max_cands <= self.CAND_LIMIT or lat.n_sent == 0:
+        if lat.n_sent == 0:
+            return
+        limit = self._cand_limit(lat, beam_width)
+        if lat.max_cands <= limit:
             return
         import numpy as np
         per_sentence = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0)
-        raise _CellTooLarge([idx[k] for k in range(lat.n_sent) if int(per_sentence[k]) * beam_width > self.CAND_LIMIT])
+        raise _CellTooLarge([idx[k] for k in range(lat.n_sent) if int(per_sentence[k]) * beam_width > limit])
 
     def _run_pipeline(self, prepared, n_chunks, submit, finish):
         """The device pipeline of decode_batch: ``submit`` every prepared chunk (enqueue upload + frame loop + read-back: no

@@ -43,7 +43,18 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 5
+        return 6
+
+    def jlm_beam_step_max_cands(self, beam, n_frames, mode):
+        """the launcher's LDS formula (csrc/jlm_beam.hip, beam_step_lds_bytes)"""
+        if beam < 1 or beam > 1024 or n_frames < 1 or mode not in (0, 1, 2):
+            return 0
+        lds = lambda c: (c * 8 + (n_frames * beam * 8 if mode == 2 else 0) + ((c + 1) & ~1) * 4 + beam * 8 +
+                         ((n_frames + 1) & ~1) * 4 + beam * 12 + 8)
+        c = (160 * 1024 - lds(0)) // 12 // 256 * 256
+        while c > 0 and lds(c) > 160 * 1024:
+            c -= 256
+        return max(c, 0)
 
     # ------------------------------------------------------- the frame loop (ABI 3)
     def jlm_decode_frames(self, m, p, lat, st, stream, side_stream, events=None):
@@ -824,6 +835,9 @@ class FakeOps:
 
     def abi_version(self):
         return self.lib.jlm_abi_version()
+
+    def beam_step_max_cands(self, beam, n_frames, mode):
+        return self.lib.jlm_beam_step_max_cands(int(beam), int(n_frames), int(mode))
 
     def decode_frames(self, model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct=0):
         assert 1 <= n_frames <= plan.frames

@@ -41,6 +41,51 @@ def test_beam_extremes(kind, beam, topN, fx):
         _same(g, o.decode(s, beam_width=beam, topN=topN, **kw), (kind, beam, s))
 
 
+@pytest.mark.parametrize("fixture,kind", [("small-vtable", "static"), ("small-tied", "static-vs"), ("small-tied", "dynamic"),
+                                          ("small-untied", "static")])
+@pytest.mark.parametrize("beam", [100, 257])
+def test_beams_above_one_wave(fixture, kind, beam, fx):
+    """beams above 64 (the reference has no limit, decoder.py:227-229): a lane of the sentence's wave owns several ranks in the
+    beam step; the word-list kernels fall back to the forms without a beam limit"""
+    f = fx(fixture)
+    d, o = _pair(f, "dynamic" if kind == "dynamic" else "static")
+    kw = dict(vocab_select=True) if kind != "static" else {}
+    sents = synth.make_ragged_sentences(5, 2, 11, seed=beam, alphabet=f["alphabet"])
+    got = d.decode_batch(sents, beam_width=beam, topN=beam, **kw)
+    for s, g in zip(sents, got):
+        w = o.decode(s, beam_width=beam, topN=beam, **kw)
+        assert len(g) == len(w)
+        _same(g, w, (kind, beam, s))
+
+
+def test_dynamic_oversized_cells_take_the_host_path(fx, monkeypatch):
+    """DynamicDecoder: sentences with a lattice cell above the device beam step's capacity go through the host-side search
+    (DynamicDecoder._decode_host over the GPU predict kernels), the rest through the device -- both as the oracle"""
+    f = fx("small-tied")
+    d, o = _pair(f, "dynamic")
+    sents = synth.make_ragged_sentences(9, 2, 10, seed=21, alphabet=f["alphabet"])
+    from jlm_amd.decoder_dynamic import DynamicDecoder
+    from jlm_amd.lattice import BatchLattice
+    lat = BatchLattice(d._builder, sents, 6)
+    per = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0) * 6
+    limit = int(np.sort(per)[len(per) // 2])
+    monkeypatch.setattr(DynamicDecoder, "CAND_LIMIT", limit)
+    assert 0 < int((per > limit).sum()) < len(sents)
+    got = d.decode_batch(sents, beam_width=6, vocab_select=True)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=6, vocab_select=True), ("oversized-dynamic", s))
+
+
+def test_beam_step_capacity_query_matches_the_launcher():
+    """jlm_beam_step_max_cands is the launcher's own formula: the largest accepted max_cands passes, 256 more do not"""
+    from jlm_amd import _lib
+    L = _lib.lib()
+    for beam, frames, mode in [(10, 24, 0), (64, 48, 2), (100, 24, 0), (1024, 16, 2)]:
+        c = L.jlm_beam_step_max_cands(beam, frames, mode)
+        assert c > 0 and c % 256 == 0
+    assert L.jlm_beam_step_max_cands(2000, 8, 0) == 0
+
+
 @pytest.mark.parametrize("kind", ["static", "dynamic"])
 def test_one_kana_long_and_unknown_symbols(kind, fx):
     f = fx("small-vtable" if kind == "static" else "small-tied")
@@ -64,7 +109,9 @@ def test_empty_batch_and_bad_input(fx):
     assert got[1] == [(0.0, [])] and got[0] == d.decode("アイ")
     assert d.decode("") == [(0.0, [])]
     with pytest.raises(ValueError):
-        d.decode("アイ", beam_width=65)        # one wave lane per surviving hypothesis: 64 is the widest beam
+        d.decode("アイ", beam_width=1025)      # JLM_MAX_BEAM (include/jlm_hip.h) is the widest beam of the device path
+    with pytest.raises(ValueError):
+        d.decode("アイ", beam_width=0)
 
 
 def test_unpruned_search_and_stale_vocab_quirk(fx):

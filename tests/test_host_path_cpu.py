@@ -105,7 +105,7 @@ def test_dynamic_requires_vocab_select(fx, fake):
     with pytest.raises(ValueError):
         dec.decode("アイウ", beam_width=None, vocab_select=True)
     with pytest.raises(ValueError):
-        dec.decode("アイウ", beam_width=65, vocab_select=True)
+        dec.decode("アイウ", beam_width=1025, vocab_select=True)
     with pytest.raises(ValueError):
         dec.decode("アイウ", beam_width=0, vocab_select=True)
 
@@ -254,8 +254,31 @@ def test_oversized_lattice_cells_take_the_host_path(fx, fake, monkeypatch):
     want_vs = dec.decode_batch(sents, beam_width=6, vocab_select=True)
     for g, w in zip(got_vs, want_vs):
         assert [x for _, x in g] == [x for _, x in w]
+    # the incremental decoder: the same routing, its own host-side search (DynamicDecoder._decode_host)
     from jlm_amd.decoder_dynamic import DynamicDecoder
     dyn = _decoder(f, "dynamic")
+    want_dyn = dyn.decode_batch(sents, beam_width=6, vocab_select=True)
     monkeypatch.setattr(DynamicDecoder, "CAND_LIMIT", limit)
-    with pytest.raises(ValueError):
-        dyn.decode_batch(sents, beam_width=6, vocab_select=True)
+    got_dyn = dyn.decode_batch(sents, beam_width=6, vocab_select=True)
+    for g, w in zip(got_dyn, want_dyn):
+        assert [x for _, x in g] == [x for _, x in w]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,kind,kw", [("small-tied", "static", {}), ("small-vtable", "static", {}),
+                                          ("small-tied", "static", dict(vocab_select=True)),
+                                          ("small-tied", "dynamic", dict(vocab_select=True))])
+def test_beams_above_one_wave(fx, fake, name, kind, kw):
+    """beam 100 (the reference has no limit, decoder.py:227-229): the beam step gives a lane several ranks; results as the
+    oracle's"""
+    from oracle import jlm_oracle as orc
+    f = fx(name)
+    dec = _decoder(f, kind)
+    o = (orc.OracleDynamicDecoder if kind == "dynamic" else orc.OracleDecoder)(f["root"], 1)
+    sents = synth.make_ragged_sentences(4, 3, 9, seed=77, alphabet=f["alphabet"])
+    got = dec.decode_batch(sents, beam_width=100, topN=100, **kw)
+    for s, g in zip(sents, got):
+        w = o.decode(s, beam_width=100, topN=100, **kw)
+        assert len(g) == len(w) and len(g) > 10
+        assert [x for _, x in g][0] == [x for _, x in w][0]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=1e-5)
