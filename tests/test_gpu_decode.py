@@ -36,11 +36,11 @@ TIE_REL = 1e-6        # two hypotheses whose reference scores are this close (re
 
 
 def _check_nbest(out, gold, tag):
-    """1-best identical, scores at 1e-5 relative / 1e-3 absolute, and the n-best ORDER identical -- except between
+    """1-best identical, scores within 2e-5 absolute (scores are ~100: 2e-7 relative; measured worst 1.7e-6) and the n-best ORDER identical -- except between
     hypotheses whose reference scores are within TIE_REL of each other (float32-derived path scores cannot order those)."""
     assert len(out) == len(gold), tag
     assert out[0][1] == gold[0][1], ("1-best differs", tag, out[0], gold[0])
-    np.testing.assert_allclose([s for s, _ in out], [s for s, _ in gold], rtol=1e-5, atol=1e-3, err_msg=str(tag))
+    np.testing.assert_allclose([s for s, _ in out], [s for s, _ in gold], rtol=0, atol=2e-5, err_msg=str(tag))
     if [w for _, w in out] == [w for _, w in gold]:
         return True
     gscore = {tuple(w): s for s, w in gold}

@@ -25,7 +25,7 @@ def _pair(f, kind):
 def _same(got, want, tag):
     assert len(got) == len(want), tag
     assert got[0][1] == want[0][1], (tag, got[0], want[0])
-    np.testing.assert_allclose([s for s, _ in got], [s for s, _ in want], rtol=1e-5, atol=1e-3, err_msg=str(tag))
+    np.testing.assert_allclose([s for s, _ in got], [s for s, _ in want], rtol=2e-6, atol=2e-5, err_msg=str(tag))
 
 
 @pytest.mark.parametrize("kind", ["static", "static-vs", "dynamic"])
