@@ -12,6 +12,8 @@ def _want_hw_queues(n=8):
     can only be defaulted here if that has not happened yet; the engine asks hw_queues_ok() and falls
     back to running the edge logits on the batch's own stream."""
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is None and os.environ.get("JLM_NO_ENV_DEFAULTS", "0") == "1":
+        return False          # the host process decides its own environment: nothing is written (INTEGRATION.md 4a)
     if cur is not None:
         try:
             return int(cur) >= n

@@ -16,6 +16,12 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+/* JLM_TRACK_RESULTS=1: leave the containers in the collector's lists (a host that links its own objects into the
+ * returned lists and relies on cycle collection through them). */
+static int jlm_untrack = -1;
+#define JLM_UNTRACK(o) do { if (jlm_untrack) PyObject_GC_UnTrack(o); } while (0)
 
 typedef struct { Py_buffer b; int ok; } Buf;
 
@@ -56,6 +62,7 @@ static PyObject *nbest(PyObject *self, PyObject *args) {
         const int32_t *pstart = (const int32_t *)start.b.buf;
         const double *ps = (const double *)score.b.buf;
         const int R = top < beam ? top : beam;
+        if (jlm_untrack < 0) { const char *e = getenv("JLM_TRACK_RESULTS"); jlm_untrack = !(e && e[0] == '1'); }
         eos = PyUnicode_FromString("<eos>");
         out = eos ? PyList_New(B) : NULL;
         if (!out) goto done;
@@ -65,14 +72,14 @@ static PyObject *nbest(PyObject *self, PyObject *args) {
             PyObject *lst = PyList_New(nr);
             if (!lst) goto fail;
             PyList_SET_ITEM(out, s, lst);
-            PyObject_GC_UnTrack(lst);
+            JLM_UNTRACK(lst);
             for (int r = 0; r < nr; ++r) {
                 const Py_ssize_t row = s * beam + r;
                 const int k = pl[row] - 1;             /* the trace ends at the root (<eos>), which is dropped */
                 if (k >= stride) { PyErr_SetString(PyExc_ValueError, "nbest: trace longer than stride"); goto fail; }
                 PyObject *words = PyList_New(k);
                 if (!words) goto fail;
-                PyObject_GC_UnTrack(words);
+                JLM_UNTRACK(words);
                 for (int j = 0; j < k; ++j) {          /* traces run from the last word back */
                     const int32_t id = pn[row * stride + (k - 1 - j)];
                     PyObject *w;
@@ -96,7 +103,7 @@ static PyObject *nbest(PyObject *self, PyObject *args) {
                 PyObject *sc = PyFloat_FromDouble(ps[row]);
                 PyObject *tup = sc ? PyTuple_New(2) : NULL;
                 if (!tup) { Py_XDECREF(sc); Py_DECREF(words); goto fail; }
-                PyObject_GC_UnTrack(tup);
+                JLM_UNTRACK(tup);
                 PyTuple_SET_ITEM(tup, 0, sc);
                 PyTuple_SET_ITEM(tup, 1, words);
                 PyList_SET_ITEM(lst, r, tup);

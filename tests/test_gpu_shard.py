@@ -88,3 +88,25 @@ def test_two_ranks_on_one_gpu_equal_one_rank(fx):
                 ref = yscore.get(tuple(w), y[-1][0])
                 assert abs(ref - y[i][0]) <= 1e-6 * max(1.0, abs(y[i][0])), ("order differs beyond a tie", si, i, ref, y[i][0])
     assert n_reordered <= len(sents) // 50, n_reordered
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no launcher, WORLD_SIZE unset) starts the two ranks itself and prints ONE
+    JSON line with n_gpus = 2 (--debug-shared-gpu: both ranks on this box's one device, control plane over gloo)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--debug-shared-gpu", "--steps", "3", "--warmup", "1",
+                        "--no-config5", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["untimed_steps"] >= 1 and d["roofline"]["frac"] > 0
+    # a world size that contradicts --gpus is refused with a message, not an assert
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r2.stderr + r2.stdout)
