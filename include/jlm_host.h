@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define JLM_HOST_ABI_VERSION 2
+#define JLM_HOST_ABI_VERSION 3
 int jlm_host_abi_version(void);
 
 typedef struct jlm_lexicon jlm_lexicon;
@@ -55,6 +55,12 @@ int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text, const int
 int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int64_t n_nodes,
                          int32_t n_sent, int32_t top_samples, int64_t cap,
                          int32_t *vs_words, int32_t *vs_off, int32_t n_threads);
+
+/* The same from the lattice's own cell structure (host ABI 3): sentence s owns the nodes
+ * end_off[f * n_sent + s] .. end_off[f * n_sent + s + 1] of every frame f -- no pass over node_sent, no
+ * per-sentence buckets; the words set bits in a bitmap over the ids and are read back in order (no sort). */
+int64_t jlm_static_vocab_cells(const int32_t *node_word, const int32_t *end_off, int32_t n_sent, int32_t n_frames,
+                               int32_t top_samples, int64_t cap, int32_t *vs_words, int32_t *vs_off);
 
 /* Word lists of the incremental-vocabulary decoder (decoder_dynamic.py:30-46,112-127) for a
  * batch lattice (node_word / end_off from jlm_lattice_build).  With lv[k] the reference's

@@ -184,19 +184,104 @@ extern "C" int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text
 // per sentence sorted unique word ids over its lattice (+ the first `top_samples` ids), decoder.py:137-151
 extern "C" int64_t jlm_static_vocab(const int32_t *node_word, const int32_t *node_sent, int64_t n_nodes, int32_t n_sent,
                                     int32_t top_samples, int64_t cap, int32_t *vs_words, int32_t *vs_off, int32_t n_threads) {
-    std::vector<std::vector<int32_t>> per(n_sent);
-    for (int64_t i = 0; i < n_nodes; ++i) per[node_sent[i]].push_back(node_word[i]);
-    parallel_for(n_sent, n_threads, [&](int s) {
-        auto &v = per[s];
-        for (int32_t k = 0; k < top_samples; ++k) v.push_back(k);
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
-    });
+    // Sorted unique ids per sentence WITHOUT a sort: the sentence's words set bits in a bitmap over the word ids, the set
+    // bits are read back in order.  (A bucket per sentence + std::sort + std::unique was 4.2 ms per 256 x 20-kana batch --
+    // more than the GPU needs for the batch, and what made Decoder.decode_batch(vocab_select=True) host-bound.)
+    (void)n_threads;
+    // 1. the words of every sentence, contiguous (counting sort by sentence: the nodes come cell by cell)
+    std::vector<int64_t> soff((size_t)n_sent + 1, 0);
+    int32_t wmax = top_samples > 0 ? top_samples - 1 : 0;
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        ++soff[(size_t)node_sent[i] + 1];
+        if (node_word[i] > wmax) wmax = node_word[i];
+    }
+    for (int s = 0; s < n_sent; ++s) soff[s + 1] += soff[s];
+    std::vector<int32_t> flat((size_t)n_nodes);
+    {
+        std::vector<int64_t> cur(soff.begin(), soff.end() - 1);
+        for (int64_t i = 0; i < n_nodes; ++i) flat[(size_t)cur[node_sent[i]]++] = node_word[i];
+    }
+    // 2. per sentence: set, scan, clear
+    std::vector<uint64_t> bits((size_t)wmax / 64 + 1, 0);
+    const int64_t top_words = ((int64_t)top_samples + 63) / 64;
     int64_t total = 0;
     vs_off[0] = 0;
-    for (int s = 0; s < n_sent; ++s) { total += (int64_t)per[s].size(); vs_off[s + 1] = (int32_t)total; }
-    if (total > cap) return total;
-    for (int s = 0; s < n_sent; ++s) std::memcpy(vs_words + vs_off[s], per[s].data(), per[s].size() * sizeof(int32_t));
+    for (int s = 0; s < n_sent; ++s) {
+        int64_t lo = (int64_t)bits.size(), hi = -1;
+        for (int64_t i = soff[s]; i < soff[s + 1]; ++i) {
+            const int64_t w = flat[(size_t)i] >> 6;
+            bits[(size_t)w] |= 1ull << (flat[(size_t)i] & 63);
+            if (w < lo) lo = w;
+            if (w > hi) hi = w;
+        }
+        if (top_samples > 0) {                 // + range(samples), decoder.py:143-146
+            for (int64_t w = 0; w < top_words; ++w) {
+                const int64_t left = (int64_t)top_samples - 64 * w;
+                bits[(size_t)w] |= left >= 64 ? ~0ull : ((1ull << left) - 1);
+            }
+            lo = 0;
+            if (top_words - 1 > hi) hi = top_words - 1;
+        }
+        for (int64_t w = lo; w <= hi; ++w) {
+            uint64_t x = bits[(size_t)w];
+            if (!x) continue;
+            bits[(size_t)w] = 0;
+            while (x) {
+                const int b = __builtin_ctzll(x);
+                x &= x - 1;
+                if (total < cap) vs_words[total] = (int32_t)(64 * w + b);
+                ++total;
+            }
+        }
+        vs_off[s + 1] = (int32_t)total;
+    }
+    return total;
+}
+
+extern "C" int64_t jlm_static_vocab_cells(const int32_t *node_word, const int32_t *end_off, int32_t n_sent, int32_t n_frames,
+                                          int32_t top_samples, int64_t cap, int32_t *vs_words, int32_t *vs_off) {
+    const int B = n_sent, F = n_frames;
+    const int64_t n_nodes = end_off[(int64_t)F * B];
+    int32_t wmax = top_samples > 0 ? top_samples - 1 : 0;
+    for (int64_t i = 0; i < n_nodes; ++i)
+        if (node_word[i] > wmax) wmax = node_word[i];
+    std::vector<uint64_t> bits((size_t)wmax / 64 + 1, 0);
+    const int64_t top_words = ((int64_t)top_samples + 63) / 64;
+    int64_t total = 0;
+    vs_off[0] = 0;
+    for (int s = 0; s < B; ++s) {
+        int64_t lo = (int64_t)bits.size(), hi = -1;
+        for (int f = 0; f < F; ++f) {
+            const int64_t c = (int64_t)f * B + s;
+            for (int32_t i = end_off[c]; i < end_off[c + 1]; ++i) {
+                const int32_t id = node_word[i];
+                const int64_t w = id >> 6;
+                bits[(size_t)w] |= 1ull << (id & 63);
+                if (w < lo) lo = w;
+                if (w > hi) hi = w;
+            }
+        }
+        if (top_samples > 0) {                 // + range(samples), decoder.py:143-146
+            for (int64_t w = 0; w < top_words; ++w) {
+                const int64_t left = (int64_t)top_samples - 64 * w;
+                bits[(size_t)w] |= left >= 64 ? ~0ull : ((1ull << left) - 1);
+            }
+            lo = 0;
+            if (top_words - 1 > hi) hi = top_words - 1;
+        }
+        for (int64_t w = lo; w <= hi; ++w) {
+            uint64_t x = bits[(size_t)w];
+            if (!x) continue;
+            bits[(size_t)w] = 0;
+            while (x) {
+                const int b = __builtin_ctzll(x);
+                x &= x - 1;
+                if (total < cap) vs_words[total] = (int32_t)(64 * w + b);
+                ++total;
+            }
+        }
+        vs_off[s + 1] = (int32_t)total;
+    }
     return total;
 }
 

@@ -107,7 +107,10 @@ class Decoder():
         # lattice builds (single-threaded, 1.4 ms per 256-sentence chunk) running ahead of the GPU: two workers keep it fed
         # (tools/probes/e2e_threads.py: 2 workers x 1 thread = 3 x 4 = 2.8-3.0 ms per step, 1 worker 3.4-3.9), three when the
         # process has CPUs to spare
-        self.prefetch_workers = 3 if usable_cpus() >= 12 else 2
+        # (round 3: four or five workers on the 16-CPU box are SLOWER for every decoder kind -- 1.64 / 1.77 vs 1.48 ms per step
+        # with vocab_select, tools/probes/host_profile2.py: they contend with the calling thread; JLM_PREFETCH_WORKERS overrides)
+        self.prefetch_workers = int(os.environ.get("JLM_PREFETCH_WORKERS", "0")) or (
+            3 if usable_cpus() >= 12 else 2)
         self._pool1 = None
         # The lexicon, the reading dictionary and the trie are a few million long-lived Python objects;
         # left in the collector's youngest-to-oldest scan they cost a ~70 ms full collection every ~20

@@ -42,9 +42,11 @@ def host_lib():
             l.jlm_lattice_build.restype = L64
             l.jlm_static_vocab.argtypes = [P, P, L64, I, I, L64, P, P, I]
             l.jlm_static_vocab.restype = L64
+            l.jlm_static_vocab_cells.argtypes = [P, P, I, I, I, L64, P, P]
+            l.jlm_static_vocab_cells.restype = L64
             l.jlm_dynamic_vocab.argtypes = [P, P, P, I, I, P, P, L64, L64, P, P, P, P, P, I]
             l.jlm_dynamic_vocab.restype = L64
-            _host = l if l.jlm_host_abi_version() == 2 else False
+            _host = l if l.jlm_host_abi_version() == 3 else False
     return _host or None
 
 
@@ -268,8 +270,8 @@ class BatchLattice:
             off = np.zeros(self.n_sent + 1, dtype=np.int32)
             cap = self.n_nodes + (top + 1) * self.n_sent
             words = np.empty(cap, dtype=np.int32)
-            n = lib.jlm_static_vocab(_ptr(np.ascontiguousarray(self.node_word)), _ptr(np.ascontiguousarray(self.node_sent)),
-                                     self.n_nodes, self.n_sent, top, cap, _ptr(words), _ptr(off), self.builder.n_threads)
+            n = lib.jlm_static_vocab_cells(_ptr(np.ascontiguousarray(self.node_word)), _ptr(self.end_off), self.n_sent,
+                                           self.n_frames, top, cap, _ptr(words), _ptr(off))
             assert n <= cap
             words = words[:int(n)]
             return words, off, _LazyLists(words, off)
