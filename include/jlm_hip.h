@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 6
+#define JLM_ABI_VERSION 7
 #define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
@@ -334,6 +334,43 @@ typedef struct {
 int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
                   int frame, int mode, int max_cands, void *stream);
 
+/* ABI 7: the vocabulary projection + log-sum-exp with the two cross terms of the split product on the INT8 matrix pipe
+ * (csrc/jlm_mixed.hip; reference project + softmax, decoder/model.py:141-193, 15-20).
+ *   t.b ~ t_hi.b_hi (f16 x f16, v_mfma_f32_32x32x16_f16) + [t_hi.b_lo + t_lo.b_hi] (int8 x int8 into one i32 accumulator,
+ *         v_mfma_i32_32x32x32_i8; hi8 = rint(hi / s), lo8 = rint(lo / (s 2^-11)), s a power of two per T row / per segment)
+ * "Mixed rows": per 32 k-values a 128-byte block [32 x f16 hi | 32 x int8 hi8 | 32 x int8 lo8]; the bias of a word rides in
+ * the f16 part as columns k (hi of b2 2^eB log2 e) and k + 1 (its f16 residual x 2^11), so a row has nb = ceil((k + 2) / 32)
+ * blocks (ld_dst = 32 nb in 4-byte units, nb <= 8).
+ * jlm_pack_mixed: src [rows, k] f32 (stride ld) and bias [rows] -> dst; scale = 2^eB, bias_scale = 2^eB log2 e, s8 = the
+ * segment's int8 scale (a power of two >= max |f16(src scale)| / 127). */
+int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias, float scale, float bias_scale, float s8,
+                   void *dst, int ld_dst, void *stream);
+/* The hypothesis side: T [G, ldt] f32 -> packed rows Tm [n_rows_max, ld_tm], COMPACT: packed row r = hypothesis row rows[r]
+ * (a frame's live rows: one small buffer, rewritten every frame) (ld_tm = jlm_mixed_t_stride(segs, n_segs), 4-byte units): per
+ * segment nb blocks of x = T 2^eT log2 e in the same block format, the bias constants 2^eT / 2^(eT-11) at columns k, k + 1 of the
+ * f16 part, and at the end of the row JLM_MAX_SEGMENTS floats: the row's int8 scale per segment.  Once per row and frame (one
+ * wave per row); the vocabulary kernel's workgroups only load the result.  t_scale[i] = 2^eT_i (a power of two). */
+int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs);
+int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                     int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream);
+/* segs[i].B = mixed rows, segs[i].ldb = 32 nb, segs[i].k the true contraction length; descale[i] = 2^-(eT_i + eB_i), s8[i] as
+ * above; Tm = the packed hypothesis rows.  Same partial-slice contract and return value as jlm_vocab_lse_split; -2: a shape
+ * this form does not take (k + 2 > 256). */
+int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, int n_segs,
+                        const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                        const int *n_dev, void *stream);
+
+/* One launch over segments of BOTH formats (csrc/jlm_split.hip, vocab_lse_hybrid_kernel): mixed[i].B != NULL runs segment i on
+ * its mixed rows (mixed[i].ldb = 32 nb; mx_descale[i], mx_s8[i] as for jlm_vocab_lse_mixed; Tm = rows packed by
+ * jlm_pack_t_mixed over the MIXED segments only, in segment order, for the same `rows`), the others on their split rows exactly as
+ * jlm_vocab_lse_split (segs / t_scale / descale / bias_col cover every segment).  The int8 cross terms pay where the matrix
+ * instructions dominate a block (k = 200, 100); where the fold does (k = 50) the three f16 passes stay.  -2: a shape the kernel
+ * does not host (mixed: k + 2 in (192, 208] or (96, 112]; split: k <= 64 with its bias column): use jlm_vocab_lse_split. */
+int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t_scale, const float *descale, const int *bias_col,
+                         const jlm_segment *mixed, const float *mx_descale, const float *mx_s8, int n_segs, const float *b2,
+                         const float *T, int ldt, const void *Tm, int ld_tm, const int *rows, float *part, int ld_part,
+                         int max_parts, int n_rows_max, const int *n_dev, void *stream);
+
 /* ABI 6: the largest max_cands (a multiple of 256, as the plans round it) jlm_beam_step accepts for this beam,
  * frame count and mode -- the launcher's own LDS formula, so that callers can route sentences with a larger lattice
  * cell to a host-side search (Decoder._decode_unpruned / DynamicDecoder._decode_host) instead of failing the batch.
@@ -361,7 +398,7 @@ int jlm_softmax_rows(const float *y, float *pred, int ld, int n_rows, int n_cols
  *   jlm_beam_step                (folds the previous frame's normaliser slices)
  *   jlm_lstm_step_xg | jlm_lstm_step(_split), jlm_gemm_nt(_split) (T projection)
  *   jlm_edge_logits              (on `side_stream` when given, forked after T and joined before the next beam step)
- *   jlm_vocab_lse_split | _stationary | jlm_wordlist_lse(_split)
+ *   [jlm_pack_t_mixed +] jlm_vocab_lse_hybrid | jlm_vocab_lse_split | _stationary | jlm_wordlist_lse(_split)
  * and jlm_backtrace at the end -- exactly the calls a host would make one by
  * one through the entry points above (jlm_amd/engine.py does, for timing and
  * for models outside this call's shapes), without ~170 trips through the host
@@ -388,6 +425,10 @@ typedef struct {
     const float *pmt; const void *pmt_split; int n_t; float t_descale;
     /* full-vocabulary normaliser: split segments (NULL: f32 rows-stationary form) */
     const jlm_segment *split_segs; const float *split_t_scale; const float *split_descale; const int *split_bias_col;
+    /* ABI 7: segments of that normaliser on MIXED rows (jlm_vocab_lse_hybrid; NULL: none): n_segs entries, mixed_segs[i].B ==
+     * NULL leaves segment i on its split rows; mixed_t_scale / mixed_descale / mixed_s8 [n_segs] as for jlm_pack_t_mixed /
+     * jlm_vocab_lse_mixed.  Used when the plan carries the packed-row buffer (plan.Tm). */
+    const jlm_segment *mixed_segs; const float *mixed_t_scale; const float *mixed_descale; const float *mixed_s8;
 } jlm_decode_model;
 
 typedef struct {
@@ -415,6 +456,9 @@ typedef struct {
      * vocabulary pairs the weight row of word di_wwords[j] with the bias and the identity of word di_words[j]; sg_wword[e]
      * is the word whose weight row the reference reads for lattice edge e (parallel to sg_word). */
     const int *di_wwords, *sg_wword;
+    /* ABI 7, kind 0 with model.mixed_segs: [n_sent * beam][ld_tm] packed hypothesis rows of the frame being stepped
+     * (jlm_pack_t_mixed over the model's mixed segments, right behind the T projection; ld_tm = jlm_mixed_t_stride of those) */
+    void *Tm; int ld_tm;
 } jlm_decode_plan;
 
 /* Returns 0 or a hipError_t.  st_host->lse_part / n_parts are managed by the call.  A full-vocabulary

@@ -44,7 +44,9 @@ class DecodeModel(Structure):
                 ("xgate", c_void_p), ("wt8", c_void_p), ("xgate8", c_void_p), ("untied_split", c_void_p), ("untied_descale", c_float),
                 ("pmt", c_void_p), ("pmt_split", c_void_p), ("n_t", c_int), ("t_descale", c_float),
                 ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
-                ("split_bias_col", POINTER(c_int))]
+                ("split_bias_col", POINTER(c_int)),
+                ("mixed_segs", POINTER(Segment)), ("mixed_t_scale", POINTER(c_float)), ("mixed_descale", POINTER(c_float)),
+                ("mixed_s8", POINTER(c_float))]
 
 
 class DecodePlan(Structure):
@@ -57,7 +59,7 @@ class DecodePlan(Structure):
                 ("dd_words", c_void_p), ("dd_off", c_void_p), ("dd_max", c_int),
                 ("run_max", c_void_p), ("run_sum", c_void_p), ("part", c_void_p), ("max_parts", c_int), ("lse_cu_share_pct", c_int),
                 ("out_nodes", c_void_p), ("out_len", c_void_p), ("out_score", c_void_p), ("stride", c_int),
-                ("di_wwords", c_void_p), ("sg_wword", c_void_p)]
+                ("di_wwords", c_void_p), ("sg_wword", c_void_p), ("Tm", c_void_p), ("ld_tm", c_int)]
 
 
 P = c_void_p
@@ -91,6 +93,13 @@ _SIGS = {
                                  P, P, P, P], c_int),
     "jlm_beam_step": ([POINTER(Lattice), POINTER(BeamState), c_int, c_int, c_int, P], c_int),
     "jlm_beam_step_max_cands": ([c_int, c_int, c_int], c_int),
+    "jlm_pack_mixed": ([P, c_int, c_int, c_int, P, c_float, c_float, c_float, P, c_int, P], c_int),
+    "jlm_vocab_lse_hybrid": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(Segment), POINTER(c_float),
+                              POINTER(c_float), c_int, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
+    "jlm_mixed_t_stride": ([POINTER(Segment), c_int], c_int),
+    "jlm_pack_t_mixed": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
+    "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), c_int, P, c_int, P, c_int, c_int, c_int, P, P],
+                            c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
     "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P, P], c_int),
@@ -121,7 +130,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 6:
+        if l.jlm_abi_version() != 7:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

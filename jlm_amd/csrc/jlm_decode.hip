@@ -130,6 +130,20 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 JLM_TRY(jlm_gemm_nt((const float *)p->h, m->H, rows, m->pmt, m->H, nullptr, p->T, m->ldt, rows, nullptr, rmax,
                                     m->n_t, m->H, ndev, stream));
         }
+        // segments of the full-vocabulary normaliser on mixed rows: this frame's live rows are packed once, here, behind T
+        bool hybrid = false;
+        if (full && !m->self_norm && !tile_form && m->mixed_segs && m->split_segs && p->Tm) {
+            jlm_segment only[JLM_MAX_SEGMENTS];
+            float only_ts[JLM_MAX_SEGMENTS];
+            int n_only = 0;
+            for (int i = 0; i < m->n_segs; ++i)
+                if (m->mixed_segs[i].B) { only[n_only] = m->mixed_segs[i]; only_ts[n_only++] = m->mixed_t_scale[i]; }
+            if (n_only) {
+                if (jlm_mixed_t_stride(only, n_only) != p->ld_tm) return -1;
+                JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, p->T, m->ldt, rows, f == 0 ? B : rmax, ndev, p->Tm, p->ld_tm, stream));
+                hybrid = true;
+            }
+        }
         const int cell = f * B;
         void *est = stream;
         if (side_s) {          // the edge logits need only T: they run beside the normaliser
@@ -185,7 +199,13 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                     c += m->n_segs - 1;            // slices = columns + the segment boundaries columns straddle
                     if (c < cap) cap = c;
                 }
-                int r = m->split_segs
+                int r = -2;
+                if (hybrid)         // -2: a shape the hybrid kernel does not host -- the split rows of every segment exist
+                    r = jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs,
+                                             m->mixed_descale, m->mixed_s8, m->n_segs, m->b2, p->T, m->ldt, p->Tm, p->ld_tm, rows,
+                                             p->part, rmax, cap, bound, ndev, stream);
+                if (r == -2)
+                    r = m->split_segs
                             ? jlm_vocab_lse_split(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col,
                                                   m->n_segs, m->b2, p->T, m->ldt, rows, p->part, rmax, cap, bound,
                                                   ndev, stream)

@@ -1,0 +1,414 @@
+// jlm_mixed.hip -- the vocabulary projection + log-sum-exp with the cross terms of the split product on the INT8 matrix pipe
+// (jlm_vocab_lse_mixed, jlm_pack_mixed; include/jlm_hip.h).  Reference: project + softmax, decoder/model.py:141-193, 15-20.
+//
+// The split-f16 scheme (jlm_split.hip) writes x 2^e = hi + lo (both f16) and takes three f16 products per pair,
+//      t.b  ~  t_hi.b_hi + t_hi.b_lo + t_lo.b_hi ,
+// each a v_mfma_f32_32x32x16_f16.  The two cross terms are 2^-11 of the first: they need 8 good bits, not 11.  Here
+//      t_hi.b_hi               f16 x f16, exact products, f32 accumulate        (v_mfma_f32_32x32x16_f16, 16 k per instruction)
+//      t_hi.b_lo + t_lo.b_hi   int8 x int8 into ONE i32 accumulator             (v_mfma_i32_32x32x32_i8, 32 k per instruction)
+// with  hi8 = rint(hi / s),  lo8 = rint(lo / (s 2^-11))  and s a power of two per T row (from the row's largest |hi|) and per
+// vocabulary segment: both cross terms then carry the same scale  s_t s_b 2^-11  and share the accumulator.  Per 32 k-values and
+// 32 x 32 block that is 2 + 2 matrix instructions instead of 6, and on this chip -- where these loops are bound by the clock the
+// power governor grants under matrix load, not by issue slots -- a pure MFMA stream of that mix runs in 0.64 of
+// the three-pass stream's time (tools/probes/mfma_mix_rate.hip: 2.50 vs 3.78 ms for equal work on random operands).
+// Error: the quantisation steps are 2^-8 of the row / segment maximum on terms that are 2^-11 of the product: ~1e-6 rms, < 1e-5
+// worst relative to a row's logit scale on the BASELINE models (bar: 1e-4; three f16 passes: 5e-7), and the errors of different
+// words are independent, so the log-normaliser -- what the decode consumes -- moves by < 1e-8.
+//
+// Row format ("mixed rows"), per 32 k-values one 128-byte block:
+//      [ 32 x f16 hi | 32 x int8 hi8 | 32 x int8 lo8 ]      = 8 granules of 16 bytes: 0-3 hi (8 k each), 4-5 hi8, 6-7 lo8
+// The bias rides in the f16 part as TWO extra columns (k: hi of b2 2^eB log2e, against the constant 2^eT on the T side; k + 1:
+// its f16 residual x 2^11 against 2^(eT-11)): both T constants are powers of two, so the bias is exact in the f16 product and
+// stays out of the int8 planes (and out of their scales).
+//
+// Kernel: rows-stationary like vocab_lse_split8_kernel -- a workgroup of 8 waves keeps 256 hypothesis rows' operands in
+// registers (32 rows per wave: f16 hi, int8 hi8, int8 lo8) and streams its vocabulary column through LDS -- but in tiles of
+// 64 words with the WHOLE contraction of a tile resident (two buffers of NB x 8 KB): one barrier per tile, no chunks; LDS-DMA
+// by buffer loads (counted lgkmcnt waits, jlm_gate.hip), fragment registers refilled in place behind the MFMA that read them.
+#include "jlm_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#include "jlm_mixed_body.h"
+using namespace jlm_mx;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ packing (load time)
+// one thread per (row, 32-k block)
+__global__ __launch_bounds__(256) void pack_mixed_kernel(const float *__restrict__ src, int rows, int k, int ld, const float *__restrict__ bias,
+                                                         float scale, float bias_scale, float inv_s8, unsigned char *__restrict__ dst,
+                                                         int nb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nb) return;
+    const int r = idx / nb, j = idx - r * nb;
+    _Float16 hi[32];
+    signed char h8[32], l8[32];
+    const float inv_lo = inv_s8 * 2048.0f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int kk = 32 * j + e;
+        float x = 0.0f;
+        bool real = kk < k;
+        if (real) x = src[(size_t)r * ld + kk] * scale;
+        _Float16 h = (_Float16)x;
+        float lo = x - (float)h;
+        if (!real) {
+            // bias columns: k = hi of the scaled bias, k + 1 = its f16 residual x 2^11 (exactly representable); zero int8 planes
+            const float xb = bias ? bias[r] * bias_scale : 0.0f;
+            const _Float16 bh = (_Float16)xb;
+            if (kk == k) h = bh;
+            else if (kk == k + 1) h = (_Float16)((xb - (float)bh) * 2048.0f);
+            else h = (_Float16)0.0f;
+            lo = 0.0f;
+        }
+        hi[e] = h;
+        const float qh = real ? rintf((float)h * inv_s8) : 0.0f, ql = rintf(lo * inv_lo);
+        h8[e] = (signed char)fminf(fmaxf(qh, -127.0f), 127.0f);
+        l8[e] = (signed char)fminf(fmaxf(ql, -127.0f), 127.0f);
+    }
+    unsigned char *o = dst + ((size_t)r * nb + j) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(o + 16 * q) = *reinterpret_cast<const f32x4 *>(hi + 8 * q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<f32x4 *>(o + 64 + 16 * q) = *reinterpret_cast<const f32x4 *>(h8 + 16 * q);
+        *reinterpret_cast<f32x4 *>(o + 96 + 16 * q) = *reinterpret_cast<const f32x4 *>(l8 + 16 * q);
+    }
+}
+
+// Hypothesis rows (T, f32) -> packed rows: per segment nb blocks [32 f16 hi | 32 int8 hi8 | 32 int8 lo8] of x = T t_scale log2 e,
+// the bias constants 2^eT / 2^(eT-11) at columns k, k + 1 of the f16 part, and at the END of the row JLM_MAX_SEGMENTS floats: the
+// row's int8 scale per segment (the power of two at or above max |hi| / 127).  One wave per row; done ONCE per row and frame --
+// the vocabulary kernel's workgroups (24 columns per row tile) only load the result.
+struct MxTSeg { int k, t_off, nb, tm_off; float t_scale, tc; };
+struct MxTArgs { int n_segs; MxTSeg seg[JLM_MAX_SEGMENTS]; };
+
+__global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
+                                                           int n_rows_max, const int *__restrict__ n_dev, unsigned char *__restrict__ Tm,
+                                                           int ld_tm) {
+    // four rows per workgroup, one wave each; lane l owns the 16-value group l of the row's groups (two per 32-k block, all segments
+    // concatenated: 26 groups for the D-softmax* 200 / 100 / 50 rows): its 16 values are loaded once and stay in registers
+    const int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int g = rows ? rows[r] : r;
+    const int lane = threadIdx.x & 63;
+    const float *trow = T + (size_t)g * ldt;
+    unsigned char *orow = Tm + (size_t)r * ld_tm * 4;          // COMPACT: packed row r = hypothesis row rows[r]
+    int total = 0;
+    for (int si = 0; si < a.n_segs; ++si) total += 2 * a.seg[si].nb;
+    for (int grp0 = 0; grp0 < total; grp0 += 64) {
+        const int grp = grp0 + lane;
+        int si = 0, base = 0;                         // the group's segment
+        while (si + 1 < a.n_segs && grp >= base + 2 * a.seg[si].nb) { base += 2 * a.seg[si].nb; ++si; }
+        const bool act = grp < total;
+        const MxTSeg sg = a.seg[si];
+        const int gs = grp - base;                    // group inside the segment: block gs >> 1, half gs & 1
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k0 = 16 * gs + 4 * q;
+            v[q] = *reinterpret_cast<const f32x4 *>(trow + sg.t_off + ((act && k0 < sg.k) ? k0 : 0));
+        }
+        float amax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, (act && 16 * gs + 4 * q + e < sg.k) ? fabsf((float)(_Float16)(v[q][e] * sg.t_scale)) : 0.0f);
+        // per segment: the maximum over the lanes that hold it
+        float smax = 0.0f;
+        for (int sj = 0; sj < a.n_segs; ++sj) {
+            float x = (act && si == sj) ? amax : 0.0f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+            if (si == sj) smax = x;
+            if (lane == 0 && grp0 == 0) {
+                const float w = x * (1.0f / 127.0f);
+                const int bt = (__float_as_int(w) + 0x007fffff) & 0x7f800000;
+                *reinterpret_cast<float *>(orow + ld_tm * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sj) = x > 0.0f ? __int_as_float(bt) : 1.0f;
+            }
+        }
+        if (!act) continue;
+        const float want = smax * (1.0f / 127.0f);
+        const int bits = (__float_as_int(want) + 0x007fffff) & 0x7f800000;
+        const float s_t = smax > 0.0f ? __int_as_float(bits) : 1.0f;
+        const float inv_h = 1.0f / s_t, inv_l = inv_h * 2048.0f;
+        const int j = gs >> 1, half = gs & 1;
+        _Float16 hi[16];
+        int ph[4], pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int wh = 0, wl = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * gs + 4 * q + e;
+                const bool real = k < sg.k;
+                const float x = real ? v[q][e] * sg.t_scale : (k == sg.k ? sg.tc : (k == sg.k + 1 ? sg.tc * (1.0f / 2048.0f) : 0.0f));
+                const _Float16 h = (_Float16)x;
+                hi[4 * q + e] = h;
+                const float hf_ = (float)h;
+                const int qh = real ? (int)rintf(hf_ * inv_h) : 0;
+                const int ql = real ? (int)rintf((x - hf_) * inv_l) : 0;
+                wh |= (max(min(qh, 127), -127) & 0xff) << (8 * e);
+                wl |= (max(min(ql, 127), -127) & 0xff) << (8 * e);
+            }
+            ph[q] = wh; pl[q] = wl;
+        }
+        unsigned char *blk = orow + sg.tm_off + j * 128;
+        *reinterpret_cast<f32x4 *>(blk + 32 * half) = *reinterpret_cast<const f32x4 *>(hi);
+        *reinterpret_cast<f32x4 *>(blk + 32 * half + 16) = *reinterpret_cast<const f32x4 *>(hi + 8);
+        *reinterpret_cast<i32x4 *>(blk + 64 + 16 * half) = i32x4{ph[0], ph[1], ph[2], ph[3]};
+        *reinterpret_cast<i32x4 *>(blk + 96 + 16 * half) = i32x4{pl[0], pl[1], pl[2], pl[3]};
+    }
+}
+
+// The kernel hosts the bodies of a LIST of (NB, NS16) shapes -- the segments of one model -- and picks per sub-range.  Hosting
+// every shape at once (16 bodies) costs hundreds of spilled registers in all of them; the launcher instantiates the lists it
+// knows (the BASELINE D-softmax* model: k = 200, 100, 50) and a generic kernel of out-of-line bodies for the rest.
+template <bool INLINE, int NB, int NS16>
+struct MxCall {
+    static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
+                                               float2 *prow, unsigned char *smem) {
+        mx_body<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    }
+};
+template <int NB, int NS16>
+__device__ __noinline__ void mx_body_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
+                                             float2 *prow, unsigned char *smem) {
+    mx_body<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+}
+template <int NB, int NS16>
+struct MxCall<false, NB, NS16> {
+    static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
+                                               float2 *prow, unsigned char *smem) {
+        mx_body_outline<NB, NS16>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    }
+};
+
+template <bool INLINE, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
+struct MxDispatch;
+template <bool INLINE>
+struct MxDispatch<INLINE> {
+    static __device__ __forceinline__ void run(const MxSeg &, int, int, int, int, int, const float *, int, const int *, float2 *, unsigned char *) {}
+};
+template <bool INLINE, int NB, int NS16, int... REST>
+struct MxDispatch<INLINE, NB, NS16, REST...> {
+    static __device__ __forceinline__ void run(const MxSeg &sg, int ns16, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt,
+                                               const int *rows, float2 *prow, unsigned char *smem) {
+        if (sg.nb == NB && ns16 == NS16) MxCall<INLINE, NB, NS16>::run(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        else MxDispatch<INLINE, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    }
+};
+
+template <bool INLINE, int... SH>
+__global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
+                                                                 float2 *__restrict__ part, int ld_part, int n_rows_max,
+                                                                 const int *n_dev, int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mx_smem[];
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    // XCD-aware order as in vocab_lse_split_main: column p on XCD p % 8 with all of its row tiles
+    const int b = blockIdx.x;
+    int p, pt;
+    const int nb8 = (a.n_cols & ~7) * n_ptiles;
+    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
+    if (p >= a.n_cols || pt * 256 >= n_paths) return;
+    for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
+        const MxSeg sg = a.seg[a.sub_seg[r]];
+        const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
+        float2 *prow = part + (size_t)r * ld_part;
+        if (r != a.col_first[p]) __syncthreads();
+        const int ns16 = (sg.k + 2 + 15) >> 4;
+        MxDispatch<INLINE, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, mx_smem);
+    }
+}
+// the shapes of BASELINE configs[1] (D-softmax* 200 / 100 / 50: k + 2 = 202, 102, 52), bodies inlined
+#define MX_KERNEL_DSOFTMAX vocab_lse_mixed_kernel<true, 7, 13, 4, 7, 2, 4>
+// every other shape, out-of-line bodies
+#define MX_KERNEL_GENERIC vocab_lse_mixed_kernel<false, 1, 1, 1, 2, 2, 3, 2, 4, 3, 5, 3, 6, 4, 7, 4, 8, 5, 9, 5, 10, 6, 11, 6, 12, 7, 13, 7, 14, 8, 15, 8, 16>
+
+#ifdef JLM_MX_RESOURCES
+// one kernel per instantiation: hipcc -S -DJLM_MX_RESOURCES shows each form's own register count (the shipped kernel hosts all)
+#define MX_RES(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
+        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body<NB_, NS_, mx_blocks_per_tile(NB_)>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
+MX_RES(2, 4) MX_RES(4, 7) MX_RES(7, 13) MX_RES(8, 16)
+#endif
+
+}  // namespace
+
+// dst rows: nb = ceil((k + 2) / 32) blocks of 128 bytes (ld_dst = 32 nb in 4-byte units).  scale = 2^eB, bias_scale = 2^eB log2(e),
+// s8 = the segment's int8 scale (a power of two >= max |f16(src scale)| / 127).
+extern "C" int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias, float scale, float bias_scale, float s8,
+                              void *dst, int ld_dst, void *stream) {
+    if (rows <= 0) return 0;
+    if (k <= 0 || k % 4 || ld < k || ld_dst % 32 || ld_dst / 32 != (k + 2 + 31) / 32 || !(s8 > 0.0f)) return -1;
+    const int nb = ld_dst / 32;
+    const long n = (long)rows * nb;
+    hipLaunchKernelGGL(pack_mixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k, ld, bias,
+                       scale, bias_scale, 1.0f / s8, reinterpret_cast<unsigned char *>(dst), nb);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+// segs[i].B = mixed rows of the segment (jlm_pack_mixed), segs[i].ldb = 32 nb, segs[i].k the true contraction length;
+// t_scale[i] = 2^eT_i (a power of two: the kernel multiplies T by t_scale log2 e and uses t_scale itself as the bias constant),
+// descale[i] = 2^-(eT_i + eB_i), s8[i] = the segment's int8 scale.  Same partial-slice contract and return value as
+// jlm_vocab_lse_split (one slice per column and segment it touches); -2: a shape this form does not take.
+// Row stride (4-byte units) of the packed rows for these segments: the segments' blocks + JLM_MAX_SEGMENTS scale floats
+extern "C" int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS) return -1;
+    int b = 0;
+    for (int i = 0; i < n_segs; ++i) b += (segs_host[i].k + 2 + 31) / 32 * 128;
+    return (b + 4 * JLM_MAX_SEGMENTS + 15) / 16 * 4;
+}
+
+// T [G, ldt] f32 -> Tm [G, ld_tm] packed rows, for the rows listed (rows[0 .. min(*n_dev, n_rows_max)), or 0 .. n_rows_max).
+// t_scale[i] = 2^eT_i (a power of two: x = T 2^eT log2 e).
+extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                                int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || ld_tm != jlm_mixed_t_stride(segs_host, n_segs)) return -1;
+    if (n_rows_max <= 0) return 0;
+    MxTArgs a;
+    a.n_segs = n_segs;
+    int off = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const jlm_segment &sg = segs_host[i];
+        const int nb = (sg.k + 2 + 31) / 32;
+        if (nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
+        a.seg[i] = MxTSeg{sg.k, sg.t_off, nb, off, t_scale[i] * 1.4426950408889634f, t_scale[i]};
+        off += nb * 128;
+    }
+    hipLaunchKernelGGL(pack_t_mixed_kernel, dim3((n_rows_max + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, T, ldt, rows, n_rows_max, n_dev,
+                       reinterpret_cast<unsigned char *>(Tm), ld_tm);
+    JLM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, int n_segs,
+                                   const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                                   const int *n_dev, void *stream) {
+    const int *rows = nullptr;                       // the packed rows are compact (jlm_pack_t_mixed)
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || n_rows_max <= 0 || ld_tm != jlm_mixed_t_stride(segs_host, n_segs)) return -1;
+    const float *T = reinterpret_cast<const float *>(Tm);
+    const int ldt = ld_tm;
+    MxArgs a;
+    a.n_segs = n_segs;
+    static int c0x2 = -1, np8 = -1;
+    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 2; }
+    if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
+    int ntiles[JLM_MAX_SEGMENTS];
+    double ctile[JLM_MAX_SEGMENTS], total = 0.0;
+    long n_tiles_all = 0;
+    int lds_max = 0, tm_off = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const jlm_segment &sg = segs_host[i];
+        const int nb = (sg.k + 2 + 31) / 32;
+        if (nb > MX_MAX_NB || sg.k % 4 || sg.ldb != 32 * nb || sg.t_off % 4) return -2;
+        if ((long)(sg.v_end - sg.v_start) * nb * 128 >= (1l << 31)) return -2;        // 32-bit buffer offsets
+        MxSeg &m = a.seg[i];
+        m.B = reinterpret_cast<const unsigned char *>(sg.B);
+        m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
+        m.tm_off = tm_off; m.seg = i;
+        tm_off += nb * 128;
+        m.descale = descale[i];
+        m.cs = s8[i] * (1.0f / 2048.0f);
+        const int mtt = mx_blocks_per_tile(nb);
+        ntiles[i] = (m.n_vocab + 32 * mtt - 1) / (32 * mtt);
+        if (ntiles[i] > 65535) return -2;
+        const int ns16 = (sg.k + 2 + 15) / 16;
+        // cost of a tile ~ its matrix instructions (f16 steps + two int8 per 32-k block, per 32-word block) + a per-tile constant,
+        // in the units of the split kernel's model (half k-steps of a 128-word tile)
+        // measured (kbench, single-segment launches): a 32-word block costs 0.055 us x (its matrix instructions + ~6: combine,
+        // fold, block start); here in the split kernel's units (a k-step of a 128-word tile = 12 instructions ~ 2 units)
+        ctile[i] = mtt * (ns16 + 2 * nb + 3.0 * c0x2) / 6.0;
+        const int lds_i = 2 * 32 * mtt * nb * 128;
+        if (lds_i > lds_max) lds_max = lds_i;
+        total += ctile[i] * ntiles[i];
+        n_tiles_all += ntiles[i];
+    }
+    const int n_ptiles = (n_rows_max + 255) / 256;
+    int cap = max_parts < MX_MAX_SUB ? max_parts : MX_MAX_SUB;
+    cap -= n_segs - 1;
+    if (cap > MX_MAX_PARTS) cap = MX_MAX_PARTS;
+    if (cap < 1) return -1;
+    int np = 256 / n_ptiles;
+    if (np < 1) np = 1;
+    if (np > cap) np = cap;
+    if (np >= 8 && np8) np &= ~7;
+    { const char *e = getenv("JLM_LSE_NP"); const int f = e ? atoi(e) : 0; if (f > 0 && f <= cap) np = f; }
+    if (np > n_tiles_all) np = (int)n_tiles_all;
+    static double pro = -1.0;
+    if (pro < 0) { const char *e = getenv("JLM_LSE_PRO"); pro = 2.0 * (e ? atof(e) : 17.0); }
+    int n_sub = 0, n_cols = 0;
+    auto fill = [&](double M, bool emit) -> int {
+        int seg = 0, t = 0, cols = 0;
+        n_sub = 0;
+        while (seg < n_segs) {
+            if (emit) { if (cols >= MX_MAX_PARTS) return -1; a.col_first[cols] = (unsigned char)n_sub; }
+            double budget = M;
+            bool first = true;
+            while (seg < n_segs) {
+                if (!first) {
+                    if (budget < pro + ctile[seg]) break;
+                    budget -= pro;
+                }
+                const int avail = ntiles[seg] - t;
+                int take = (int)(budget / ctile[seg] + 1e-9);
+                if (take > avail) take = avail;
+                if (take < 1) { if (!first) break; take = 1; }
+                if (emit) {
+                    if (n_sub >= MX_MAX_SUB) return -1;
+                    a.sub_seg[n_sub] = (unsigned char)seg;
+                    a.sub_t0[n_sub] = (unsigned short)t;
+                    a.sub_t1[n_sub] = (unsigned short)(t + take);
+                }
+                ++n_sub;
+                budget -= take * ctile[seg];
+                first = false;
+                t += take;
+                if (t < ntiles[seg]) break;
+                ++seg;
+                t = 0;
+            }
+            ++cols;
+        }
+        if (emit) a.col_first[cols] = (unsigned char)n_sub;
+        return cols;
+    };
+    {
+        double cmax = 0.0;
+        for (int i = 0; i < n_segs; ++i) cmax = ctile[i] > cmax ? ctile[i] : cmax;
+        double lo = total / np, hi = total / np + (2.0 * cmax + pro) * n_segs + 1.0;
+        for (int it = 0; it < 32; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid, false) <= np) hi = mid; else lo = mid;
+        }
+        n_cols = fill(hi, true);
+        if (n_cols < 1 || n_cols > np) return -4;
+    }
+    a.n_cols = n_cols;
+    a.n_sub = n_sub;
+    if (n_sub > max_parts) return -1;
+    const int lds = lds_max;
+    bool dsoft = true;
+    for (int i = 0; i < n_segs; ++i) {
+        const int nb = a.seg[i].nb, ns16 = (a.seg[i].k + 2 + 15) / 16;
+        dsoft = dsoft && ((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4));
+    }
+    static int attr[2] = {0, 0};
+    const void *fn = dsoft ? reinterpret_cast<const void *>(MX_KERNEL_DSOFTMAX) : reinterpret_cast<const void *>(MX_KERNEL_GENERIC);
+    if (lds > attr[dsoft]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
+        attr[dsoft] = lds;
+    }
+    if (dsoft)
+        hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    else
+        hipLaunchKernelGGL(MX_KERNEL_GENERIC, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e - 100;
+    return n_sub;
+}

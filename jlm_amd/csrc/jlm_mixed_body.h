@@ -1,0 +1,255 @@
+// jlm_mixed_body.h -- device side of the mixed (f16 hi.hi + int8 cross terms) vocabulary kernel: segment descriptor and the
+// per-sub-range body, shared by jlm_mixed.hip (all segments mixed) and jlm_split.hip (the hybrid kernel: mixed bodies for the long
+// contractions, split-f16 bodies for the short ones).  See jlm_mixed.hip for the scheme.
+#pragma once
+#include "jlm_common.h"
+#include <type_traits>
+#include <utility>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define MX_MAX_NB 8                // 32-k blocks per row: k + 2 <= 256 (the nine-block form does not fit the register file)
+#define MX_MAX_PARTS 96
+#define MX_MAX_SUB (MX_MAX_PARTS + JLM_MAX_SEGMENTS)
+
+#ifndef MX_ABL
+#define MX_ABL 0      // measurement builds: 1 no in-stream fold, 2 no combine, 4 no DMA in the loop, 8 no barrier, 16 no MFMAs
+#endif
+
+namespace jlm_mx {
+
+// 32-word blocks per tile by contraction length (host and device): ~54-64 matrix instructions per tile and wave
+__host__ __device__ constexpr int mx_blocks_per_tile(int nb) { return nb >= 5 ? 2 : nb >= 3 ? 4 : 8; }
+
+template <int N> using IC = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void mx_for_each_ic(F &&f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+
+// ------------------------------------------------------------------------------------------------ the kernel
+struct MxSeg {
+    const unsigned char *B;      // mixed rows
+    int n_vocab, k, t_off, nb;   // words, true contraction length, column offset in T, 32-k blocks per row (k + 2 <= 32 nb)
+    int tm_off, seg;             // byte offset of the segment's blocks inside a packed T row; segment number (row scale index)
+    float descale;               // 2^-(eT + eB): f32 accumulator -> base-2 logit
+    float cs;                    // s_b 2^-11: (row scale s_t x) int accumulator -> the f32 accumulator's units
+};
+
+struct MxArgs {
+    int n_cols, n_sub, n_segs;
+    MxSeg seg[JLM_MAX_SEGMENTS];
+    unsigned char col_first[MX_MAX_PARTS + 1];
+    unsigned char sub_seg[MX_MAX_SUB];
+    unsigned short sub_t0[MX_MAX_SUB], sub_t1[MX_MAX_SUB];
+};
+
+// one sub-range (tiles [vt0, vt1) of one segment) for this workgroup's 256 rows; NB 32-k blocks, NS16 f16 steps (2 NB or 2 NB - 1)
+template <int NB, int NS16, int MTT>
+__device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *__restrict__ T, int ldt,
+                                        const int *__restrict__ rows, float2 *__restrict__ part_row, unsigned char *smem) {
+    // (T = the PACKED hypothesis rows of jlm_pack_t_mixed, ldt = their stride in 4-byte units; the rows' int8 scales follow the
+    //  rows' blocks: see pack_t_mixed_kernel)
+    constexpr float LN2 = 0.6931471805599453f;
+    constexpr int ROWB = NB * 128;                       // bytes per mixed row
+    constexpr int TW = 32 * MTT;                         // words per tile: MTT 32-word blocks (2 at k = 200 ... 8 at k = 50: about the
+                                                         // same MFMA count -- and DMA lead time -- per tile whatever the contraction length)
+    constexpr int BUFB = TW * ROWB;                      // bytes per LDS buffer
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = lane >> 5, li = lane & 31;
+    // ---- 1. this lane's row operands, ready-made by jlm_pack_t_mixed (one round trip, no arithmetic: quantising the rows here
+    //         cost 21 us of a 52-us launch at k = 200 -- every one of a row tile's 24 column workgroups repeated it)
+    const int prow = pt * 256 + wave * 32 + li;
+    const bool row_ok = prow < n_paths;
+    const unsigned char *trow = reinterpret_cast<const unsigned char *>(T) + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt * 4;
+    f16x8 thi[NS16];
+    i32x4 thi8[NB], tlo8[NB];
+    float s_t;
+    {
+        const unsigned char *tb = trow + sg.tm_off;
+        i32x4 raw[NS16 + 2 * NB];
+#pragma unroll
+        for (int q = 0; q < NS16; ++q) raw[q] = *reinterpret_cast<const i32x4 *>(tb + (q >> 1) * 128 + (2 * (q & 1) + hf) * 16);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            raw[NS16 + 2 * j] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (4 + hf) * 16);
+            raw[NS16 + 2 * j + 1] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (6 + hf) * 16);
+        }
+        s_t = *reinterpret_cast<const float *>(trow + ldt * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sg.seg);
+        const i32x4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < NS16; ++q) thi[q] = __builtin_bit_cast(f16x8, row_ok ? raw[q] : z);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            thi8[j] = row_ok ? raw[NS16 + 2 * j] : z;
+            tlo8[j] = row_ok ? raw[NS16 + 2 * j + 1] : z;
+        }
+    }
+    const float csr = s_t * sg.cs;
+    const float descale = sg.descale;
+
+    // ---- 2. LDS-DMA of a tile: wave w fills row group w (8 rows) of every block j: one 1-KB piece per (w, j), lane = (row lane >> 3,
+    //         slot lane & 7), source granule = slot ^ ((row >> 1) & 7) (the swizzle sits on the source, the LDS image is lane-linear)
+    // (the descriptor's words made provably wave-uniform: otherwise every DMA instruction sits in a waterfall loop)
+    const unsigned long long bptr = reinterpret_cast<unsigned long long>(sg.B);
+    const unsigned long long bptr_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bptr >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)bptr);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0,
+                                                                          __builtin_amdgcn_readfirstlane(sg.n_vocab) * ROWB, 0x00020000);
+    const int r8 = lane >> 3, dslot = lane & 7;
+    const int drow = 8 * wave + r8;
+    const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
+    constexpr int NRG = MTT / 2;                         // row groups (8 rows) per wave and tile: wave, wave + 8, ...
+    auto issue = [&](int t, int buf) {
+        // the row goes into the per-lane offset (the part the hardware range-checks: a row at or past n_vocab reads zeros), the
+        // block into the scalar offset
+        const int voff = dvoff + t * (TW * ROWB);
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            unsigned char *dst = smem + buf * BUFB + ((wave + 8 * i) * NB) * 1024;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
+                                                         voff + i * (64 * ROWB), j * 128, 0, 0);
+        }
+    };
+    // fragment addresses: block mt, row li: piece (4 mt + li / 8, j); inside it row li % 8, granule g ^ ((li >> 1) & 7)
+    const int x = (li >> 1) & 7;
+    const int fbase = (li >> 3) * (NB * 1024) + (li & 7) * 128;
+    int goff[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) goff[g4] = fbase + ((2 * g4 + hf) ^ x) * 16;       // granules hf, 2 + hf (f16 steps), 4 + hf (hi8), 6 + hf (lo8)
+
+    float m = JLM_NEG_BIG, s = 0.0f;
+    // One accumulator pair.  When a block's last MFMA is out, its 16 logits are COMBINED (y = acc_f + s_t s_b 2^-11 acc_i, masked
+    // past the segment's end) into v[16] -- a short VALU burst -- and the accumulators are free for the next block; the fold of
+    // v (max; then scale, exp2, add) is issued between the next block's MFMAs.  (Folding as a burst after the block left the
+    // matrix pipe idle as long as the block's MFMAs take: 108 us; a second accumulator pair for a fully in-stream fold does
+    // not fit beside the 108 registers of row operands at k = 200: 44 of them went to scratch and every reload waited
+    // vmcnt(0), i.e. for the tile in flight: 130 us.)  v starts at -1e30: the first fold leaves (m, s) = (very negative, 16),
+    // which the first real fold scales to 0.
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = -1.0e30f;
+    float tmax, nmn, sc_old, add0, add1;
+    constexpr int NMF = NS16 + 2 * NB;                   // matrix instructions of a block
+    constexpr int NPIECE = 8 + 1 + 16 + 1;               // 8 x max3, 1, 16 x exp, 1
+    constexpr int PP = (NPIECE + NMF - 1) / NMF;
+    auto fold_piece = [&](int pc) {
+        if (MX_ABL & 1) { if (pc == 0) asm volatile("" :: "v"(v[0]), "v"(v[5]), "v"(v[10]), "v"(v[15])); return; }
+        if (pc < 8) {
+            const float t2 = fmaxf(v[2 * pc], v[2 * pc + 1]);
+            tmax = pc == 0 ? t2 : fmaxf(tmax, t2);
+        } else if (pc == 8) {
+            const float mn = fmaxf(m, tmax * descale);
+            nmn = -mn;
+            sc_old = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            add0 = 0.0f; add1 = 0.0f;
+        } else if (pc < 25) {
+            const int r = pc - 9;
+            const float e = __builtin_amdgcn_exp2f(fmaf(v[r], descale, nmn));
+            if (r & 1) add1 += e; else add0 += e;
+        } else if (pc == 25) {
+            s = s * sc_old + (add0 + add1);
+        }
+    };
+    issue(vt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    f32x16 accf;
+    i32x16 acci;
+    bool have = false;                                    // accf / acci hold a finished block that is not combined yet
+    int lim_acc = 0, mt_acc = 0;                          // ... of a tile with lim_acc valid words, its block mt_acc
+    auto combine = [&]() {
+        if (MX_ABL & 2) { asm volatile("" :: "v"(accf), "v"(acci)); return; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float y = fmaf((float)acci[r], csr, accf[r]);
+            v[r] = (mt_acc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim_acc) ? JLM_NEG_BIG : y;
+        }
+    };
+    for (int t = vt0; t < vt1; ++t) {
+        if (!(MX_ABL & 4) && t + 1 < vt1) issue(t + 1, buf ^ 1);
+        const int lim = sg.n_vocab - t * TW;               // valid words of this tile
+        // Fragments of 32-k block j: F[0..1] the f16 granules of steps 2 j, 2 j + 1; F[2] hi8, F[3] lo8; one register set, each
+        // refilled in place with block j + 1's (or the next 32-word block's first) right behind the MFMA that read it.  f16 and
+        // int8 instructions alternate: consecutive ones never share an accumulator.  A tile's first fragments are requested
+        // right behind the barrier; the combine of the previous tile's last block runs while they are on their way.
+        i32x4 F[4];
+        {
+            const unsigned char *bs0 = smem + buf * BUFB;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) F[g4] = *reinterpret_cast<const i32x4 *>(bs0 + goff[g4]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            const unsigned char *bs = smem + buf * BUFB + mt * (4 * NB * 1024);
+            if (have) combine();                          // the block before this one: its logits into v (frees the accumulators)
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const i32x16 zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            auto rd = [&](int g4, int j) {
+                if (j < NB) F[g4] = *reinterpret_cast<const i32x4 *>(bs + j * 1024 + goff[g4]);
+                else if (mt + 1 < MTT) F[g4] = *reinterpret_cast<const i32x4 *>(bs + (4 * NB * 1024) + goff[g4]);
+            };
+            mx_for_each_ic([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr bool second = 2 * J + 1 < NS16;         // the block's second f16 step exists
+                constexpr bool rdm = (J + 1 < NB);                // (reads behind the last block: only when a next 32-word block exists)
+                auto pieces = [&](int q) {                        // the fold pieces that ride behind matrix instruction q of the block
+#pragma unroll
+                    for (int pc = q * PP; pc < (q + 1) * PP && pc < NPIECE; ++pc) fold_piece(pc);
+                };
+                accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[0]), thi[2 * J], J == 0 ? zf : accf, 0, 0, 0);
+                rd(0, J + 1);
+                pieces(4 * J);
+                acci = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], tlo8[J], J == 0 ? zi : acci, 0, 0, 0);
+                rd(2, J + 1);
+                pieces(4 * J + 1);
+                if constexpr (second) {
+                    accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[1]), thi[second ? 2 * J + 1 : 0], accf, 0, 0, 0);
+                }
+                rd(1, J + 1);
+                pieces(4 * J + 2);
+                acci = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[3], thi8[J], acci, 0, 0, 0);
+                rd(3, J + 1);
+                pieces(4 * J + 3);
+                // issue order of the block: matrix instruction, the read behind it, its share of the fold
+                constexpr int NM = second ? 4 : 3;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (rdm || mt + 1 < MTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (!(MX_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
+                }
+                if constexpr (!second) { if (rdm || mt + 1 < MTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            }, std::make_integer_sequence<int, NB>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // pieces the block's instruction count did not reach (short contractions)
+#pragma unroll
+            for (int pc = 4 * NB * PP; pc < NPIECE; ++pc) fold_piece(pc);
+            have = true; lim_acc = lim; mt_acc = mt;
+        }
+        // the next tile has landed (this wave's pieces) and every wave is done reading this buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(MX_ABL & 8)) __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+    }
+    // the last block: combine, fold
+    if (have) combine();
+#pragma unroll
+    for (int pc = 0; pc < NPIECE; ++pc) fold_piece(pc);
+    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
+    {
+        const float mm = fmaxf(m, m2);
+        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+        m = mm * LN2;
+    }
+    if (hf == 0 && row_ok) part_row[prow] = make_float2(m, s);
+}
+
+}  // namespace jlm_mx

@@ -17,6 +17,7 @@
 // as K/8 blocks of 32 bytes: [8 x f16 hi][8 x f16 lo] -- the same bytes per element as f32, and one
 // 16-byte granule = one MFMA operand (8 consecutive k of one plane) for the LDS-DMA.
 #include "jlm_common.h"
+#include "jlm_mixed_body.h"
 #include <stdlib.h>
 
 #define GLDS16(gp, lp)                                                                          \
@@ -572,6 +573,9 @@ __device__ __forceinline__ void lse_split_body_h(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#if defined(JLM_HY_STAGE) && JLM_HY_STAGE == 1
+    if (part_row) { if (h == 0 && row_ok) part_row[prow] = make_float2((float)thi[0][0], (float)tlo[0][0]); return; }
+#endif
     float *Bs = smem;                              // [2][BMV][64]
     const int lrow = lane >> 4, pslot = lane & 15;
     const int dma_g0 = pslot ^ ((wave * NINST * 4 + lrow) & 15);
@@ -660,6 +664,9 @@ __device__ __forceinline__ void lse_split_body_h(
     };
     issue(vt0, 0, 0);
     __syncthreads();
+#if defined(JLM_HY_STAGE) && JLM_HY_STAGE == 2
+    if (part_row) { if (h == 0 && row_ok) part_row[prow] = make_float2(Bs[lane], 0.0f); return; }
+#endif
     int buf = 0;
     for (int t = vt0; t < vt1; ++t) {
 #pragma unroll
@@ -952,6 +959,192 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return given;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HYBRID: one launch whose columns walk segments of BOTH formats -- mixed rows (f16 hi.hi + int8 cross terms, jlm_mixed.hip) where
+// the contraction is long enough for the matrix instructions to dominate (k = 200, 100: 27 / 15 instead of 39 / 21 instructions
+// per 32 x 32 block), split rows with three f16 passes where the fold's VALU work dominates either way (k = 50: 8 vs 12
+// instructions against ~90 VALU instructions of fold per block -- the int accumulator's combine makes the mixed form SLOWER there:
+// 30.2 vs 27.2 us for the segment alone).  Same equal-cost columns, same partial slices.
+struct LseHybridArgs {
+    LseSplitArgs sp;                                 // the split view of every segment (unused fields for mixed ones)
+    jlm_mx::MxSeg mx[JLM_MAX_SEGMENTS];
+    unsigned mixed_mask;                             // bit i: segment i runs on its mixed rows (a scalar, not a byte array: the
+                                                     // compiler based the other per-segment loads on &is_mixed[si], unaligned)
+};
+
+__global__ __launch_bounds__(512, 1) void vocab_lse_hybrid_kernel(LseHybridArgs a, const float *__restrict__ T, int ldt, const float *__restrict__ Tm,
+                                                                  int ld_tm, const int *__restrict__ rows, float2 *__restrict__ part, int ld_part,
+                                                                  int n_rows_max, const int *n_dev, int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    const int b = blockIdx.x;
+    int p, pt;
+    const int nb8 = (a.sp.n_cols & ~7) * n_ptiles;
+    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { const int bb = b - nb8; p = (a.sp.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
+    if (p >= a.sp.n_cols || pt * 256 >= n_paths) return;
+    for (int r = a.sp.col_first[p]; r < a.sp.col_first[p + 1]; ++r) {
+        const int si = a.sp.sub_seg[r];
+        const int vt0 = a.sp.sub_t0[r], vt1 = a.sp.sub_t1[r];
+        float2 *prow = part + (size_t)r * ld_part;
+        if (r != a.sp.col_first[p]) __syncthreads();
+#ifdef JLM_HY_DEBUG
+        if ((JLM_HY_DEBUG & 1) && ((a.mixed_mask >> si) & 1)) continue;
+        if ((JLM_HY_DEBUG & 2) && !((a.mixed_mask >> si) & 1)) continue;
+#endif
+        if ((a.mixed_mask >> si) & 1) {
+            const jlm_mx::MxSeg sg = a.mx[si];
+            const int ns16 = (sg.k + 2 + 15) >> 4;
+            unsigned char *sm8 = reinterpret_cast<unsigned char *>(smem);
+            if (sg.nb == 7 && ns16 == 13) jlm_mx::mx_body<7, 13, 2>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, nullptr, prow, sm8);
+            else if (sg.nb == 4 && ns16 == 7) jlm_mx::mx_body<4, 7, 4>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, nullptr, prow, sm8);      // (packed rows: compact)
+        } else {
+            const jlm_segment sg = a.sp.seg[si];
+            const int ns = (sg.k + 15) >> 4;
+            if (ns <= 2) lse_split_body_h<2, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+            else lse_split_body_h<4, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        }
+    }
+}
+
+// segs / t_scale / descale / bias_col: as for jlm_vocab_lse_split, for EVERY segment (the T column offsets of the mixed ones are
+// read from here too).  mixed[i].B != NULL: segment i runs on its mixed rows (mixed[i].ldb = 32 nb; mx_descale / mx_s8 as for
+// jlm_vocab_lse_mixed), else on its split rows.  -2: a shape this kernel does not host (mixed: k + 2 in (192, 208] or (96, 112];
+// split: k <= 64, with a bias column) -- the caller falls back to jlm_vocab_lse_split.
+extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t_scale, const float *descale, const int *bias_col,
+                                    const jlm_segment *mixed, const float *mx_descale, const float *mx_s8, int n_segs, const float *b2,
+                                    const float *T, int ldt, const void *Tm, int ld_tm, const int *rows, float *part, int ld_part,
+                                    int max_parts, int n_rows_max, const int *n_dev, void *stream) {
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
+    LseHybridArgs h;
+    unsigned char is_mixed[JLM_MAX_SEGMENTS];
+    h.mixed_mask = 0;
+    LseSplitArgs &a = h.sp;
+    a.n_segs = n_segs;
+    static int c0x2 = -1, np8 = -1;
+    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 2; }
+    if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
+    int ntiles[JLM_MAX_SEGMENTS];
+    double ctile[JLM_MAX_SEGMENTS], total = 0.0;
+    long n_tiles_all = 0;
+    int lds = (2 * 128 * 64 + 3 * 128) * 4, tm_off = 0, any_mixed = 0, n_mixed = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const jlm_segment &sg = segs_host[i];
+        is_mixed[i] = (mixed && mixed[i].B) ? 1 : 0;
+        h.mixed_mask |= (unsigned)is_mixed[i] << i;
+        a.seg[i] = sg;
+        a.bias[i] = b2 + sg.v_start;
+        a.t_scale[i] = t_scale[i] * 1.4426950408889634f;
+        a.descale[i] = descale[i];
+        a.bias_col[i] = (short)(bias_col ? bias_col[i] : -1);
+        if (is_mixed[i]) {
+            const int nb = (sg.k + 2 + 31) / 32, ns16 = (sg.k + 2 + 15) / 16;
+            if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7)) || mixed[i].ldb != 32 * nb || sg.k % 4 || sg.t_off % 4) return -2;
+            if ((long)(sg.v_end - sg.v_start) * nb * 128 >= (1l << 31)) return -2;
+            jlm_mx::MxSeg &m = h.mx[i];
+            m.B = reinterpret_cast<const unsigned char *>(mixed[i].B);
+            m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
+            m.tm_off = tm_off; m.seg = n_mixed++;
+            m.descale = mx_descale[i];
+            m.cs = mx_s8[i] * (1.0f / 2048.0f);
+            const int mtt = jlm_mx::mx_blocks_per_tile(nb);
+            ntiles[i] = (m.n_vocab + 32 * mtt - 1) / (32 * mtt);
+            ctile[i] = mtt * (ns16 + 2 * nb + 3.0 * c0x2) / 6.0;
+            const int l = 2 * 32 * mtt * nb * 128;
+            if (l > lds) lds = l;
+            any_mixed = 1;
+        } else {
+            const int ns = (sg.k + 15) / 16;
+            const int bc = bias_col ? bias_col[i] : -1;
+            if (ns > 4 || bc != sg.k || sg.k % 16 == 0 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4) return -2;
+            ntiles[i] = (sg.v_end - sg.v_start + 127) / 128;
+            ctile[i] = 2 * ns + c0x2;
+        }
+        // (every segment has its slot in the packed rows, mixed or not: jlm_pack_t_mixed packs what it is told to)
+        if (is_mixed[i]) tm_off += ((sg.k + 2 + 31) / 32) * 128;
+        if (ntiles[i] > 65535) return -2;
+        total += ctile[i] * ntiles[i];
+        n_tiles_all += ntiles[i];
+    }
+    if (!any_mixed) return -2;
+    const int n_ptiles = (n_rows_max + 255) / 256;
+    int cap = max_parts < LSES_MAX_SUB ? max_parts : LSES_MAX_SUB;
+    cap -= n_segs - 1;
+    if (cap > LSES_MAX_PARTS) cap = LSES_MAX_PARTS;
+    if (cap < 1) return -1;
+    int np = 256 / n_ptiles;
+    if (np < 1) np = 1;
+    if (np > cap) np = cap;
+    if (np >= 8 && np8) np &= ~7;
+    { const char *e = getenv("JLM_LSE_NP"); const int f = e ? atoi(e) : 0; if (f > 0 && f <= cap) np = f; }
+    if (np > n_tiles_all) np = (int)n_tiles_all;
+    static double pro = -1.0;
+    if (pro < 0) { const char *e = getenv("JLM_LSE_PRO"); pro = 2.0 * (e ? atof(e) : 17.0); }
+    int n_sub = 0, n_cols = 0;
+    auto fill = [&](double M, bool emit) -> int {
+        int seg = 0, t = 0, cols = 0;
+        n_sub = 0;
+        while (seg < n_segs) {
+            if (emit) { if (cols >= LSES_MAX_PARTS) return -1; a.col_first[cols] = (unsigned char)n_sub; }
+            double budget = M;
+            bool first = true;
+            while (seg < n_segs) {
+                if (!first) {
+                    if (budget < pro + ctile[seg]) break;
+                    budget -= pro;
+                }
+                const int avail = ntiles[seg] - t;
+                int take = (int)(budget / ctile[seg] + 1e-9);
+                if (take > avail) take = avail;
+                if (take < 1) { if (!first) break; take = 1; }
+                if (emit) {
+                    if (n_sub >= LSES_MAX_SUB) return -1;
+                    a.sub_seg[n_sub] = (unsigned char)seg;
+                    a.sub_t0[n_sub] = (unsigned short)t;
+                    a.sub_t1[n_sub] = (unsigned short)(t + take);
+                }
+                ++n_sub;
+                budget -= take * ctile[seg];
+                first = false;
+                t += take;
+                if (t < ntiles[seg]) break;
+                ++seg;
+                t = 0;
+            }
+            ++cols;
+        }
+        if (emit) a.col_first[cols] = (unsigned char)n_sub;
+        return cols;
+    };
+    {
+        double cmax = 0.0;
+        for (int i = 0; i < n_segs; ++i) cmax = ctile[i] > cmax ? ctile[i] : cmax;
+        double lo = total / np, hi = total / np + (2.0 * cmax + pro) * n_segs + 1.0;
+        for (int it = 0; it < 32; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid, false) <= np) hi = mid; else lo = mid;
+        }
+        n_cols = fill(hi, true);
+        if (n_cols < 1 || n_cols > np) return -4;
+    }
+    a.n_cols = n_cols;
+    a.n_sub = n_sub;
+    if (n_sub > max_parts) return -1;
+    { const char *e = getenv("JLM_HY_SKIP"); const int sk = e ? atoi(e) : 0;      // debugging: 1 = mixed sub-ranges empty, 2 = split ones
+      for (int r = 0; sk && r < n_sub; ++r) if ((is_mixed[a.sub_seg[r]] ? 1 : 2) & sk) a.sub_t1[r] = a.sub_t0[r]; }
+    static int attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_hybrid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -3;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(vocab_lse_hybrid_kernel, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, h, T, ldt,
+                       reinterpret_cast<const float *>(Tm), ld_tm, rows, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return -(int)e - 100;
+    return n_sub;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -104,14 +104,20 @@ template <class T = void> T *tptr(const TDict &d, const char *key) {
 // ------------------------------------------------------------------------------------------------- Model
 struct JlmModel : torch::CustomClassHolder {
     TDict tensors;
-    Segments segs, split;
+    Segments segs, split, mixed_some;
     std::vector<float> t_scale, descale;
     std::vector<int> bias_col;
+    std::vector<jlm_segment> mixed;                 // n_segs entries, B == NULL where the segment has no mixed rows
+    std::vector<float> mx_t_scale, mx_descale, mx_s8;
     jlm_decode_model m{};
+    // mixed_*: the segments of the full-vocabulary normaliser that also exist as mixed rows (ABI 7): their indices, blocks,
+    // (v_start, v_end, k, t_off, ldb) and the three scales, one entry per such segment
     JlmModel(TDict t, IDict i, FDict f, std::vector<Tensor> seg_B, std::vector<int64_t> seg_meta, std::vector<Tensor> split_B,
              std::vector<int64_t> split_meta, std::vector<double> split_t_scale, std::vector<double> split_descale,
-             std::vector<int64_t> split_bias_col)
-        : tensors(std::move(t)), segs(seg_B, seg_meta), split(split_B, split_meta) {
+             std::vector<int64_t> split_bias_col, std::vector<int64_t> mixed_idx, std::vector<Tensor> mixed_B,
+             std::vector<int64_t> mixed_meta, std::vector<double> mixed_t_scale, std::vector<double> mixed_descale,
+             std::vector<double> mixed_s8)
+        : tensors(std::move(t)), segs(seg_B, seg_meta), split(split_B, split_meta), mixed_some(mixed_B, mixed_meta) {
         for (double x : split_t_scale) t_scale.push_back((float)x);
         for (double x : split_descale) descale.push_back((float)x);
         for (int64_t x : split_bias_col) bias_col.push_back((int)x);
@@ -133,6 +139,27 @@ struct JlmModel : torch::CustomClassHolder {
         if (!split.v.empty()) {
             m.split_segs = split.v.data(); m.split_t_scale = t_scale.data(); m.split_descale = descale.data();
             m.split_bias_col = bias_col.data();
+        }
+        if (!mixed_idx.empty()) {
+            const size_t n = mixed_idx.size();
+            TORCH_CHECK(!split.v.empty() && mixed_some.v.size() == n && mixed_t_scale.size() == n && mixed_descale.size() == n &&
+                            mixed_s8.size() == n,
+                        "jlm.Model: mixed segments need the split table and one block / scale / descale / s8 each");
+            jlm_segment none{};
+            mixed.assign(segs.v.size(), none);
+            mx_t_scale.assign(segs.v.size(), 0.0f); mx_descale.assign(segs.v.size(), 0.0f); mx_s8.assign(segs.v.size(), 0.0f);
+            for (size_t j = 0; j < n; ++j) {
+                const int64_t si = mixed_idx[j];
+                TORCH_CHECK(si >= 0 && si < (int64_t)segs.v.size() && !mixed[si].B, "jlm.Model: bad mixed segment index");
+                const jlm_segment &a = mixed_some.v[j], &b = split.v[si];
+                TORCH_CHECK(a.v_start == b.v_start && a.v_end == b.v_end && a.k == b.k && a.t_off == b.t_off,
+                            "jlm.Model: a mixed segment must describe the same words and T columns as its split form");
+                TORCH_CHECK(mixed_some.keep[j].numel() >= (int64_t)(a.v_end - a.v_start) * a.ldb, "jlm.Model: mixed block too small");
+                mixed[si] = a;
+                mx_t_scale[si] = (float)mixed_t_scale[j]; mx_descale[si] = (float)mixed_descale[j]; mx_s8[si] = (float)mixed_s8[j];
+            }
+            m.mixed_segs = mixed.data(); m.mixed_t_scale = mx_t_scale.data(); m.mixed_descale = mx_descale.data();
+            m.mixed_s8 = mx_s8.data();
         }
         TORCH_CHECK(m.b2 && m.n_segs >= 1 && m.H > 0, "jlm.Model: b2, the segments and H are required");
         TORCH_CHECK(!m.split_lstm || (m.wt8 && m.xgate8 && (m.pmt_split || m.untied)), "jlm.Model: split_lstm needs wt8, xgate8, pmt_split");
@@ -186,6 +213,9 @@ struct JlmPlan : torch::CustomClassHolder {
         p.sg_wword = i.find("off_sg_wword") != i.end() ? at_off("off_sg_wword") : nullptr;
         p.run_max = tptr<float>(tensors, "run_max"); p.run_sum = tptr<double>(tensors, "run_sum");
         p.part = tptr<float>(tensors, "part"); p.max_parts = (int)geti(i, "max_parts");
+        p.Tm = tptr<void>(tensors, "Tm"); p.ld_tm = (int)geti(i, "ld_tm");
+        TORCH_CHECK(!p.Tm || (p.ld_tm > 0 && find(tensors, "Tm")->numel() >= (int64_t)lat.n_sent * lat.beam * p.ld_tm),
+                    "jlm.Plan: Tm must hold n_sent * beam rows of ld_tm");
         p.out_nodes = tptr<int>(tensors, "out_nodes"); p.out_len = tptr<int>(tensors, "out_len");
         p.out_score = tptr<double>(tensors, "out_score"); p.stride = (int)geti(i, "stride");
         TORCH_CHECK(st.score && st.lse && st.bp && st.node && st.word && st.cnt && st.live && st.n_live && st.live_base && p.h && p.c &&
@@ -344,6 +374,17 @@ void pack_split_f16_col(const Tensor &v, int64_t v_off, int64_t rows, double sca
               "jlm_pack_split_f16_col");
 }
 
+// mixed rows of a vocabulary block (include/jlm_hip.h ABI 7): src [rows, k] f32 + the words' biases -> dst [rows, ld_dst]
+void pack_mixed(const Tensor &src, int64_t src_off, int64_t rows, int64_t k, int64_t ld, const Tensor &bias, int64_t bias_off, double scale,
+                double bias_scale, double s8, const Tensor &dst, int64_t ld_dst) {
+    TORCH_CHECK(src_off >= 0 && rows >= 0 && (rows == 0 || src_off + (rows - 1) * ld + k <= src.numel()), "jlm.pack_mixed: source range");
+    TORCH_CHECK(bias_off >= 0 && bias_off + rows <= bias.numel(), "jlm.pack_mixed: bias range");
+    TORCH_CHECK(ld_dst % 32 == 0 && ld_dst >= (k + 2 + 31) / 32 * 32 && rows * ld_dst <= dst.numel(), "jlm.pack_mixed: destination shape");
+    jlm_check(jlm_pack_mixed(ptr<const float>(src, "src") + src_off, (int)rows, (int)k, (int)ld, ptr<const float>(bias, "bias") + bias_off,
+                             (float)scale, (float)bias_scale, (float)s8, ptr<void>(dst, "dst"), (int)ld_dst, stream_of(src)),
+              "jlm_pack_mixed");
+}
+
 // dst[r][c] = codebook[code[r][c]]: the k-means (code, codebook) form of a weight tensor expanded on the device
 void dequant_u8(const Tensor &code, int64_t rows, int64_t k, int64_t ld_code, const Tensor &codebook, const Tensor &dst, int64_t ld_dst) {
     TORCH_CHECK(code.scalar_type() == at::kByte && codebook.scalar_type() == at::kFloat && dst.scalar_type() == at::kFloat,
@@ -362,7 +403,8 @@ int64_t beam_step_max_cands(int64_t beam, int64_t n_frames, int64_t mode) { retu
 TORCH_LIBRARY(jlm, m) {
     m.class_<JlmModel>("Model").def(
         torch::init<TDict, IDict, FDict, std::vector<Tensor>, std::vector<int64_t>, std::vector<Tensor>, std::vector<int64_t>,
-                    std::vector<double>, std::vector<double>, std::vector<int64_t>>());
+                    std::vector<double>, std::vector<double>, std::vector<int64_t>, std::vector<int64_t>, std::vector<Tensor>,
+                    std::vector<int64_t>, std::vector<double>, std::vector<double>, std::vector<double>>());
     m.class_<JlmPlan>("Plan").def(torch::init<TDict, IDict>());
     m.def("decode_frames(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, int n_frames, int vs_max, "
           "int di_max, int dd_max, bool use_side, bool timed, int lse_cu_share_pct) -> int", decode_frames);
@@ -375,6 +417,8 @@ TORCH_LIBRARY(jlm, m) {
     m.def("pack_split_f16(Tensor src, int src_off, int rows, int k, int ld, float scale, Tensor(a!) dst, int dst_off, int ld_dst) -> ()",
           pack_split_f16);
     m.def("pack_split_f16_col(Tensor v, int v_off, int rows, float scale, Tensor(a!) dst, int ld_dst, int col) -> ()", pack_split_f16_col);
+    m.def("pack_mixed(Tensor src, int src_off, int rows, int k, int ld, Tensor bias, int bias_off, float scale, float bias_scale, float s8, "
+          "Tensor(a!) dst, int ld_dst) -> ()", pack_mixed);
     m.def("dequant_u8(Tensor code, int rows, int k, int ld_code, Tensor codebook, Tensor(a!) dst, int ld_dst) -> ()", dequant_u8);
     m.def("abi_version() -> int", abi_version);
     m.def("beam_step_max_cands(int beam, int n_frames, int mode) -> int", beam_step_max_cands);

@@ -120,6 +120,10 @@ class _Plan:
             else:
                 self.n_part = max(m.n_vocab_tiles, 1)
                 self.part = e((self.n_part, rmax, 2), f32)
+        # packed rows of the frame being stepped, for the segments of the normaliser on mixed rows (jlm_pack_t_mixed)
+        self.Tm = None
+        if self.part is not None and getattr(m, "ld_tm", 0):
+            self.Tm = torch.zeros((rmax, m.ld_tm), device=dev, dtype=f32)
         self.stride = F + 1
         self.out_nodes = e((rmax, self.stride), i32)
         self.out_len = e(rmax, i32)
@@ -135,11 +139,13 @@ class _Plan:
         tensors = dict(ints=self.dev_ints, score=self.score, lse=self.lse, bp=self.bp, node=self.node, word=self.word,
                        cnt=self.cnt, live=self.live, n_live=self.n_live, live_base=self.live_base, edge=self.edge, h=self.h,
                        c=self.c, T=self.T, out_nodes=self.out_nodes, out_len=self.out_len, out_score=self.out_score)
-        for name in ("ysum", "run_max", "run_sum", "part"):
+        for name in ("ysum", "run_max", "run_sum", "part", "Tm"):
             if getattr(self, name) is not None:
                 tensors[name] = getattr(self, name)
         ints = dict(n_sent=B, beam=beam, frames=F, kind=2 if dynamic else (1 if vmode == "select" else 0),
                     max_cands=caps["cands"], max_parts=self.n_part, stride=self.stride)
+        if self.Tm is not None:
+            ints["ld_tm"] = m.ld_tm
         ints.update({"off_" + n: o for n, o in self.ioff.items()})
         self.obj = ops.backend().Plan(tensors, ints)
 

@@ -283,6 +283,7 @@ class DeviceModel:
         if self.precision not in ("f16x3", "f32"):
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
+        self.mixed_idx, self.ld_tm = [], 0
         self.split_lstm = False
         self.um_split = None
         if self.precision == "f16x3" and (self.stationary_ok or self.mode == "untied"):
@@ -331,6 +332,7 @@ class DeviceModel:
                 self.split_descale.append(2.0 ** -(eT + eB))
             if self.stationary_ok:
                 self.split_array = list(zip(self.split_segments, self.seg_split))
+                self._build_mixed(t_bound, pow2_below)
             # --- the LSTM step and the T projection on split rows.  An untied model's T is the state itself (model.py:189-191):
             #     its rows ARE the split rows the step writes (scale 2^14), the vocabulary matrix UM^T [V, H] gets split rows
             #     too, and the k = H > 256 normaliser runs as a tile GEMM on them (jlm_vocab_lse_partials_split)
@@ -379,6 +381,54 @@ class DeviceModel:
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
 
+    # (k + 2 -> 32-k blocks, 16-k f16 steps) the hybrid normaliser hosts on mixed rows (csrc/jlm_split.hip vocab_lse_hybrid_kernel)
+    MIXED_SHAPES = ((7, 13), (4, 7))
+
+    def _build_mixed(self, t_bound, pow2_below):
+        """Mixed rows (f16 hi + int8 cross-term planes, include/jlm_hip.h ABI 7) of the segments whose contraction is long enough
+        for the int8 matrix instructions to pay (k = 200, 100 of BASELINE configs[1]); the other segments must be ones the hybrid
+        kernel runs on split rows (k <= 64 with a bias column), else the model stays on split rows alone.  JLM_LSE_MIXED=0
+        switches the form off.  Scales: 2^eB puts max(|B|, |b2| log2 e) at <= 2^14 (the bias rides in two f16 columns), the int8
+        scale s8 is the power of two at or above max|f16(B 2^eB)| / 127, 2^eT as for the split rows."""
+        self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []
+        self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [], [], []
+        self.ld_tm = 0
+        if os.environ.get("JLM_LSE_MIXED", "1") == "0" or self.self_norm:
+            return
+        torch, O = self.torch, _ops.backend()
+        take = []
+        for i, sg in enumerate(self.segments):
+            nv, k = sg["v_end"] - sg["v_start"], sg["k"]
+            if nv > 0 and ((k + 2 + 31) // 32, (k + 2 + 15) // 16) in self.MIXED_SHAPES:
+                take.append(i)
+            elif not (nv > 0 and k <= 64 and self.split_bias_col[i] == k):
+                return
+        if not take:
+            return
+        LOG2E = 1.4426950408889634
+        for i in take:
+            sg = self.segments[i]
+            nv, k = sg["v_end"] - sg["v_start"], sg["k"]
+            nb = (k + 2 + 31) // 32
+            bmax = max(float(self.seg_B[i].abs().max().item()), float(self.b2[sg["v_start"]:sg["v_end"]].abs().max().item()) * LOG2E)
+            eB = pow2_below(2.0 ** 14, bmax)
+            hmax = float((self.seg_B[i] * float(2.0 ** eB)).to(torch.float16).to(torch.float32).abs().max().item())
+            s8 = 2.0 ** int(np.ceil(np.log2(max(hmax, 2.0 ** -100) / 127.0)))
+            tb = 1.0 if t_bound is None else max(float(t_bound[sg["t_off"]:sg["t_off"] + k].max()), 1.0)
+            eT = pow2_below(2.0 ** 15, tb * LOG2E)
+            dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device=self.device)
+            O.pack_mixed(self.seg_B[i], 0, nv, k, sg["ldb"], self.b2, sg["v_start"], float(2.0 ** eB), float(2.0 ** eB * LOG2E), float(s8),
+                         dst, 32 * nb)
+            self.mixed_idx.append(i)
+            self.seg_mixed.append(dst)
+            self.mixed_segments.append(dict(v_start=sg["v_start"], v_end=sg["v_end"], k=k, t_off=sg["t_off"], ldb=32 * nb))
+            self.mixed_t_scale.append(2.0 ** eT)
+            self.mixed_descale.append(2.0 ** -(eT + eB))
+            self.mixed_s8.append(s8)
+        # stride of the packed hypothesis rows (jlm_mixed_t_stride): the segments' 128-byte blocks + JLM_MAX_SEGMENTS scale floats
+        nbytes = sum(msg["ldb"] * 4 for msg in self.mixed_segments) + 4 * 8
+        self.ld_tm = (nbytes + 15) // 16 * 4
+
     def _ctx(self):
         """every launch of this model happens with ITS device current (streams, events and the launches of the HIP runtime
         follow the current device, not the tensors')"""
@@ -415,7 +465,12 @@ class DeviceModel:
                       [float(x) for x in self.split_descale], [int(x) for x in self.split_bias_col])
             else:
                 sp = ([], [], [], [], [])
-            d = self._decode_model = O.Model(t, i, f, list(self.seg_B), meta(self.segments), *sp)
+            if self.split_array is not None and getattr(self, "mixed_idx", None):
+                mx = ([int(x) for x in self.mixed_idx], list(self.seg_mixed), meta(self.mixed_segments),
+                      [float(x) for x in self.mixed_t_scale], [float(x) for x in self.mixed_descale], [float(x) for x in self.mixed_s8])
+            else:
+                mx = ([], [], [], [], [], [])
+            d = self._decode_model = O.Model(t, i, f, list(self.seg_B), meta(self.segments), *(sp + mx))
         return d
 
     # -- launch helpers of LSTM_Model.predict / project (f32 operands, torch's current stream) --------------------

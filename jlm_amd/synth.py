@@ -182,6 +182,11 @@ def small_segs(V):
     return [(32, 0, V // 4), (16, V // 4, (3 * V) // 5), (8, (3 * V) // 5, None)]
 
 
+def wide_segs(V):
+    """BASELINE configs[1]'s segment widths (200 / 100 / 50) over a small vocabulary: the shapes the normaliser runs on mixed rows"""
+    return [(200, 0, V // 4), (100, V // 4, (3 * V) // 5), (50, (3 * V) // 5, None)]
+
+
 def write_arpa(root, lexicon, vocab_size, seed=77, name="lm3"):
     """A synthetic back-off n-gram file ``data/lm3`` in the layout the reference's parser reads
     (decoder/model_ngram.py:30-52: tab-separated ``log10 prob <TAB> w1 w2 .. [<TAB> log10 backoff]``, every other line
@@ -224,6 +229,7 @@ def build_fixture(root, name, exp_id=1):
     that their 2 200-word lexicon still gives a dense lattice.  Names:
 
       small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
+      wide-{vtable,dsoftmax}                      V=2000 H=64, segments 200 / 100 / 50 (the mixed-row shapes, small vocabulary)
       mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
     """
@@ -234,6 +240,9 @@ def build_fixture(root, name, exp_id=1):
     if size == "small":
         scale = 0.25                      # keeps the tiny model's logits O(1)
         V, H, E, segs, alphabet = 2000, 64, 32, small_segs(2000), 12
+    elif size == "wide":
+        scale = 0.1
+        V, H, E, segs, alphabet = 2000, 64, 200, wide_segs(2000), 12
     elif size == "mid":
         V, H, E, segs = 50000, 512, 256, README_SEGS
     elif size == "big":

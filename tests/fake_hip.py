@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 6
+        return 7
 
     def jlm_beam_step_max_cands(self, beam, n_frames, mode):
         """the launcher's LDS formula (csrc/jlm_beam.hip, beam_step_lds_bytes)"""
@@ -120,6 +120,18 @@ class FakeLib:
                                          stream)
                 if r:
                     return r
+            hybrid = False
+            if full and not m.self_norm and not tile_form and m.mixed_segs and split and p.Tm:
+                idx = [i for i in range(m.n_segs) if m.mixed_segs[i].B]
+                if idx:
+                    only = (type(m.mixed_segs[0]) * len(idx))(*[m.mixed_segs[i] for i in idx])
+                    if self.jlm_mixed_t_stride(only, len(idx)) != p.ld_tm:
+                        return -1
+                    r = self.jlm_pack_t_mixed(only, [m.mixed_t_scale[i] for i in idx], len(idx), p.T, m.ldt, rows, B if f == 0 else rmax,
+                                              ndev, p.Tm, p.ld_tm, stream)
+                    if r:
+                        return r
+                    hybrid = True
             cell = f * B
             perm = dynamic and bool(p.di_wwords) and bool(p.sg_wword)
             r = self.jlm_edge_logits_perm(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
@@ -155,7 +167,14 @@ class FakeLib:
                     pending, r = n_parts, 0
                 else:
                     bound = B if f == 0 else rmax
-                    if split:
+                    r = -2
+                    if hybrid:
+                        r = self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs,
+                                                      m.mixed_descale, m.mixed_s8, m.n_segs, m.b2, p.T, m.ldt, p.Tm, p.ld_tm, rows,
+                                                      p.part, rmax, p.max_parts, bound, ndev, stream)
+                    if r != -2:
+                        pass
+                    elif split:
                         r = self.jlm_vocab_lse_split(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col,
                                                      m.n_segs, m.b2, p.T, m.ldt, rows, p.part, rmax, p.max_parts, bound, ndev,
                                                      stream)
@@ -473,6 +492,147 @@ class FakeLib:
             pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
         return n_segs
 
+    # ------------------------------------------------------------------ ABI 7: mixed rows (f16 hi + int8 cross-term planes)
+    @staticmethod
+    def _mixed_view(ptr, rows, nb, ld_bytes=None):
+        """(hi f16 [rows, 32 nb], hi8 int8 [rows, 32 nb], lo8 int8 [rows, 32 nb]) views of rows of 128-byte blocks"""
+        ld_bytes = ld_bytes or nb * 128
+        raw = np.frombuffer((ctypes.c_uint8 * (rows * ld_bytes)).from_address(_p(ptr)), dtype=np.uint8).reshape(rows, ld_bytes)
+        blk = raw[:, :nb * 128].reshape(rows, nb, 128)
+        return blk[:, :, :64], blk[:, :, 64:96], blk[:, :, 96:128]
+
+    @staticmethod
+    def _quant(x32, s):
+        """x (f32) -> (hi f16, hi8, lo8) with int8 scale s for hi and s / 2048 for the residual"""
+        hi = x32.astype(np.float16)
+        lo = x32 - hi.astype(np.float32)
+        q = lambda v: np.clip(np.rint(v), -127, 127).astype(np.int8)
+        return hi, q(hi.astype(np.float32) / s), q(lo / (s / np.float32(2048.0)))
+
+    def jlm_pack_mixed(self, src, rows, k, ld, bias, scale, bias_scale, s8, dst, ld_dst, stream):
+        nb = ld_dst // 32
+        if rows < 0 or k <= 0 or ld < k or ld_dst % 32 or nb * 32 < k + 2 or nb > 8:
+            return -1
+        if rows == 0:
+            return 0
+        flat = view(src, (rows - 1) * ld + k, np.float32)
+        x = np.zeros((rows, 32 * nb), dtype=np.float32)
+        x[:, :k] = np.lib.stride_tricks.as_strided(flat, shape=(rows, k), strides=(4 * ld, 4)) * np.float32(scale)
+        hi, h8, l8 = self._quant(x, np.float32(s8))
+        xb = (view(bias, rows, np.float32) * np.float32(bias_scale)) if _p(bias) else np.zeros(rows, dtype=np.float32)
+        bh = xb.astype(np.float16)
+        hi[:, k] = bh
+        hi[:, k + 1] = ((xb - bh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        h8[:, k:] = 0
+        l8[:, k:] = 0
+        vh, v8, vl = self._mixed_view(dst, rows, nb)
+        vh[:] = hi.reshape(rows, nb, 32).view(np.uint8).reshape(rows, nb, 64)
+        v8[:] = h8.reshape(rows, nb, 32).view(np.uint8)
+        vl[:] = l8.reshape(rows, nb, 32).view(np.uint8)
+        return 0
+
+    def jlm_mixed_t_stride(self, segs, n_segs):
+        if n_segs < 1 or n_segs > 8:
+            return -1
+        b = sum((segs[i].k + 2 + 31) // 32 * 128 for i in range(n_segs))
+        return (b + 4 * 8 + 15) // 16 * 4
+
+    def jlm_pack_t_mixed(self, segs, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream):
+        """packed row r (COMPACT) = hypothesis row rows[r]; per segment the blocks of x = T 2^eT log2 e, the bias constants at
+        f16 columns k, k + 1, and the row's int8 scale per segment in the last 8 floats of the row"""
+        if n_segs < 1 or n_segs > 8 or ldt % 4 or ld_tm != self.jlm_mixed_t_stride(segs, n_segs):
+            return -1
+        n = _n(n_rows_max, n_dev)
+        if n <= 0:
+            return 0
+        g = _rows(rows, n)
+        off = 0
+        scales = view(_p(Tm), n * ld_tm, np.float32).reshape(n, ld_tm)[:, ld_tm - 8:]
+        for i in range(n_segs):
+            sg = segs[i]
+            nb = (sg.k + 2 + 31) // 32
+            Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g])
+            x = np.zeros((n, 32 * nb), dtype=np.float32)
+            x[:, :sg.k] = Tv * np.float32(float(t_scale[i]) * 1.4426950408889634)
+            amax = np.abs(x.astype(np.float16).astype(np.float32)).max(axis=1)
+            with np.errstate(divide="ignore"):
+                s_t = np.where(amax > 0, np.exp2(np.ceil(np.log2(np.maximum(amax, 1e-37) / 127.0))), 1.0).astype(np.float32)
+            hi, h8, l8 = self._quant(x, s_t[:, None])
+            hi[:, sg.k] = np.float16(t_scale[i])
+            hi[:, sg.k + 1] = np.float16(float(t_scale[i]) / 2048.0)
+            h8[:, sg.k:] = 0
+            l8[:, sg.k:] = 0
+            vh, v8, vl = self._mixed_view(_p(Tm) + off, n, nb, ld_tm * 4)
+            vh[:] = hi.reshape(n, nb, 32).view(np.uint8).reshape(n, nb, 64)
+            v8[:] = h8.reshape(n, nb, 32).view(np.uint8)
+            vl[:] = l8.reshape(n, nb, 32).view(np.uint8)
+            scales[:, i] = s_t
+            off += nb * 128
+        return 0
+
+    def _mixed_logits(self, sg, Tm, ld_tm, tm_off, slot, n, descale, s8):
+        """base-e logits [n, words] of a mixed segment: (hi.hi in f16 products + int8 cross terms x s_t s8 / 2048) descale ln 2"""
+        nb, nv = sg.ldb // 32, sg.v_end - sg.v_start
+        f = lambda v, dt: np.ascontiguousarray(v).view(dt).reshape(v.shape[0], -1).astype(np.float64)
+        bh, b8, bl = self._mixed_view(sg.B, nv, nb)
+        th, t8, tl = self._mixed_view(_p(Tm) + tm_off, n, nb, ld_tm * 4)
+        s_t = view(_p(Tm), n * ld_tm, np.float32).reshape(n, ld_tm)[:, ld_tm - 8 + slot].astype(np.float64)
+        main = f(th, np.float16) @ f(bh, np.float16).T
+        cross = f(t8, np.int8) @ f(bl, np.int8).T + f(tl, np.int8) @ f(b8, np.int8).T
+        y2 = (main + cross * (s_t * (float(s8) / 2048.0))[:, None]).astype(np.float32) * np.float32(descale)
+        return y2.astype(np.float64) * 0.6931471805599453
+
+    def jlm_vocab_lse_mixed(self, segs, descale, s8, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream):
+        if n_segs < 1 or n_segs > max_parts or ld_tm != self.jlm_mixed_t_stride(segs, n_segs):
+            return -1
+        n = _n(n_rows_max, n_dev)
+        pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
+        off = 0
+        for i in range(n_segs):
+            if n:
+                y = self._mixed_logits(segs[i], Tm, ld_tm, off, i, n, descale[i], s8[i])
+                mx = y.max(axis=1)
+                pv[i, :n, 0] = mx
+                pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
+            off += segs[i].ldb * 4
+        return n_segs
+
+    def jlm_vocab_lse_hybrid(self, segs, t_scale, descale, bias_col, mixed, mx_descale, mx_s8, n_segs, b2, T, ldt, Tm, ld_tm, rows,
+                             part, ld_part, max_parts, n_rows_max, n_dev, stream):
+        """mixed[i].B: segment i from its mixed rows and the packed hypothesis rows, else from its split rows (the contract of
+        jlm_vocab_lse_split); -2 for the shapes the kernel does not host"""
+        if n_segs < 1 or n_segs > max_parts:
+            return -1
+        is_mixed = [bool(mixed[i].B) for i in range(n_segs)]
+        if not any(is_mixed):
+            return -2
+        for i in range(n_segs):
+            k = segs[i].k
+            if is_mixed[i]:
+                if ((k + 2 + 31) // 32, (k + 2 + 15) // 16) not in ((7, 13), (4, 7)) or mixed[i].ldb != 32 * ((k + 2 + 31) // 32):
+                    return -2
+            elif k > 64 or bias_col is None or bias_col[i] != k or k % 16 == 0:
+                return -2
+        n = _n(n_rows_max, n_dev)
+        pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
+        one = type(segs[0]) * 1
+        tm_off = slot = 0
+        for i in range(n_segs):
+            if is_mixed[i]:
+                if n:
+                    y = self._mixed_logits(mixed[i], Tm, ld_tm, tm_off, slot, n, mx_descale[i], mx_s8[i])
+                    mx = y.max(axis=1)
+                    pv[i, :n, 0] = mx
+                    pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
+                tm_off += mixed[i].ldb * 4
+                slot += 1
+            else:
+                r = self.jlm_vocab_lse_split(one(segs[i]), [t_scale[i]], [descale[i]], [bias_col[i]], 1, b2, T, ldt, rows,
+                                             _p(part) + 8 * i * ld_part, ld_part, 1, n_rows_max, n_dev, stream)
+                if r != 1:
+                    return r
+        return n_segs
+
     def jlm_lse_combine(self, part, ld_part, n_tiles, rows, lse, n_rows_max, n_dev, stream):
         n = _n(n_rows_max, n_dev)
         if n == 0:
@@ -761,9 +921,10 @@ class FakeLib:
 # interface: it does what the C++ shim does -- turn tensor arguments into the C structs and pointers of include/jlm_hip.h
 # -- and hands them to the numpy double of the C ABI above, so the host code is driven through the same two layers.
 class _FakeModel:
-    def __init__(self, t, i, f, seg_B, seg_meta, split_B, split_meta, t_scale, descale, bias_col):
+    def __init__(self, t, i, f, seg_B, seg_meta, split_B, split_meta, t_scale, descale, bias_col, mixed_idx=(), mixed_B=(), mixed_meta=(),
+                 mixed_t_scale=(), mixed_descale=(), mixed_s8=()):
         from jlm_amd import _lib
-        self.keep = (t, list(seg_B), list(split_B))
+        self.keep = (t, list(seg_B), list(split_B), list(mixed_B))
 
         def segs(B, meta):
             arr = (_lib.Segment * max(len(B), 1))()
@@ -789,6 +950,21 @@ class _FakeModel:
             m.split_t_scale = ctypes.cast(self.ts, ctypes.POINTER(ctypes.c_float))
             m.split_descale = ctypes.cast(self.ds, ctypes.POINTER(ctypes.c_float))
             m.split_bias_col = ctypes.cast(self.bc, ctypes.POINTER(ctypes.c_int))
+        if len(mixed_idx):
+            assert len(split_B) and len(mixed_B) == len(mixed_idx) == len(mixed_t_scale) == len(mixed_descale) == len(mixed_s8)
+            n = len(seg_B)
+            some = segs(mixed_B, mixed_meta)
+            self.mixed = (_lib.Segment * n)()
+            self.mts, self.mds, self.ms8 = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_float * n)()
+            for j, si in enumerate(mixed_idx):
+                assert (some[j].v_start, some[j].v_end, some[j].k, some[j].t_off) == \
+                    (self.split[si].v_start, self.split[si].v_end, self.split[si].k, self.split[si].t_off)
+                self.mixed[si] = some[j]
+                self.mts[si], self.mds[si], self.ms8[si] = mixed_t_scale[j], mixed_descale[j], mixed_s8[j]
+            m.mixed_segs = self.mixed
+            m.mixed_t_scale = ctypes.cast(self.mts, ctypes.POINTER(ctypes.c_float))
+            m.mixed_descale = ctypes.cast(self.mds, ctypes.POINTER(ctypes.c_float))
+            m.mixed_s8 = ctypes.cast(self.ms8, ctypes.POINTER(ctypes.c_float))
 
 
 class _FakePlan:
@@ -814,6 +990,8 @@ class _FakePlan:
         d.sg_wword = at("sg_wword") if "off_sg_wword" in i else None
         d.run_max, d.run_sum, d.part, d.max_parts = ptr("run_max"), ptr("run_sum"), ptr("part"), i["max_parts"]
         d.out_nodes, d.out_len, d.out_score, d.stride = ptr("out_nodes"), ptr("out_len"), ptr("out_score"), i["stride"]
+        d.Tm, d.ld_tm = ptr("Tm"), i.get("ld_tm", 0)
+        assert not d.Tm or t["Tm"].numel() >= i["n_sent"] * i["beam"] * d.ld_tm
         self.timed_frames = 0
 
 
@@ -870,6 +1048,10 @@ class FakeOps:
     def pack_split_f16(self, src, src_off, rows, k, ld, scale, dst, dst_off, ld_dst):
         self._chk(self.lib.jlm_pack_split_f16(self._o(src, src_off), rows, k, ld, scale, self._o(dst, dst_off), ld_dst, 0),
                   "jlm_pack_split_f16")
+
+    def pack_mixed(self, src, src_off, rows, k, ld, bias, bias_off, scale, bias_scale, s8, dst, ld_dst):
+        self._chk(self.lib.jlm_pack_mixed(self._o(src, src_off), rows, k, ld, self._o(bias, bias_off), scale, bias_scale, s8, self._o(dst),
+                                          ld_dst, 0), "jlm_pack_mixed")
 
     def dequant_u8(self, code, rows, k, ld_code, codebook, dst, ld_dst):
         self._chk(self.lib.jlm_dequant_u8(code.data_ptr(), rows, k, ld_code, codebook.data_ptr(), codebook.numel(), dst.data_ptr(),

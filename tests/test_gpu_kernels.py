@@ -791,3 +791,138 @@ def test_softmax_rows(L, R, C, sn):
     assert L.jlm_softmax_rows(yg.data_ptr(), pg.data_ptr(), ld, R, C, sn, _st()) == 0
     torch.cuda.synchronize()
     np.testing.assert_allclose(pg.cpu().numpy()[:, :C], p.numpy()[:, :C], rtol=3e-5, atol=1e-9)
+
+
+def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
+    """mixed rows of every segment (jlm_pack_mixed) + the scale arrays jlm_vocab_lse_mixed takes"""
+    import ctypes
+    n = len(widths)
+    segs = (_lib.Segment * n)()
+    ts, ds, s8 = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    keep, Bs, off = [], [], 0
+    b2 = torch.as_tensor(b2_np).cuda()
+    for i, k in enumerate(widths):
+        nv = bounds[i + 1] - bounds[i]
+        B_np = (rng.standard_normal((nv, k)) * 0.08).astype(np.float32)
+        Bs.append(B_np)
+        Bg = torch.as_tensor(B_np).cuda()
+        bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427)
+        eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
+        hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
+        s_b = 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
+        nb = (k + 2 + 31) // 32
+        dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device="cuda")
+        assert L.jlm_pack_mixed(Bg.data_ptr(), nv, k, k, b2.data_ptr() + 4 * bounds[i], 2.0 ** eB, 2.0 ** eB * 1.4426950408889634,
+                                s_b, dst.data_ptr(), 32 * nb, _st()) == 0
+        keep += [Bg, dst]
+        segs[i] = _lib.Segment(bounds[i], bounds[i + 1], k, off, dst.data_ptr(), 32 * nb)
+        ts[i], ds[i], s8[i] = 2.0 ** eT, 2.0 ** -(eT + eB), s_b
+        off += k
+    return segs, ts, ds, s8, Bs, keep, off, b2
+
+
+@pytest.mark.parametrize("V,widths,bounds,R", [(3000, [200, 100, 52], [0, 700, 1900, 3000], 300), (50000, [200, 100, 52], [0, 12000, 30000, 50000], 2560),
+                                               (777, [64], [0, 777], 40), (5000, [252], [0, 5000], 513), (1000, [4, 36], [0, 300, 1000], 33)])
+def test_vocab_lse_mixed(L, V, widths, bounds, R):
+    """jlm_vocab_lse_mixed (f16 hi.hi + int8 cross terms, csrc/jlm_mixed.hip): log-sum-exp of T.B^T + b2 over the vocabulary
+    against the f64 evaluation of the f32 operands; the logits behind it are good to ~1e-5 of the row's logit scale (a one-word
+    vocabulary range makes the kernel return a logit), the normaliser itself far better (the words' errors are independent)"""
+    rng = np.random.default_rng(V + R)
+    b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    G = R + 9
+    T_np = (np.tanh(rng.standard_normal((G, ldt))) * rng.uniform(0.05, 1.0, size=(G, 1))).astype(np.float32)
+    T = torch.as_tensor(T_np).cuda()
+    rows_np = rng.permutation(G)[:R].astype(np.int32)
+    rows = torch.as_tensor(rows_np).cuda()
+    nd = torch.as_tensor(np.array([R - 2], dtype=np.int32)).cuda()
+    part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
+    ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
+    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
+    assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
+    n = L.jlm_vocab_lse_mixed(segs, ds, s8, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
+    assert n >= len(widths), n
+    torch.cuda.synchronize()
+    p = part[:n, :R - 2].cpu().numpy().astype(np.float64)
+    with np.errstate(divide="ignore"):
+        v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
+    mx = v.max(axis=0)
+    lse = mx + np.log(np.exp(v - mx).sum(axis=0))
+    Tsel = T_np[rows_np[:R - 2]].astype(np.float64)
+    y = np.concatenate([Tsel[:, segs[i].t_off:segs[i].t_off + widths[i]] @ Bs[i].astype(np.float64).T for i in range(len(widths))], axis=1) + b2_np
+    ymax = y.max(axis=1)
+    ref = ymax + np.log(np.exp(y - ymax[:, None]).sum(axis=1))
+    assert np.abs(lse - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), np.abs(lse - ref).max()
+    # logits through one-word ranges (sampled words of every segment)
+    worst = 0.0
+    for i in range(len(widths)):
+        for w in rng.choice(np.arange(bounds[i], bounds[i + 1]), size=min(6, bounds[i + 1] - bounds[i]), replace=False):
+            w = int(w)
+            nb = segs[i].ldb // 32
+            one = (_lib.Segment * 1)(_lib.Segment(w, w + 1, widths[i], segs[i].t_off, segs[i].B + 128 * nb * (w - bounds[i]), segs[i].ldb))
+            import ctypes
+            ld1 = L.jlm_mixed_t_stride(one, 1)
+            Tm1 = torch.zeros((R, ld1), dtype=torch.float32, device="cuda")
+            assert L.jlm_pack_t_mixed(one, (ctypes.c_float * 1)(ts[i]), 1, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
+                                      Tm1.data_ptr(), ld1, _st()) == 0
+            n1 = L.jlm_vocab_lse_mixed(one, (ctypes.c_float * 1)(ds[i]), (ctypes.c_float * 1)(s8[i]), 1,
+                                       Tm1.data_ptr(), ld1, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
+            assert n1 == 1
+            torch.cuda.synchronize()
+            q = part[0, :R - 2].cpu().numpy().astype(np.float64)
+            yw = q[:, 0] + np.log(q[:, 1])
+            worst = max(worst, float((np.abs(yw - y[:, w]) / np.abs(y).max(axis=1)).max()))
+    assert worst <= 3e-5, worst
+
+
+@pytest.mark.parametrize("V,bounds,R", [(50000, [0, 12000, 30000, 50000], 2560), (3100, [0, 700, 1900, 3100], 300)])
+def test_vocab_lse_hybrid(L, V, bounds, R):
+    """jlm_vocab_lse_hybrid: the D-softmax* shapes in one launch -- k = 200 and k = 100 on mixed rows (int8 cross terms), k = 50 on
+    split rows (three f16 passes) -- against the f64 evaluation of the f32 operands"""
+    import ctypes
+    widths = [200, 100, 52]
+    rng = np.random.default_rng(V + R)
+    b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    mx, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    n = 3
+    # the split view of every segment (the hybrid runs only the last one on it), from the same matrices
+    plain = (_lib.Segment * n)()
+    off = 0
+    for i in range(n):
+        Bg = keep[2 * i]
+        plain[i] = _lib.Segment(bounds[i], bounds[i + 1], widths[i], off, Bg.data_ptr(), widths[i])
+        off += widths[i]
+    sp, sts, sds, bc, keep2 = _split_segments(L, plain, None, n, [6] * n, b2)
+    for i in range(n):
+        sts[i] = 2.0 ** 10
+        sds[i] = 2.0 ** -(10 + 6)
+    mixed = (_lib.Segment * n)()
+    for i in range(2):
+        mixed[i] = mx[i]
+    only = (_lib.Segment * 2)(mx[0], mx[1])
+    G = R + 9
+    T_np = (np.tanh(rng.standard_normal((G, ldt))) * rng.uniform(0.05, 1.0, size=(G, 1))).astype(np.float32)
+    T = torch.as_tensor(T_np).cuda()
+    rows_np = rng.permutation(G)[:R].astype(np.int32)
+    rows = torch.as_tensor(rows_np).cuda()
+    nd = torch.as_tensor(np.array([R - 2], dtype=np.int32)).cuda()
+    ld_tm = L.jlm_mixed_t_stride(only, 2)
+    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
+    assert L.jlm_pack_t_mixed(only, (ctypes.c_float * 2)(ts[0], ts[1]), 2, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
+                              Tm.data_ptr(), ld_tm, _st()) == 0
+    part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
+    nn = L.jlm_vocab_lse_hybrid(sp, sts, sds, bc, mixed, ds, s8, n, b2.data_ptr(), T.data_ptr(), ldt, Tm.data_ptr(), ld_tm,
+                                rows.data_ptr(), part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
+    assert nn >= n, nn
+    torch.cuda.synchronize()
+    p = part[:nn, :R - 2].cpu().numpy().astype(np.float64)
+    with np.errstate(divide="ignore"):
+        v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
+    m = v.max(axis=0)
+    lse = m + np.log(np.exp(v - m).sum(axis=0))
+    Tsel = T_np[rows_np[:R - 2]].astype(np.float64)
+    o = np.cumsum([0] + widths)
+    y = np.concatenate([Tsel[:, o[i]:o[i + 1]] @ Bs[i].astype(np.float64).T for i in range(n)], axis=1) + b2_np
+    ymax = y.max(axis=1)
+    ref = ymax + np.log(np.exp(y - ymax[:, None]).sum(axis=1))
+    assert np.abs(lse - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), np.abs(lse - ref).max()

@@ -282,3 +282,47 @@ def test_beams_above_one_wave(fx, fake, name, kind, kw):
         assert len(g) == len(w) and len(g) > 10
         assert [x for _, x in g][0] == [x for _, x in w][0]
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax"])
+def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
+    """Segments of width 200 / 100 get mixed rows at load (DeviceModel._build_mixed), the plan its packed-row buffer, and the
+    frame loop packs the live rows and calls the hybrid normaliser (include/jlm_hip.h ABI 7); results as the oracle's, and as
+    the split rows' (JLM_LSE_MIXED=0)."""
+    f = fx(name)
+    calls = {"hybrid": 0, "pack_t": 0}
+    lib = fake
+    hy, pk = lib.jlm_vocab_lse_hybrid, lib.jlm_pack_t_mixed
+
+    def hybrid(*a):
+        calls["hybrid"] += 1
+        return hy(*a)
+
+    def pack_t(*a):
+        calls["pack_t"] += 1
+        return pk(*a)
+    monkeypatch.setattr(lib, "jlm_vocab_lse_hybrid", hybrid, raising=False)
+    monkeypatch.setattr(lib, "jlm_pack_t_mixed", pack_t, raising=False)
+    dec = _decoder(f, "static")
+    m = dec.model.dev
+    assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
+    assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128]
+    sents = synth.make_ragged_sentences(6, 2, 9, seed=5, alphabet=f["alphabet"])
+    got = dec.decode_batch(sents, beam_width=8)
+    n_steps = max(len(s) for s in sents)             # frames 0 .. L - 1 are stepped
+    assert calls["hybrid"] == calls["pack_t"] == n_steps
+    o = orc.OracleDecoder(f["root"], 1)
+    for s, g in zip(sents, got):
+        w = o.decode(s, beam_width=8)
+        assert [x for _, x in g] == [x for _, x in w]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=2e-5)
+    # the split rows alone: the same n-best
+    monkeypatch.setenv("JLM_LSE_MIXED", "0")
+    dec0 = _decoder(f, "static")
+    assert dec0.model.dev.mixed_idx == [] and dec0.model.dev.ld_tm == 0
+    before = calls["hybrid"]
+    got0 = dec0.decode_batch(sents, beam_width=8)
+    assert calls["hybrid"] == before
+    for g, g0 in zip(got, got0):
+        assert [x for _, x in g] == [x for _, x in g0]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in g0], rtol=1e-6, atol=2e-5)

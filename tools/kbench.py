@@ -122,6 +122,100 @@ def bench_lse_split(V, widths, R, tag, bias_col=False):
     report("vocab_lse_split%s %s V=%d k=%s R=%d" % ("+bcol " if bias_col else "      ", tag, V, widths, R), flops, timeit(f))
 
 
+def bench_lse_mixed(V, widths, R, tag):
+    """jlm_vocab_lse_mixed: f16 hi.hi + int8 cross terms"""
+    if flt and flt not in "lse":
+        return
+    if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "mixed split " + tag:
+        return
+    import ctypes
+    bounds = [0, 12000, 30000, V] if len(widths) == 3 else [0, V]
+    n = len(widths)
+    segs = (_lib.Segment * n)()
+    ts, ds, s8 = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    keep, off, flops = [], 0, 0.0
+    b2 = rnd(V, scale=0.05)
+    for i, k in enumerate(widths):
+        kp = (k + 3) // 4 * 4
+        nb = (kp + 2 + 31) // 32
+        nv = bounds[i + 1] - bounds[i]
+        Bm = rnd(nv, kp, scale=0.05)
+        dst = torch.zeros((nv, 32 * nb), device=dev)
+        assert L.jlm_pack_mixed(Bm.data_ptr(), nv, kp, kp, b2.data_ptr() + 4 * bounds[i], 2.0 ** 15, 2.0 ** 15 * 1.4427, 2.0 ** 7,
+                                dst.data_ptr(), 32 * nb, st) == 0
+        keep += [Bm, dst]
+        segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, dst.data_ptr(), 32 * nb)
+        ts[i], ds[i], s8[i] = 2.0 ** 10, 2.0 ** -25, 2.0 ** 7
+        off += kp
+        flops += 2.0 * k * nv * R
+    T = rnd(R, off)
+    part = torch.empty((96, R, 2), device=dev)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    rows = torch.arange(R, device=dev, dtype=torch.int32)
+    ld_tm = L.jlm_mixed_t_stride(segs, n)
+    Tm = torch.zeros((R, ld_tm), device=dev)
+    g = lambda: L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
+    assert g() == 0
+    f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
+    print("parts:", f())
+    report("vocab_lse_mixed      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+    report("pack_t_mixed         %s R=%d" % (tag, R), 1.0, timeit(g))
+
+
+def bench_lse_hybrid(V, widths, R, tag, n_mixed=2):
+    """jlm_vocab_lse_hybrid: the first n_mixed segments on mixed rows, the rest on split rows with a bias column"""
+    if flt and flt not in "lse":
+        return
+    if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "hybrid mixed split " + tag:
+        return
+    import ctypes
+    bounds = [0, 12000, 30000, V]
+    n = len(widths)
+    sp, mx = (_lib.Segment * n)(), (_lib.Segment * n)()
+    ts, ds, bcol = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)()
+    mts, mds, ms8 = (ctypes.c_float * n)(), (ctypes.c_float * n)(), (ctypes.c_float * n)()
+    keep, off, flops = [], 0, 0.0
+    b2 = rnd(V, scale=0.05)
+    for i, k in enumerate(widths):
+        kp = (k + 3) // 4 * 4
+        k16 = (k + 15) // 16 * 16
+        nv = bounds[i + 1] - bounds[i]
+        Bm = rnd(nv, kp, scale=0.05)
+        Bs = torch.zeros((nv, k16), device=dev)
+        assert L.jlm_pack_split_f16(Bm.data_ptr(), nv, kp, kp, 1024.0, Bs.data_ptr(), k16, st) == 0
+        keep += [Bm, Bs]
+        sp[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, Bs.data_ptr(), k16)
+        bcol[i] = kp if kp % 16 else -1
+        if bcol[i] >= 0:
+            assert L.jlm_pack_split_f16_col(b2.data_ptr() + 4 * bounds[i], nv, 1024.0, sp[i].B, sp[i].ldb, bcol[i], st) == 0
+        ts[i], ds[i] = 16.0, 1.0 / (16.0 * 1024.0)
+        if i < n_mixed:
+            nb = (kp + 2 + 31) // 32
+            dst = torch.zeros((nv, 32 * nb), device=dev)
+            assert L.jlm_pack_mixed(Bm.data_ptr(), nv, kp, kp, b2.data_ptr() + 4 * bounds[i], 2.0 ** 15, 2.0 ** 15 * 1.4427, 2.0 ** 7,
+                                    dst.data_ptr(), 32 * nb, st) == 0
+            keep.append(dst)
+            mx[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, dst.data_ptr(), 32 * nb)
+            mts[i], mds[i], ms8[i] = 2.0 ** 10, 2.0 ** -25, 2.0 ** 7
+        off += kp
+        flops += 2.0 * k * nv * R
+    T = rnd(R, off)
+    part = torch.empty((96, R, 2), device=dev)
+    nd = torch.tensor([R], device=dev, dtype=torch.int32)
+    rows = torch.arange(R, device=dev, dtype=torch.int32)
+    only = (_lib.Segment * n_mixed)(*[mx[i] for i in range(n_mixed)])
+    ld_tm = L.jlm_mixed_t_stride(only, n_mixed)
+    Tm = torch.zeros((R, ld_tm), device=dev)
+    g = lambda: L.jlm_pack_t_mixed(only, mts, n_mixed, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
+    assert g() == 0
+    f = lambda: L.jlm_vocab_lse_hybrid(sp, ts, ds, bcol, mx, mds, ms8, n, b2.data_ptr(), T.data_ptr(), off, Tm.data_ptr(), ld_tm,
+                                       rows.data_ptr(), part.data_ptr(), R, 96, R, nd.data_ptr(), st)
+    print("parts:", f())
+    report("vocab_lse_hybrid     %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+    report("pack_t_mixed (%d seg) %s R=%d" % (n_mixed, tag, R), 1.0, timeit(g))
+    report("pack_t + hybrid      %s R=%d" % (tag, R), flops, timeit(lambda: (g(), f())))
+
+
 def bench_gate(H, E, R):
     if flt and flt not in "gate":
         return
@@ -230,6 +324,12 @@ if __name__ == "__main__":
         bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*", bias_col=True)
+        bench_lse_mixed(50000, [200, 100, 50], R, "dsoftmax*")
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*")
+        if os.environ.get("KBENCH_SEGS"):
+            for V1, k1 in ((12000, 200), (18000, 100), (20000, 50)):
+                bench_lse_split(V1, [k1], R, "seg-k%d" % k1, bias_col=True)
+                bench_lse_mixed(V1, [k1], R, "seg-k%d" % k1)
         bench_lse_stat(50000, [256], R, "tied50k")
         bench_lse_split(50000, [256], R, "tied50k")
         bench_lse(12000, 200, R, "seg0")
