@@ -131,7 +131,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                                     m->n_t, m->H, ndev, stream));
         }
         // segments of the full-vocabulary normaliser on mixed rows: this frame's live rows are packed once, here, behind T
-        bool hybrid = false;
+        bool hybrid = false, all_mixed = false;
         if (full && !m->self_norm && !tile_form && m->mixed_segs && m->split_segs && p->Tm) {
             jlm_segment only[JLM_MAX_SEGMENTS];
             float only_ts[JLM_MAX_SEGMENTS];
@@ -142,6 +142,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 if (jlm_mixed_t_stride(only, n_only) != p->ld_tm) return -1;
                 JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, p->T, m->ldt, rows, f == 0 ? B : rmax, ndev, p->Tm, p->ld_tm, stream));
                 hybrid = true;
+                all_mixed = n_only == m->n_segs;
             }
         }
         const int cell = f * B;
@@ -200,7 +201,10 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                     if (c < cap) cap = c;
                 }
                 int r = -2;
-                if (hybrid)         // -2: a shape the hybrid kernel does not host -- the split rows of every segment exist
+                if (all_mixed)      // every segment on mixed rows
+                    r = jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->n_segs, p->Tm, p->ld_tm, p->part, rmax, cap,
+                                            bound, ndev, stream);
+                else if (hybrid)    // -2: a shape the hybrid kernel does not host -- the split rows of every segment exist
                     r = jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs,
                                              m->mixed_descale, m->mixed_s8, m->n_segs, m->b2, p->T, m->ldt, p->Tm, p->ld_tm, rows,
                                              p->part, rmax, cap, bound, ndev, stream);

@@ -163,6 +163,20 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
     }
 }
 
+#ifdef JLM_WGTIME
+// -DJLM_WGTIME: per workgroup [start, end] on the constant 100 MHz clock, the segment of its last sub-range, shader-clock cycles
+// in between (tools/probes/mixed_clock.py: workgroup durations and the shader clock the kernel actually ran at)
+static __device__ unsigned long long jlm_prof_wg_mx[1024][4];
+extern "C" int jlm_prof_read_wg_mx(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_prof_wg_mx), sizeof(jlm_prof_wg_mx)) == hipSuccess ? 0 : -1;
+}
+#define MX_WG_T0 const unsigned long long wg_t0 = wall_clock64(), wg_c0 = clock64(); int si_last = 0;
+#define MX_WG_T1 if (threadIdx.x == 0 && b < 1024) { jlm_prof_wg_mx[b][0] = wg_t0; jlm_prof_wg_mx[b][1] = wall_clock64(); jlm_prof_wg_mx[b][2] = si_last; jlm_prof_wg_mx[b][3] = clock64() - wg_c0; }
+#else
+#define MX_WG_T0
+#define MX_WG_T1
+#endif
+
 // The kernel hosts the bodies of a LIST of (NB, NS16) shapes -- the segments of one model -- and picks per sub-range.  Hosting
 // every shape at once (16 bodies) costs hundreds of spilled registers in all of them; the launcher instantiates the lists it
 // knows (the BASELINE D-softmax* model: k = 200, 100, 50) and a generic kernel of out-of-line bodies for the rest.
@@ -214,15 +228,48 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const
     if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
     else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
     if (p >= a.n_cols || pt * 256 >= n_paths) return;
+    MX_WG_T0
     for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
         const MxSeg sg = a.seg[a.sub_seg[r]];
         const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
         float2 *prow = part + (size_t)r * ld_part;
         if (r != a.col_first[p]) __syncthreads();
         const int ns16 = (sg.k + 2 + 15) >> 4;
+#ifdef JLM_WGTIME
+        si_last = a.sub_seg[r];
+#endif
         MxDispatch<INLINE, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, mx_smem);
     }
+    MX_WG_T1
 }
+// Four waves of 64 rows (mx_body2): the shapes of BASELINE configs[1], bodies inlined
+__global__ __launch_bounds__(256) void vocab_lse_mixed2_kernel(MxArgs a, const float *__restrict__ T, int ldt, float2 *__restrict__ part,
+                                                               int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mx_smem[];
+    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    const int b = blockIdx.x;
+    int p, pt;
+    const int nb8 = (a.n_cols & ~7) * n_ptiles;
+    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
+    else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
+    if (p >= a.n_cols || pt * 256 >= n_paths) return;
+    MX_WG_T0
+    for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
+        const MxSeg sg = a.seg[a.sub_seg[r]];
+        const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
+        float2 *prow = part + (size_t)r * ld_part;
+        if (r != a.col_first[p]) __syncthreads();
+        const int ns16 = (sg.k + 2 + 15) >> 4;
+#ifdef JLM_WGTIME
+        si_last = a.sub_seg[r];
+#endif
+        if (sg.nb == 7 && ns16 == 13) mx_body2<7, 13, mx_blocks_per_tile(7)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
+        else if (sg.nb == 4 && ns16 == 7) mx_body2<4, 7, mx_blocks_per_tile(4)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
+        else if (sg.nb == 2 && ns16 == 4) mx_body2<2, 4, mx_blocks_per_tile(2)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
+    }
+    MX_WG_T1
+}
+
 // the shapes of BASELINE configs[1] (D-softmax* 200 / 100 / 50: k + 2 = 202, 102, 52), bodies inlined
 #define MX_KERNEL_DSOFTMAX vocab_lse_mixed_kernel<true, 7, 13, 4, 7, 2, 4>
 // every other shape, out-of-line bodies
@@ -402,7 +449,20 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
         attr[dsoft] = lds;
     }
-    if (dsoft)
+    // JLM_MX_ROWS=64: four waves of 64 rows (mx_body2, an experiment: half the LDS reads, and no faster -- 38.1 / 32.8 / 30.8 us
+    // against 32.7 / 29.3 / 26.1 for the three segments alone: one wave per SIMD has nobody to cover its LDS waits and its VALU)
+    static int form = -1;
+    if (form < 0) { const char *e = getenv("JLM_MX_ROWS"); form = (e && atoi(e) == 64) ? 64 : 32; }
+    if (dsoft && form == 64) {
+        static int attr2 = 0;
+        if (lds > attr2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_mixed2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return -3;
+            attr2 = lds;
+        }
+        hipLaunchKernelGGL(vocab_lse_mixed2_kernel, dim3(n_cols * n_ptiles), dim3(256), lds, (hipStream_t)stream, a, T, ldt,
+                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    } else if (dsoft)
         hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
                            reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
     else

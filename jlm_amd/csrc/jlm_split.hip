@@ -573,9 +573,6 @@ __device__ __forceinline__ void lse_split_body_h(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#if defined(JLM_HY_STAGE) && JLM_HY_STAGE == 1
-    if (part_row) { if (h == 0 && row_ok) part_row[prow] = make_float2((float)thi[0][0], (float)tlo[0][0]); return; }
-#endif
     float *Bs = smem;                              // [2][BMV][64]
     const int lrow = lane >> 4, pslot = lane & 15;
     const int dma_g0 = pslot ^ ((wave * NINST * 4 + lrow) & 15);
@@ -664,9 +661,6 @@ __device__ __forceinline__ void lse_split_body_h(
     };
     issue(vt0, 0, 0);
     __syncthreads();
-#if defined(JLM_HY_STAGE) && JLM_HY_STAGE == 2
-    if (part_row) { if (h == 0 && row_ok) part_row[prow] = make_float2(Bs[lane], 0.0f); return; }
-#endif
     int buf = 0;
     for (int t = vt0; t < vt1; ++t) {
 #pragma unroll
@@ -970,8 +964,11 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
 struct LseHybridArgs {
     LseSplitArgs sp;                                 // the split view of every segment (unused fields for mixed ones)
     jlm_mx::MxSeg mx[JLM_MAX_SEGMENTS];
-    unsigned mixed_mask;                             // bit i: segment i runs on its mixed rows (a scalar, not a byte array: the
-                                                     // compiler based the other per-segment loads on &is_mixed[si], unaligned)
+    // bit i: segment i runs on its mixed rows.  A scalar, NOT a byte array indexed by the segment: with `unsigned char
+    // is_mixed[8]` hipcc based every per-segment kernarg load on &is_mixed[si] (s_load_dwordx2 s[80:81], s[8:9], s4 with
+    // s[8:9] = kernarg + si, s4 = 31 si): base and offset each unaligned, their sum aligned -- the scalar unit drops the low
+    // bits of the parts, segment 2's matrix pointer came out of the wrong dwords and the LDS-DMA faulted
+    unsigned mixed_mask;
 };
 
 __global__ __launch_bounds__(512, 1) void vocab_lse_hybrid_kernel(LseHybridArgs a, const float *__restrict__ T, int ldt, const float *__restrict__ Tm,
@@ -990,10 +987,6 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_hybrid_kernel(LseHybridArgs 
         const int vt0 = a.sp.sub_t0[r], vt1 = a.sp.sub_t1[r];
         float2 *prow = part + (size_t)r * ld_part;
         if (r != a.sp.col_first[p]) __syncthreads();
-#ifdef JLM_HY_DEBUG
-        if ((JLM_HY_DEBUG & 1) && ((a.mixed_mask >> si) & 1)) continue;
-        if ((JLM_HY_DEBUG & 2) && !((a.mixed_mask >> si) & 1)) continue;
-#endif
         if ((a.mixed_mask >> si) & 1) {
             const jlm_mx::MxSeg sg = a.mx[si];
             const int ns16 = (sg.k + 2 + 15) >> 4;
@@ -1132,8 +1125,6 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
     a.n_cols = n_cols;
     a.n_sub = n_sub;
     if (n_sub > max_parts) return -1;
-    { const char *e = getenv("JLM_HY_SKIP"); const int sk = e ? atoi(e) : 0;      // debugging: 1 = mixed sub-ranges empty, 2 = split ones
-      for (int r = 0; sk && r < n_sub; ++r) if ((is_mixed[a.sub_seg[r]] ? 1 : 2) & sk) a.sub_t1[r] = a.sub_t0[r]; }
     static int attr = 0;
     if (lds > attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_hybrid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)

@@ -381,13 +381,14 @@ class DeviceModel:
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
 
-    # (k + 2 -> 32-k blocks, 16-k f16 steps) the hybrid normaliser hosts on mixed rows (csrc/jlm_split.hip vocab_lse_hybrid_kernel)
-    MIXED_SHAPES = ((7, 13), (4, 7))
+    # (k + 2 -> 32-k blocks, 16-k f16 steps) with inlined mixed-row bodies: k = 200, 100, 50 (csrc/jlm_mixed.hip MX_KERNEL_DSOFTMAX; the
+    # first two also in csrc/jlm_split.hip vocab_lse_hybrid_kernel, beside split-row bodies for other short segments)
+    MIXED_SHAPES = ((7, 13), (4, 7), (2, 4))
 
     def _build_mixed(self, t_bound, pow2_below):
-        """Mixed rows (f16 hi + int8 cross-term planes, include/jlm_hip.h ABI 7) of the segments whose contraction is long enough
-        for the int8 matrix instructions to pay (k = 200, 100 of BASELINE configs[1]); the other segments must be ones the hybrid
-        kernel runs on split rows (k <= 64 with a bias column), else the model stays on split rows alone.  JLM_LSE_MIXED=0
+        """Mixed rows (f16 hi + int8 cross-term planes, include/jlm_hip.h ABI 7) of the segments with a hosted shape (k = 200, 100, 50
+        of BASELINE configs[1]): all of them -> jlm_vocab_lse_mixed; the other segments must be ones the hybrid kernel runs on
+        split rows (k <= 64 with a bias column), else the model stays on split rows alone.  JLM_LSE_MIXED=0
         switches the form off.  Scales: 2^eB puts max(|B|, |b2| log2 e) at <= 2^14 (the bias rides in two f16 columns), the int8
         scale s8 is the power of two at or above max|f16(B 2^eB)| / 127, 2^eT as for the split rows."""
         self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []

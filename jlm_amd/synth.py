@@ -187,6 +187,11 @@ def wide_segs(V):
     return [(200, 0, V // 4), (100, V // 4, (3 * V) // 5), (50, (3 * V) // 5, None)]
 
 
+def wideh_segs(V):
+    """200 / 100 / 36: two mixed-row shapes and a short segment the hybrid launch keeps on split rows"""
+    return [(200, 0, V // 4), (100, V // 4, (3 * V) // 5), (36, (3 * V) // 5, None)]
+
+
 def write_arpa(root, lexicon, vocab_size, seed=77, name="lm3"):
     """A synthetic back-off n-gram file ``data/lm3`` in the layout the reference's parser reads
     (decoder/model_ngram.py:30-52: tab-separated ``log10 prob <TAB> w1 w2 .. [<TAB> log10 backoff]``, every other line
@@ -230,6 +235,7 @@ def build_fixture(root, name, exp_id=1):
 
       small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
       wide-{vtable,dsoftmax}                      V=2000 H=64, segments 200 / 100 / 50 (the mixed-row shapes, small vocabulary)
+      wideh-vtable                                 the same with 200 / 100 / 36: the hybrid launch (mixed + split rows)
       mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
     """
@@ -243,6 +249,9 @@ def build_fixture(root, name, exp_id=1):
     elif size == "wide":
         scale = 0.1
         V, H, E, segs, alphabet = 2000, 64, 200, wide_segs(2000), 12
+    elif size == "wideh":
+        scale = 0.1
+        V, H, E, segs, alphabet = 2000, 64, 200, wideh_segs(2000), 12
     elif size == "mid":
         V, H, E, segs = 50000, 512, 256, README_SEGS
     elif size == "big":

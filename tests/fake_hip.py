@@ -120,7 +120,7 @@ class FakeLib:
                                          stream)
                 if r:
                     return r
-            hybrid = False
+            hybrid = all_mixed = False
             if full and not m.self_norm and not tile_form and m.mixed_segs and split and p.Tm:
                 idx = [i for i in range(m.n_segs) if m.mixed_segs[i].B]
                 if idx:
@@ -132,6 +132,7 @@ class FakeLib:
                     if r:
                         return r
                     hybrid = True
+                    all_mixed = len(idx) == m.n_segs
             cell = f * B
             perm = dynamic and bool(p.di_wwords) and bool(p.sg_wword)
             r = self.jlm_edge_logits_perm(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
@@ -168,7 +169,10 @@ class FakeLib:
                 else:
                     bound = B if f == 0 else rmax
                     r = -2
-                    if hybrid:
+                    if all_mixed:
+                        r = self.jlm_vocab_lse_mixed(m.mixed_segs, m.mixed_descale, m.mixed_s8, m.n_segs, p.Tm, p.ld_tm, p.part, rmax,
+                                                     p.max_parts, bound, ndev, stream)
+                    elif hybrid:
                         r = self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs,
                                                       m.mixed_descale, m.mixed_s8, m.n_segs, m.b2, p.T, m.ldt, p.Tm, p.ld_tm, rows,
                                                       p.part, rmax, p.max_parts, bound, ndev, stream)

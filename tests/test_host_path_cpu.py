@@ -284,15 +284,17 @@ def test_beams_above_one_wave(fx, fake, name, kind, kw):
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax"])
+@pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax", "wideh-vtable"])
 def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
-    """Segments of width 200 / 100 get mixed rows at load (DeviceModel._build_mixed), the plan its packed-row buffer, and the
+    """Segments of width 200 / 100 / 50 get mixed rows at load (DeviceModel._build_mixed), the plan its packed-row buffer, and the
     frame loop packs the live rows and calls the hybrid normaliser (include/jlm_hip.h ABI 7); results as the oracle's, and as
     the split rows' (JLM_LSE_MIXED=0)."""
     f = fx(name)
     calls = {"hybrid": 0, "pack_t": 0}
     lib = fake
-    hy, pk = lib.jlm_vocab_lse_hybrid, lib.jlm_pack_t_mixed
+    # wide-*: all three widths are hosted mixed shapes, the all-mixed launch; wideh-*: the last one stays on split rows, the hybrid
+    launch = "jlm_vocab_lse_hybrid" if name.startswith("wideh") else "jlm_vocab_lse_mixed"
+    hy, pk = getattr(lib, launch), lib.jlm_pack_t_mixed
 
     def hybrid(*a):
         calls["hybrid"] += 1
@@ -301,12 +303,16 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     def pack_t(*a):
         calls["pack_t"] += 1
         return pk(*a)
-    monkeypatch.setattr(lib, "jlm_vocab_lse_hybrid", hybrid, raising=False)
+    monkeypatch.setattr(lib, launch, hybrid, raising=False)
     monkeypatch.setattr(lib, "jlm_pack_t_mixed", pack_t, raising=False)
     dec = _decoder(f, "static")
     m = dec.model.dev
-    assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
-    assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128]
+    if name.startswith("wideh"):
+        assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
+        assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128]
+    else:
+        assert m.mixed_idx == [0, 1, 2] and m.ld_tm == (7 * 128 + 4 * 128 + 2 * 128 + 32) // 4
+        assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128, 64]
     sents = synth.make_ragged_sentences(6, 2, 9, seed=5, alphabet=f["alphabet"])
     got = dec.decode_batch(sents, beam_width=8)
     n_steps = max(len(s) for s in sents)             # frames 0 .. L - 1 are stepped

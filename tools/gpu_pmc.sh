@@ -15,7 +15,7 @@ R = os.environ["GRAFT_REPO_ROOT"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R + "/gpurun_out/pmc2/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:28] + " grid=" + r.get("Grid_Size", "?")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:40] + " grid=" + r.get("Grid_Size", "?")
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     if "lse" not in k: continue
