@@ -342,7 +342,9 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     MxArgs a;
     a.n_segs = n_segs;
     static int c0x2 = -1, np8 = -1;
-    if (c0x2 < 0) { const char *e = getenv("JLM_LSE_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 2; }
+    // per-block constant of the cost model below; swept on the three-segment launch (kbench, C0 x prologue cost): 0.5: 78-80 us,
+    // 1: 72.7-73.4, 1.5: 72.2-72.6, 2: 69.8-72.3, 3: 72.3-73.2
+    if (c0x2 < 0) { const char *e = getenv("JLM_MX_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 4; }
     if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
     int ntiles[JLM_MAX_SEGMENTS];
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
