@@ -48,7 +48,7 @@ CONFIG5_SENTENCES = 8192
 def kernel_source_sha256():
     """Identity of the kernels the committed PMC traffic figure was measured on (profiles/traffic_latest.json)."""
     h = hashlib.sha256()
-    for f in ("jlm_split.hip", "jlm_common.h"):
+    for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_body.h", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -208,10 +208,18 @@ def main():
         # executed MFMA work: 3 passes, contraction padded to whole 16-value steps (+ the bias column where it rides in the GEMM)
         k16 = lambda sg: (sg["k"] + (1 if (sg["k"] % 16 and m.stationary_ok) else 0) + 15) // 16 * 16
         exec_per_row_vocab = SPLIT_PASSES * sum(2.0 * k16(sg) * (sg["v_end"] - sg["v_start"]) for sg in m.segments)
+        # every segment on mixed rows (jlm_vocab_lse_mixed): per 32 x 32 block and 32 k-values two f16 and two int8 matrix
+        # instructions of 32 cycles each, against six f16 ones of the split form; counted here in f16-instruction units
+        # (2 x 16 flop per row, word and instruction), k + 2 padded to whole f16 steps / int8 blocks
+        mixed = split and len(getattr(m, "mixed_idx", [])) == m.n_segs
+        if mixed:
+            exec_per_row_vocab = sum(2.0 * 16 * ((sg["k"] + 2 + 15) // 16 + 2 * ((sg["k"] + 2 + 31) // 32)) * (sg["v_end"] - sg["v_start"])
+                                     for sg in m.segments)
         v = kernel_stats(durs, rows, "vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
         roofline = None
         if v:
             kname = ("gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
+                     "vocab_lse_mixed_kernel (jlm_vocab_lse_mixed; its rows packed by pack_t_mixed_kernel behind the T projection)" if mixed else
                      "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                      else "gemm2_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
@@ -235,15 +243,24 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_note,
                         "avg_launch_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                         "flops_per_launch": v["flops_per_launch"],
-                        "mfma_dtype": ("f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): `peak` = %.1f dense f16 / %d passes prices "
+                        "mfma_dtype": (("f16 hi.hi (v_mfma_f32_32x32x16_f16) + int8 cross terms (v_mfma_i32_32x32x32_i8): 4 matrix instructions per "
+                                        "32 k-values instead of the split form's 6.  `peak` stays %.1f dense f16 / %d -- the pricing of rounds 1-2 "
+                                        "(three f16 passes per f32-grade product), so `frac` compares across rounds; the scheme's own ceiling is "
+                                        "dense f16 / 2 (`frac_of_scheme_peak`); frac_of_dense_f16 prices the executed instructions at 32 cycles each"
+                                        % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES)) if mixed else
+                                       "f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): `peak` = %.1f dense f16 / %d passes prices "
                                        "ALGORITHMIC flops; frac_of_dense_f16 prices the executed ones (3 passes, k padded to 16)"
                                        % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES) if split else "f32 (v_mfma_f32_32x32x2_f32)"),
                         "measured": "HIP events around every launch of the dominant kernel on its stream, in a repeat of the timed decode"}
+            if mixed:
+                roofline["frac_of_scheme_peak"] = round(v["tflops"] / (F16_MFMA_PEAK_TFLOPS / 2.0), 4)
             if not full_vocab:
                 # the vocabulary-selected / per-frame-deduplicated decoders run this kernel over a sub-problem whose size is
                 # decided on the device each frame: the full-vocabulary flop count does not apply, so nothing is priced
-                for k in ("achieved", "frac", "frac_of_dense_f16", "frac_of_dense_f16_algorithmic", "executed_tflops", "flops_per_launch", "traffic"):
-                    roofline[k] = None
+                for k in ("achieved", "frac", "frac_of_dense_f16", "frac_of_dense_f16_algorithmic", "frac_of_scheme_peak", "executed_tflops",
+                          "flops_per_launch", "traffic"):
+                    if k in roofline:
+                        roofline[k] = None
                 roofline["note"] = ("decoder=%s works on a per-frame selected sub-problem (rows x columns decided on the device): "
                                     "only the launch time is reported; the roofline is quoted on decoder=static" % decoder_name)
         g = kernel_stats(durs, rows, "gate_gemm", 2.0 * H * 4 * H * (SPLIT_PASSES if gsplit else 1))
@@ -495,8 +512,9 @@ def main():
         "ms_per_step": round(steps_ms, 3),
         "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
-        "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate: f32-grade error, tests/test_gpu_kernels.py; "
-                  "scores f64)" if getattr(m, "split_lstm", False) else "f32"),
+        "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate%s: f32-grade error, tests/test_gpu_kernels.py; "
+                  "scores f64)" % ("; the vocabulary projection as f16 hi.hi + two int8 cross-term passes" if getattr(m, "mixed_idx", None) else "")
+                  if getattr(m, "split_lstm", False) else "f32"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "fixture": args.fixture,
                    "sentences_per_gpu": args.batch if args.config == 2 else CONFIG5_SENTENCES // world,
