@@ -340,7 +340,7 @@ int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
  *         v_mfma_i32_32x32x32_i8; hi8 = rint(hi / s), lo8 = rint(lo / (s 2^-11)), s a power of two per T row / per segment)
  * "Mixed rows": per 32 k-values a 128-byte block [32 x f16 hi | 32 x int8 hi8 | 32 x int8 lo8]; the bias of a word rides in
  * the f16 part as columns k (hi of b2 2^eB log2 e) and k + 1 (its f16 residual x 2^11), so a row has nb = ceil((k + 2) / 32)
- * blocks (ld_dst = 32 nb in 4-byte units, nb <= 8).
+ * blocks (ld_dst = 32 nb in 4-byte units, nb <= 8) -- or, for k a multiple of 32, nb = k / 32 and no bias columns (below).
  * jlm_pack_mixed: src [rows, k] f32 (stride ld) and bias [rows] -> dst; scale = 2^eB, bias_scale = 2^eB log2 e, s8 = the
  * segment's int8 scale (a power of two >= max |f16(src scale)| / 127). */
 int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias, float scale, float bias_scale, float s8,
@@ -355,8 +355,11 @@ int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_s
                      int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream);
 /* segs[i].B = mixed rows, segs[i].ldb = 32 nb, segs[i].k the true contraction length; descale[i] = 2^-(eT_i + eB_i), s8[i] as
  * above; Tm = the packed hypothesis rows.  Same partial-slice contract and return value as jlm_vocab_lse_split; -2: a shape
- * this form does not take (k + 2 > 256). */
-int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, int n_segs,
+ * this form does not take (more than 8 blocks; segments of both bias forms in one launch).
+ * A contraction that fills its last block (k a multiple of 32: the tied k = 256 models) has no columns left for the bias: its
+ * rows are packed with ld_dst = k (jlm_pack_mixed then ignores `bias`), segs[i].ldb = k says so, and the kernel takes the
+ * biases from bias2 [V] = b2 log2(e) (device; may be NULL otherwise) -- staged into LDS beside each tile, added in the combine. */
+int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
                         const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
                         const int *n_dev, void *stream);
 
@@ -429,6 +432,7 @@ typedef struct {
      * NULL leaves segment i on its split rows; mixed_t_scale / mixed_descale / mixed_s8 [n_segs] as for jlm_pack_t_mixed /
      * jlm_vocab_lse_mixed.  Used when the plan carries the packed-row buffer (plan.Tm). */
     const jlm_segment *mixed_segs; const float *mixed_t_scale; const float *mixed_descale; const float *mixed_s8;
+    const float *mixed_bias2;       /* b2 log2(e) [V] for mixed segments without bias columns (NULL: none) */
 } jlm_decode_model;
 
 typedef struct {

@@ -46,7 +46,7 @@ class DecodeModel(Structure):
                 ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
                 ("split_bias_col", POINTER(c_int)),
                 ("mixed_segs", POINTER(Segment)), ("mixed_t_scale", POINTER(c_float)), ("mixed_descale", POINTER(c_float)),
-                ("mixed_s8", POINTER(c_float))]
+                ("mixed_s8", POINTER(c_float)), ("mixed_bias2", c_void_p)]
 
 
 class DecodePlan(Structure):
@@ -98,7 +98,7 @@ _SIGS = {
                               POINTER(c_float), c_int, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_mixed_t_stride": ([POINTER(Segment), c_int], c_int),
     "jlm_pack_t_mixed": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
-    "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), c_int, P, c_int, P, c_int, c_int, c_int, P, P],
+    "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
                             c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pack_mixed_kernel(const float *__restrict
         float lo = x - (float)h;
         if (!real) {
             // bias columns: k = hi of the scaled bias, k + 1 = its f16 residual x 2^11 (exactly representable); zero int8 planes
-            const float xb = bias ? bias[r] * bias_scale : 0.0f;
+            const float xb = (bias && k + 2 <= 32 * nb) ? bias[r] * bias_scale : 0.0f;
             const _Float16 bh = (_Float16)xb;
             if (kk == k) h = bh;
             else if (kk == k + 1) h = (_Float16)((xb - (float)bh) * 2048.0f);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void pack_mixed_kernel(const float *__restrict
 // the bias constants 2^eT / 2^(eT-11) at columns k, k + 1 of the f16 part, and at the END of the row JLM_MAX_SEGMENTS floats: the
 // row's int8 scale per segment (the power of two at or above max |hi| / 127).  One wave per row; done ONCE per row and frame --
 // the vocabulary kernel's workgroups (24 columns per row tile) only load the result.
-struct MxTSeg { int k, t_off, nb, tm_off; float t_scale, tc; };
+struct MxTSeg { int k, t_off, nb, tm_off; float t_scale, tc; };      // tc = 0: no bias columns (k = 32 nb)
 struct MxTArgs { int n_segs; MxTSeg seg[JLM_MAX_SEGMENTS]; };
 
 __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
@@ -180,42 +180,43 @@ extern "C" int jlm_prof_read_wg_mx(unsigned long long *out) {
 // The kernel hosts the bodies of a LIST of (NB, NS16) shapes -- the segments of one model -- and picks per sub-range.  Hosting
 // every shape at once (16 bodies) costs hundreds of spilled registers in all of them; the launcher instantiates the lists it
 // knows (the BASELINE D-softmax* model: k = 200, 100, 50) and a generic kernel of out-of-line bodies for the rest.
-template <bool INLINE, int NB, int NS16>
+template <bool INLINE, bool XB, int NB, int NS16>
 struct MxCall {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                                float2 *prow, unsigned char *smem) {
-        mx_body<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
     }
 };
-template <int NB, int NS16>
+template <bool XB, int NB, int NS16>
 __device__ __noinline__ void mx_body_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                              float2 *prow, unsigned char *smem) {
-    mx_body<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
 }
-template <int NB, int NS16>
-struct MxCall<false, NB, NS16> {
+template <bool XB, int NB, int NS16>
+struct MxCall<false, XB, NB, NS16> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                                float2 *prow, unsigned char *smem) {
-        mx_body_outline<NB, NS16>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        mx_body_outline<XB, NB, NS16>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
     }
 };
 
-template <bool INLINE, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
+template <bool INLINE, bool XB, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
 struct MxDispatch;
-template <bool INLINE>
-struct MxDispatch<INLINE> {
+template <bool INLINE, bool XB>
+struct MxDispatch<INLINE, XB> {
     static __device__ __forceinline__ void run(const MxSeg &, int, int, int, int, int, const float *, int, const int *, float2 *, unsigned char *) {}
 };
-template <bool INLINE, int NB, int NS16, int... REST>
-struct MxDispatch<INLINE, NB, NS16, REST...> {
+template <bool INLINE, bool XB, int NB, int NS16, int... REST>
+struct MxDispatch<INLINE, XB, NB, NS16, REST...> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int ns16, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt,
                                                const int *rows, float2 *prow, unsigned char *smem) {
-        if (sg.nb == NB && ns16 == NS16) MxCall<INLINE, NB, NS16>::run(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
-        else MxDispatch<INLINE, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        if (sg.nb == NB && ns16 == NS16) MxCall<INLINE, XB, NB, NS16>::run(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        else MxDispatch<INLINE, XB, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
     }
 };
 
-template <bool INLINE, int... SH>
+// XB: every segment of the launch is in the external-bias form (mx_body XBIAS); f16 steps = min(2 nb, ceil((k + 2) / 16))
+template <bool INLINE, bool XB, int... SH>
 __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
                                                                  float2 *__restrict__ part, int ld_part, int n_rows_max,
                                                                  const int *n_dev, int n_ptiles) {
@@ -234,51 +235,27 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const
         const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
         float2 *prow = part + (size_t)r * ld_part;
         if (r != a.col_first[p]) __syncthreads();
-        const int ns16 = (sg.k + 2 + 15) >> 4;
+        const int ns16 = XB ? 2 * sg.nb : (sg.k + 2 + 15) >> 4;
 #ifdef JLM_WGTIME
         si_last = a.sub_seg[r];
 #endif
-        MxDispatch<INLINE, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, mx_smem);
+        MxDispatch<INLINE, XB, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, T, ldt, rows, prow, mx_smem);
     }
     MX_WG_T1
 }
-// Four waves of 64 rows (mx_body2): the shapes of BASELINE configs[1], bodies inlined
-__global__ __launch_bounds__(256) void vocab_lse_mixed2_kernel(MxArgs a, const float *__restrict__ T, int ldt, float2 *__restrict__ part,
-                                                               int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mx_smem[];
-    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
-    const int b = blockIdx.x;
-    int p, pt;
-    const int nb8 = (a.n_cols & ~7) * n_ptiles;
-    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
-    else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
-    if (p >= a.n_cols || pt * 256 >= n_paths) return;
-    MX_WG_T0
-    for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
-        const MxSeg sg = a.seg[a.sub_seg[r]];
-        const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
-        float2 *prow = part + (size_t)r * ld_part;
-        if (r != a.col_first[p]) __syncthreads();
-        const int ns16 = (sg.k + 2 + 15) >> 4;
-#ifdef JLM_WGTIME
-        si_last = a.sub_seg[r];
-#endif
-        if (sg.nb == 7 && ns16 == 13) mx_body2<7, 13, mx_blocks_per_tile(7)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
-        else if (sg.nb == 4 && ns16 == 7) mx_body2<4, 7, mx_blocks_per_tile(4)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
-        else if (sg.nb == 2 && ns16 == 4) mx_body2<2, 4, mx_blocks_per_tile(2)>(sg, vt0, vt1, pt, n_paths, T, ldt, prow, mx_smem);
-    }
-    MX_WG_T1
-}
-
 // the shapes of BASELINE configs[1] (D-softmax* 200 / 100 / 50: k + 2 = 202, 102, 52), bodies inlined
-#define MX_KERNEL_DSOFTMAX vocab_lse_mixed_kernel<true, 7, 13, 4, 7, 2, 4>
+#define MX_KERNEL_DSOFTMAX vocab_lse_mixed_kernel<true, false, 7, 13, 4, 7, 2, 4>
 // every other shape, out-of-line bodies
-#define MX_KERNEL_GENERIC vocab_lse_mixed_kernel<false, 1, 1, 1, 2, 2, 3, 2, 4, 3, 5, 3, 6, 4, 7, 4, 8, 5, 9, 5, 10, 6, 11, 6, 12, 7, 13, 7, 14, 8, 15, 8, 16>
+#define MX_KERNEL_GENERIC vocab_lse_mixed_kernel<false, false, 1, 1, 1, 2, 2, 3, 2, 4, 3, 5, 3, 6, 4, 7, 4, 8, 5, 9, 5, 10, 6, 11, 6, 12, 7, 13, 7, 14, 8, 15, 8, 16>
+// the tied k = 256 models (BASELINE configs[2..4]: one segment, no spare column for the bias), body inlined
+#define MX_KERNEL_TIED vocab_lse_mixed_kernel<true, true, 8, 16>
+// external-bias form of the other contractions that fill their last block (k = 64, 128, 192), out-of-line
+#define MX_KERNEL_GENERIC_XB vocab_lse_mixed_kernel<false, true, 2, 4, 4, 8, 6, 12, 8, 16>
 
 #ifdef JLM_MX_RESOURCES
 // one kernel per instantiation: hipcc -S -DJLM_MX_RESOURCES shows each form's own register count (the shipped kernel hosts all)
 #define MX_RES(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
-        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body<NB_, NS_, mx_blocks_per_tile(NB_)>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
+        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body<NB_, NS_, mx_blocks_per_tile(NB_), false>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
 MX_RES(2, 4) MX_RES(4, 7) MX_RES(7, 13) MX_RES(8, 16)
 #endif
 
@@ -289,7 +266,9 @@ MX_RES(2, 4) MX_RES(4, 7) MX_RES(7, 13) MX_RES(8, 16)
 extern "C" int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias, float scale, float bias_scale, float s8,
                               void *dst, int ld_dst, void *stream) {
     if (rows <= 0) return 0;
-    if (k <= 0 || k % 4 || ld < k || ld_dst % 32 || ld_dst / 32 != (k + 2 + 31) / 32 || !(s8 > 0.0f)) return -1;
+    // ld_dst = 32 ceil((k + 2) / 32): the bias rides in columns k, k + 1; = 32 ceil(k / 32) < that (k a multiple of 32): no bias columns
+    // (bias ignored; jlm_vocab_lse_mixed takes the biases separately)
+    if (k <= 0 || k % 4 || ld < k || ld_dst % 32 || (ld_dst / 32 != (k + 2 + 31) / 32 && ld_dst / 32 != (k + 31) / 32) || !(s8 > 0.0f)) return -1;
     const int nb = ld_dst / 32;
     const long n = (long)rows * nb;
     hipLaunchKernelGGL(pack_mixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k, ld, bias,
@@ -302,11 +281,22 @@ extern "C" int jlm_pack_mixed(const float *src, int rows, int k, int ld, const f
 // t_scale[i] = 2^eT_i (a power of two: the kernel multiplies T by t_scale log2 e and uses t_scale itself as the bias constant),
 // descale[i] = 2^-(eT_i + eB_i), s8[i] = the segment's int8 scale.  Same partial-slice contract and return value as
 // jlm_vocab_lse_split (one slice per column and segment it touches); -2: a shape this form does not take.
+// blocks per row of a segment as its ldb says: ceil((k + 2) / 32) (bias columns) or, for k a multiple of 32, k / 32 (none); -1: neither
+static int mx_seg_blocks(const jlm_segment &sg) {
+    if (sg.k <= 0 || sg.ldb % 32) return -1;
+    const int nb = sg.ldb / 32;
+    return (nb == (sg.k + 2 + 31) / 32 || nb == (sg.k + 31) / 32) ? nb : -1;
+}
+
 // Row stride (4-byte units) of the packed rows for these segments: the segments' blocks + JLM_MAX_SEGMENTS scale floats
 extern "C" int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS) return -1;
     int b = 0;
-    for (int i = 0; i < n_segs; ++i) b += (segs_host[i].k + 2 + 31) / 32 * 128;
+    for (int i = 0; i < n_segs; ++i) {
+        const int nb = mx_seg_blocks(segs_host[i]);
+        if (nb < 0) return -1;
+        b += nb * 128;
+    }
     return (b + 4 * JLM_MAX_SEGMENTS + 15) / 16 * 4;
 }
 
@@ -321,9 +311,9 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
     int off = 0;
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
-        const int nb = (sg.k + 2 + 31) / 32;
-        if (nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
-        a.seg[i] = MxTSeg{sg.k, sg.t_off, nb, off, t_scale[i] * 1.4426950408889634f, t_scale[i]};
+        const int nb = mx_seg_blocks(sg);
+        if (nb < 1 || nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
+        a.seg[i] = MxTSeg{sg.k, sg.t_off, nb, off, t_scale[i] * 1.4426950408889634f, sg.k + 2 <= 32 * nb ? t_scale[i] : 0.0f};
         off += nb * 128;
     }
     hipLaunchKernelGGL(pack_t_mixed_kernel, dim3((n_rows_max + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, T, ldt, rows, n_rows_max, n_dev,
@@ -332,7 +322,7 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
     return 0;
 }
 
-extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, int n_segs,
+extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
                                    const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
                                    const int *n_dev, void *stream) {
     const int *rows = nullptr;                       // the packed rows are compact (jlm_pack_t_mixed)
@@ -350,12 +340,17 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
     long n_tiles_all = 0;
     int lds_max = 0, tm_off = 0;
+    bool xbias = false;
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
-        const int nb = (sg.k + 2 + 31) / 32;
-        if (nb > MX_MAX_NB || sg.k % 4 || sg.ldb != 32 * nb || sg.t_off % 4) return -2;
+        const int nb = mx_seg_blocks(sg);
+        if (nb < 1 || nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
         if ((long)(sg.v_end - sg.v_start) * nb * 128 >= (1l << 31)) return -2;        // 32-bit buffer offsets
+        const bool xb = sg.k + 2 > 32 * nb;                  // no bias columns: the biases come from bias2 (base-2 units)
+        if (i == 0) xbias = xb;
+        if (xb != xbias || (xb && (!bias2 || nb % 2))) return -2;      // one form per launch; external-bias bodies exist for even nb
         MxSeg &m = a.seg[i];
+        m.bias2 = xb ? bias2 + sg.v_start : nullptr;
         m.B = reinterpret_cast<const unsigned char *>(sg.B);
         m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
         m.tm_off = tm_off; m.seg = i;
@@ -365,13 +360,13 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         const int mtt = mx_blocks_per_tile(nb);
         ntiles[i] = (m.n_vocab + 32 * mtt - 1) / (32 * mtt);
         if (ntiles[i] > 65535) return -2;
-        const int ns16 = (sg.k + 2 + 15) / 16;
+        const int ns16 = xb ? 2 * nb : (sg.k + 2 + 15) / 16;
         // cost of a tile ~ its matrix instructions (f16 steps + two int8 per 32-k block, per 32-word block) + a per-tile constant,
         // in the units of the split kernel's model (half k-steps of a 128-word tile)
         // measured (kbench, single-segment launches): a 32-word block costs 0.055 us x (its matrix instructions + ~6: combine,
         // fold, block start); here in the split kernel's units (a k-step of a 128-word tile = 12 instructions ~ 2 units)
         ctile[i] = mtt * (ns16 + 2 * nb + 3.0 * c0x2) / 6.0;
-        const int lds_i = 2 * 32 * mtt * nb * 128;
+        const int lds_i = 2 * 32 * mtt * nb * 128 + (xb ? 3 * 32 * mtt * 4 : 0);
         if (lds_i > lds_max) lds_max = lds_i;
         total += ctile[i] * ntiles[i];
         n_tiles_all += ntiles[i];
@@ -440,36 +435,29 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     a.n_sub = n_sub;
     if (n_sub > max_parts) return -1;
     const int lds = lds_max;
-    bool dsoft = true;
+    // which kernel: 0 the D-softmax* shapes (inlined), 1 any other bias-column shape, 2 tied k = 256 (inlined), 3 other external-bias shapes
+    int which = xbias ? 2 : 0;
     for (int i = 0; i < n_segs; ++i) {
         const int nb = a.seg[i].nb, ns16 = (a.seg[i].k + 2 + 15) / 16;
-        dsoft = dsoft && ((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4));
+        if (xbias) { if (nb != 8) which = 3; }
+        else if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4))) which = 1;
     }
-    static int attr[2] = {0, 0};
-    const void *fn = dsoft ? reinterpret_cast<const void *>(MX_KERNEL_DSOFTMAX) : reinterpret_cast<const void *>(MX_KERNEL_GENERIC);
-    if (lds > attr[dsoft]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
-        attr[dsoft] = lds;
+    static int attr[4] = {0, 0, 0, 0};
+    const void *fns[4] = {reinterpret_cast<const void *>(MX_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MX_KERNEL_GENERIC),
+                          reinterpret_cast<const void *>(MX_KERNEL_TIED), reinterpret_cast<const void *>(MX_KERNEL_GENERIC_XB)};
+    if (lds > attr[which]) {
+        if (hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
+        attr[which] = lds;
     }
-    // JLM_MX_ROWS=64: four waves of 64 rows (mx_body2, an experiment: half the LDS reads, and no faster -- 38.1 / 32.8 / 30.8 us
-    // against 32.7 / 29.3 / 26.1 for the three segments alone: one wave per SIMD has nobody to cover its LDS waits and its VALU)
-    static int form = -1;
-    if (form < 0) { const char *e = getenv("JLM_MX_ROWS"); form = (e && atoi(e) == 64) ? 64 : 32; }
-    if (dsoft && form == 64) {
-        static int attr2 = 0;
-        if (lds > attr2) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_mixed2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                return -3;
-            attr2 = lds;
-        }
-        hipLaunchKernelGGL(vocab_lse_mixed2_kernel, dim3(n_cols * n_ptiles), dim3(256), lds, (hipStream_t)stream, a, T, ldt,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
-    } else if (dsoft)
-        hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
-    else
-        hipLaunchKernelGGL(MX_KERNEL_GENERIC, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
-                           reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
+    const dim3 grid(n_cols * n_ptiles), block(512);
+    float2 *part2 = reinterpret_cast<float2 *>(part);
+    hipStream_t st = (hipStream_t)stream;
+    switch (which) {
+    case 0: hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    case 1: hipLaunchKernelGGL(MX_KERNEL_GENERIC, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    case 2: hipLaunchKernelGGL(MX_KERNEL_TIED, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    default: hipLaunchKernelGGL(MX_KERNEL_GENERIC_XB, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return n_sub;

@@ -33,6 +33,7 @@ struct MxSeg {
     int tm_off, seg;             // byte offset of the segment's blocks inside a packed T row; segment number (row scale index)
     float descale;               // 2^-(eT + eB): f32 accumulator -> base-2 logit
     float cs;                    // s_b 2^-11: (row scale s_t x) int accumulator -> the f32 accumulator's units
+    const float *bias2;          // rows WITHOUT bias columns (32 nb < k + 2: k = 256): the words' biases x log2 e, else unused
 };
 
 struct MxArgs {
@@ -44,7 +45,11 @@ struct MxArgs {
 };
 
 // one sub-range (tiles [vt0, vt1) of one segment) for this workgroup's 256 rows; NB 32-k blocks, NS16 f16 steps (2 NB or 2 NB - 1)
-template <int NB, int NS16, int MTT>
+// XBIAS: the rows carry no bias columns (a contraction that fills its last block: the tied k = 256 models); the tile's biases
+// (base-2 units) come into LDS beside it -- one 4-byte DMA per word, three slots: the block awaiting its fold belongs to the tile
+// before the one being multiplied while the tile after it is already landing -- and join the logits in the combine:
+// v = y descale + bias, one VALU instruction per logit more than the column form.
+template <int NB, int NS16, int MTT, bool XBIAS = false>
 __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *__restrict__ T, int ldt,
                                         const int *__restrict__ rows, float2 *__restrict__ part_row, unsigned char *smem) {
     // (T = the PACKED hypothesis rows of jlm_pack_t_mixed, ldt = their stride in 4-byte units; the rows' int8 scales follow the
@@ -54,6 +59,7 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     constexpr int TW = 32 * MTT;                         // words per tile: MTT 32-word blocks (2 at k = 200 ... 8 at k = 50: about the
                                                          // same MFMA count -- and DMA lead time -- per tile whatever the contraction length)
     constexpr int BUFB = TW * ROWB;                      // bytes per LDS buffer
+    constexpr int BIAS_OFF = 2 * BUFB;                   // XBIAS: three slots of TW floats behind the two buffers
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));
     const int tid = tid_, lane = tid & 63;
@@ -105,7 +111,21 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     const int drow = 8 * wave + r8;
     const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
     constexpr int NRG = MTT / 2;                         // row groups (8 rows) per wave and tile: wave, wave + 8, ...
+    __amdgpu_buffer_rsrc_t rs_bias = rs_b;
+    if (XBIAS) {
+        const unsigned long long p2 = reinterpret_cast<unsigned long long>(sg.bias2);
+        const unsigned long long p2u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(p2 >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)p2);
+        rs_bias = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p2u), 0, __builtin_amdgcn_readfirstlane(sg.n_vocab) * 4, 0x00020000);
+    }
     auto issue = [&](int t, int buf) {
+        if (XBIAS && wave == 0) {                         // (words past the segment's end read 0: they are masked anyway)
+#pragma unroll
+            for (int i = 0; i < (TW + 63) / 64; ++i)
+                if (i * 64 + 64 <= TW || lane < TW - i * 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, (__attribute__((address_space(3))) void *)(smem + BIAS_OFF + (t % 3) * (TW * 4) + i * 256),
+                                                             4, (t * TW + i * 64 + lane) * 4, 0, 0, 0);
+        }
         // the row goes into the per-lane offset (the part the hardware range-checks: a row at or past n_vocab reads zeros), the
         // block into the scalar offset
         const int voff = dvoff + t * (TW * ROWB);
@@ -146,14 +166,14 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
             const float t2 = fmaxf(v[2 * pc], v[2 * pc + 1]);
             tmax = pc == 0 ? t2 : fmaxf(tmax, t2);
         } else if (pc == 8) {
-            const float mn = fmaxf(m, tmax * descale);
+            const float mn = fmaxf(m, XBIAS ? tmax : tmax * descale);     // (XBIAS: v is in base-2 logit units already)
             nmn = -mn;
             sc_old = __builtin_amdgcn_exp2f(m - mn);
             m = mn;
             add0 = 0.0f; add1 = 0.0f;
         } else if (pc < 25) {
             const int r = pc - 9;
-            const float e = __builtin_amdgcn_exp2f(fmaf(v[r], descale, nmn));
+            const float e = __builtin_amdgcn_exp2f(XBIAS ? v[r] + nmn : fmaf(v[r], descale, nmn));
             if (r & 1) add1 += e; else add0 += e;
         } else if (pc == 25) {
             s = s * sc_old + (add0 + add1);
@@ -166,15 +186,22 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     f32x16 accf;
     i32x16 acci;
     bool have = false;                                    // accf / acci hold a finished block that is not combined yet
-    int lim_acc = 0, mt_acc = 0;                          // ... of a tile with lim_acc valid words, its block mt_acc
+    int lim_acc = 0, mt_acc = 0, t_acc = 0;               // ... of tile t_acc with lim_acc valid words, its block mt_acc
     // (the mask -- words past the segment's end, zeros from the range-checked DMA -- costs a compare and a select per logit, a
     //  quarter of the block's VALU work: only the tile loop of a segment's last, partial tile carries it)
     auto combine = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value != 0;
         if (MX_ABL & 2) { asm volatile("" :: "v"(accf), "v"(acci)); return; }
+        f32x4 bq[4];
+        if (XBIAS) {
+            const unsigned char *bp = smem + BIAS_OFF + (t_acc % 3) * (TW * 4) + (mt_acc * 32 + 4 * hf) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(bp + q * 32);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float y = fmaf((float)acci[r], csr, accf[r]);
+            float y = fmaf((float)acci[r], csr, accf[r]);
+            if (XBIAS) y = fmaf(y, descale, bq[r >> 2][r & 3]);
             v[r] = (MASKED && mt_acc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim_acc) ? JLM_NEG_BIG : y;
         }
     };
@@ -239,7 +266,7 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
             // pieces the block's instruction count did not reach (short contractions)
 #pragma unroll
             for (int pc = 4 * NB * PP; pc < NPIECE; ++pc) fold_piece(pc);
-            have = true; lim_acc = lim; mt_acc = mt;
+            have = true; lim_acc = lim; mt_acc = mt; t_acc = t;
         }
         // the next tile has landed (this wave's pieces) and every wave is done reading this buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,235 +291,9 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     if (hf == 0 && row_ok) part_row[prow] = make_float2(m, s);
 }
 
-// ------------------------------------------------------------------------------------------------ 64 rows per wave
-// The same sub-range with FOUR waves of 64 rows (two 32-row sets) instead of eight of 32: every vocabulary fragment read from LDS
-// feeds two matrix instructions.  Why: a 32 x 32 block instruction takes 1 KB of vocabulary operand per 32 cycles and SIMD,
-// 128 B per cycle and CU -- all the LDS can deliver; measured on mx_body (kbench, one segment per launch, MX_ABL builds): without any
-// fold 28.7 / 22.8 / 16.5 us at k = 200 / 100 / 50, without the fold AND without the LDS reads 19.4 / 12.5 / 9.2.  One wave per
-// SIMD owns the 512-register file: the two sets' row operands (216 registers at k = 200) sit in the accumulation half (matrix
-// instructions read them from there), and there is room for TWO accumulator sets per row set -- block b's logits are combined and
-// folded between block b + 1's matrix instructions straight from its accumulators (no staging copy, no burst between blocks).
-// Rows past n_paths read row 0's operands and are never written.
-template <int NB, int NS16, int MTT>
-__device__ __forceinline__ void mx_body2(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *__restrict__ T, int ldt,
-                                         float2 *__restrict__ part_row, unsigned char *smem) {
-    static_assert(MTT % 2 == 0, "the accumulator parity of a block is its index in the tile");
-    constexpr float LN2 = 0.6931471805599453f;
-    constexpr int ROWB = NB * 128;
-    constexpr int TW = 32 * MTT;
-    constexpr int BUFB = TW * ROWB;
-    int tid_ = threadIdx.x;
-    asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 3
-    const int hf = lane >> 5, li = lane & 31;
-    // ---- 1. row operands of the wave's two row sets (packed rows are compact: row index = position)
-    f16x8 thi[2][NS16];
-    i32x4 thi8[2][NB], tlo8[2][NB];
-    float csr[2];
-    int prow[2];
-    bool row_ok[2];
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-        prow[rs] = pt * 256 + wave * 64 + rs * 32 + li;
-        row_ok[rs] = prow[rs] < n_paths;
-        const unsigned char *trow = reinterpret_cast<const unsigned char *>(T) + (size_t)(row_ok[rs] ? prow[rs] : 0) * ldt * 4;
-        const unsigned char *tb = trow + sg.tm_off;
-#pragma unroll
-        for (int q = 0; q < NS16; ++q)
-            thi[rs][q] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4 *>(tb + (q >> 1) * 128 + (2 * (q & 1) + hf) * 16));
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            thi8[rs][j] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (4 + hf) * 16);
-            tlo8[rs][j] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (6 + hf) * 16);
-        }
-        csr[rs] = *reinterpret_cast<const float *>(trow + ldt * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sg.seg) * sg.cs;
-    }
-    const float descale = sg.descale;
-
-    // ---- 2. LDS-DMA of a tile: wave w fills row groups w, w + 4, ... (8 rows each) of every block j; same LDS image as mx_body
-    const unsigned long long bptr = reinterpret_cast<unsigned long long>(sg.B);
-    const unsigned long long bptr_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bptr >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)bptr);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0,
-                                                                          __builtin_amdgcn_readfirstlane(sg.n_vocab) * ROWB, 0x00020000);
-    const int r8 = lane >> 3, dslot = lane & 7;
-    const int drow = 8 * wave + r8;
-    const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
-    constexpr int NRG = MTT;                             // row groups per wave and tile
-    auto issue = [&](int t, int buf) {
-        const int voff = dvoff + t * (TW * ROWB);
-#pragma unroll
-        for (int i = 0; i < NRG; ++i) {
-            unsigned char *dst = smem + buf * BUFB + ((wave + 4 * i) * NB) * 1024;
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
-                                                         voff + i * (32 * ROWB), j * 128, 0, 0);
-        }
-    };
-    const int x = (li >> 1) & 7;
-    const int fbase = (li >> 3) * (NB * 1024) + (li & 7) * 128;
-    int goff[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) goff[g4] = fbase + ((2 * g4 + hf) ^ x) * 16;
-
-    // ---- 3. accumulators [parity][row set]; the "previous block" of the very first one: logits of -1e30 (their fold leaves
-    //         (m, s) = (very negative, 16), scaled to nothing by the first real fold)
-    f32x16 accf[2][2];
-    i32x16 acci[2][2];
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accf[1][rs][r] = -1.0e30f; acci[1][rs][r] = 0; }
-    float m[2] = {JLM_NEG_BIG, JLM_NEG_BIG}, s[2] = {0.0f, 0.0f};
-    float tmax[2], nmn[2], sc_old[2], add0[2], add1[2];
-    int thr = 1 << 30;                                   // words of the block being folded that exist, minus 4 hf (masked form)
-    constexpr int NMF = 2 * (NS16 + 2 * NB);             // matrix instructions of a 64-row block
-    constexpr int NPC1 = 16 + 8 + 1 + 16 + 1;            // pieces per row set: 16 combine, 8 max, 1, 16 exp, 1
-    constexpr int NPIECE = 2 * NPC1;
-    constexpr int LAG = 2;
-    constexpr int PP = (NPIECE + NMF - LAG - 1) / (NMF - LAG);
-    // piece p of the block with accumulator parity P: row set p & 1, step p >> 1
-    auto fold_piece = [&](auto masked_c, auto par_c, int p) {
-        constexpr bool MASKED = decltype(masked_c)::value != 0;
-        constexpr int P = decltype(par_c)::value;
-        if (MX_ABL & 1) { if (p == 0) asm volatile("" :: "v"(accf[P][0]), "v"(accf[P][1]), "v"(acci[P][0]), "v"(acci[P][1])); return; }
-        const int rs = p & 1, pc = p >> 1;
-        if (pc < 16) {
-            const int r = pc;
-            float y = fmaf((float)acci[P][rs][r], csr[rs], accf[P][rs][r]);
-            if (MASKED) y = ((r & 3) + 8 * (r >> 2) >= thr) ? JLM_NEG_BIG : y;
-            accf[P][rs][r] = y;
-        } else if (pc < 24) {
-            const int q = pc - 16;
-            const float t2 = fmaxf(accf[P][rs][2 * q], accf[P][rs][2 * q + 1]);
-            tmax[rs] = q == 0 ? t2 : fmaxf(tmax[rs], t2);
-        } else if (pc == 24) {
-            const float mn = fmaxf(m[rs], tmax[rs] * descale);
-            nmn[rs] = -mn;
-            sc_old[rs] = __builtin_amdgcn_exp2f(m[rs] - mn);
-            m[rs] = mn;
-            add0[rs] = 0.0f; add1[rs] = 0.0f;
-        } else if (pc < 41) {
-            const int r = pc - 25;
-            const float e = __builtin_amdgcn_exp2f(fmaf(accf[P][rs][r], descale, nmn[rs]));
-            if (r & 1) add1[rs] += e; else add0[rs] += e;
-        } else {
-            s[rs] = s[rs] * sc_old[rs] + (add0[rs] + add1[rs]);
-        }
-    };
-    issue(vt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    int thr_next = 1 << 30;
-    auto tile = [&](auto masked_c, int t) {
-        if (!(MX_ABL & 4) && t + 1 < vt1) issue(t + 1, buf ^ 1);
-        const int lim = sg.n_vocab - t * TW;               // valid words of this tile
-        i32x4 F[4];
-        {
-            const unsigned char *bs0 = smem + buf * BUFB;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) F[g4] = *reinterpret_cast<const i32x4 *>(bs0 + goff[g4]);
-        }
-        mx_for_each_ic([&](auto mtc) {
-            constexpr int mt = decltype(mtc)::value;
-            constexpr int Q = mt & 1;                      // this block's accumulators; the pieces fold parity 1 - Q
-            using PAR = IC<1 - Q>;
-            const unsigned char *bs = smem + buf * BUFB + mt * (4 * NB * 1024);
-            thr = thr_next;                                // of the block being folded now
-            thr_next = lim - mt * 32 - 4 * hf;             // of this block, folded during the next one
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const i32x16 zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            auto rd = [&](int g4, int j) {
-                if (MX_ABL & 32) return;
-                if (j < NB) F[g4] = *reinterpret_cast<const i32x4 *>(bs + j * 1024 + goff[g4]);
-                else if (mt + 1 < MTT) F[g4] = *reinterpret_cast<const i32x4 *>(bs + (4 * NB * 1024) + goff[g4]);
-            };
-            mx_for_each_ic([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                constexpr bool second = 2 * J + 1 < NS16;
-                constexpr bool rdm = (J + 1 < NB) || (mt + 1 < MTT);
-                constexpr int NM = second ? 8 : 6;         // matrix instructions of this 32-k block (both row sets)
-                constexpr int M0 = J * 8;                  // ... and those before it in the 64-row block (every earlier J has 8)
-                // (the first LAG units of a block carry nothing: the previous block's last matrix instructions are still in the pipe
-                //  and reading their accumulators would stall the wave 8 + cycles)
-                auto pieces = [&](int q) {
-#pragma unroll
-                    for (int p = (M0 + q - LAG) * PP; p < (M0 + q - LAG + 1) * PP && p < NPIECE; ++p)
-                        if (p >= 0) fold_piece(masked_c, PAR{}, p);
-                };
-                constexpr int QA = second ? 6 : 4;         // index of the block's last int8 pair among its matrix instructions
-                // a unit = one matrix instruction, (behind every second one) the read that refills its fragment, its share of the
-                // fold; units stay in program order (sched_barrier), inside a unit: matrix instruction, read, VALU.  Consecutive
-                // instructions never share an accumulator: f16 set 0, f16 set 1, int8 set 0, int8 set 1 (left to its own choice the
-                // scheduler puts dependent ones back to back -- with ONE wave per SIMD nothing covers the 16-pass wait)
-                auto unit_end = [&](bool read) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (read) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (!(MX_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 4 * PP, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                accf[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[0]), thi[0][2 * J], J == 0 ? zf : accf[Q][0], 0, 0, 0);
-                pieces(0);
-                unit_end(false);
-                accf[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[0]), thi[1][2 * J], J == 0 ? zf : accf[Q][1], 0, 0, 0);
-                rd(0, J + 1);
-                pieces(1);
-                unit_end(rdm);
-                acci[Q][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], tlo8[0][J], J == 0 ? zi : acci[Q][0], 0, 0, 0);
-                pieces(2);
-                unit_end(false);
-                acci[Q][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], tlo8[1][J], J == 0 ? zi : acci[Q][1], 0, 0, 0);
-                rd(2, J + 1);
-                pieces(3);
-                unit_end(rdm);
-                if constexpr (second) {
-                    accf[Q][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[1]), thi[0][second ? 2 * J + 1 : 0], accf[Q][0], 0, 0, 0);
-                    pieces(4);
-                    unit_end(false);
-                    accf[Q][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[1]), thi[1][second ? 2 * J + 1 : 0], accf[Q][1], 0, 0, 0);
-                    rd(1, J + 1);
-                    pieces(5);
-                    unit_end(rdm);
-                } else {
-                    rd(1, J + 1);
-                }
-                acci[Q][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[3], thi8[0][J], acci[Q][0], 0, 0, 0);
-                pieces(QA);
-                unit_end(!second && rdm);
-                acci[Q][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[3], thi8[1][J], acci[Q][1], 0, 0, 0);
-                rd(3, J + 1);
-                pieces(QA + 1);
-                unit_end(rdm);
-            }, std::make_integer_sequence<int, NB>{});
-            __builtin_amdgcn_sched_barrier(0);
-            // pieces the block's instruction count did not reach
-#pragma unroll
-            for (int p = (NMF - LAG) * PP; p < NPIECE; ++p) fold_piece(masked_c, PAR{}, p);
-        }, std::make_integer_sequence<int, MTT>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(MX_ABL & 8)) __builtin_amdgcn_s_barrier();
-        buf ^= 1;
-    };
-    // every tile but a segment's last is whole: its folds need no mask
-    const int t_full = min(vt1, sg.n_vocab / TW);
-    for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, t);
-    for (int t = max(vt0, t_full); t < vt1; ++t) tile(IC<1>{}, t);
-    // the last block (parity 1)
-    thr = thr_next;
-#pragma unroll
-    for (int p = 0; p < NPIECE; ++p) fold_piece(IC<1>{}, IC<1>{}, p);
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-        float mm = m[rs], ss = s[rs];
-        const float m2 = __shfl_xor(mm, 32), s2 = __shfl_xor(ss, 32);
-        const float mx = fmaxf(mm, m2);
-        ss = ss * __builtin_amdgcn_exp2f(mm - mx) + s2 * __builtin_amdgcn_exp2f(m2 - mx);
-        if (hf == 0 && row_ok[rs]) part_row[prow[rs]] = make_float2(mx * LN2, ss);
-    }
-}
+// (Round 3 also tried FOUR waves of 64 rows -- two 32-row sets per wave, every fragment feeding two matrix instructions, one wave per
+//  SIMD owning the 512-register file with two accumulator sets: half the LDS reads, and no faster: 38.1 / 32.8 / 30.8 us against
+//  32.7 / 29.3 / 26.1 for the k = 200 / 100 / 50 segments alone.  With nobody to cover them the wave's LDS waits, the ~60 cycles each
+//  LDS-DMA instruction costs to issue and its VALU stream are all exposed.  DESIGN.md 6c.2; the code is in the history: mx_body2.)
 
 }  // namespace jlm_mx

@@ -1039,7 +1039,7 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
             jlm_mx::MxSeg &m = h.mx[i];
             m.B = reinterpret_cast<const unsigned char *>(mixed[i].B);
             m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
-            m.tm_off = tm_off; m.seg = n_mixed++;
+            m.tm_off = tm_off; m.seg = n_mixed++; m.bias2 = nullptr;
             m.descale = mx_descale[i];
             m.cs = mx_s8[i] * (1.0f / 2048.0f);
             const int mtt = jlm_mx::mx_blocks_per_tile(nb);

@@ -160,6 +160,7 @@ struct JlmModel : torch::CustomClassHolder {
             }
             m.mixed_segs = mixed.data(); m.mixed_t_scale = mx_t_scale.data(); m.mixed_descale = mx_descale.data();
             m.mixed_s8 = mx_s8.data();
+            m.mixed_bias2 = tptr<const float>(tensors, "b2_log2");
         }
         TORCH_CHECK(m.b2 && m.n_segs >= 1 && m.H > 0, "jlm.Model: b2, the segments and H are required");
         TORCH_CHECK(!m.split_lstm || (m.wt8 && m.xgate8 && (m.pmt_split || m.untied)), "jlm.Model: split_lstm needs wt8, xgate8, pmt_split");
@@ -379,7 +380,8 @@ void pack_mixed(const Tensor &src, int64_t src_off, int64_t rows, int64_t k, int
                 double bias_scale, double s8, const Tensor &dst, int64_t ld_dst) {
     TORCH_CHECK(src_off >= 0 && rows >= 0 && (rows == 0 || src_off + (rows - 1) * ld + k <= src.numel()), "jlm.pack_mixed: source range");
     TORCH_CHECK(bias_off >= 0 && bias_off + rows <= bias.numel(), "jlm.pack_mixed: bias range");
-    TORCH_CHECK(ld_dst % 32 == 0 && ld_dst >= (k + 2 + 31) / 32 * 32 && rows * ld_dst <= dst.numel(), "jlm.pack_mixed: destination shape");
+    TORCH_CHECK(ld_dst % 32 == 0 && (ld_dst == (k + 2 + 31) / 32 * 32 || ld_dst == (k + 31) / 32 * 32) && rows * ld_dst <= dst.numel(),
+                "jlm.pack_mixed: destination shape");
     jlm_check(jlm_pack_mixed(ptr<const float>(src, "src") + src_off, (int)rows, (int)k, (int)ld, ptr<const float>(bias, "bias") + bias_off,
                              (float)scale, (float)bias_scale, (float)s8, ptr<void>(dst, "dst"), (int)ld_dst, stream_of(src)),
               "jlm_pack_mixed");

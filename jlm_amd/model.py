@@ -283,7 +283,7 @@ class DeviceModel:
         if self.precision not in ("f16x3", "f32"):
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
-        self.mixed_idx, self.ld_tm = [], 0
+        self.mixed_idx, self.ld_tm, self.b2_log2 = [], 0, None
         self.split_lstm = False
         self.um_split = None
         if self.precision == "f16x3" and (self.stationary_ok or self.mode == "untied"):
@@ -397,21 +397,28 @@ class DeviceModel:
         if os.environ.get("JLM_LSE_MIXED", "1") == "0" or self.self_norm:
             return
         torch, O = self.torch, _ops.backend()
-        take = []
+        take, xbias = [], set()
         for i, sg in enumerate(self.segments):
             nv, k = sg["v_end"] - sg["v_start"], sg["k"]
             if nv > 0 and ((k + 2 + 31) // 32, (k + 2 + 15) // 16) in self.MIXED_SHAPES:
                 take.append(i)
+            elif nv > 0 and k % 64 == 0 and k <= 256:
+                # a contraction that fills its last block (tied k = 256): no columns left for the bias -- rows of k / 32 blocks, the
+                # biases (x log2 e) go to the kernel separately (jlm_vocab_lse_mixed, bias2)
+                take.append(i)
+                xbias.add(i)
             elif not (nv > 0 and k <= 64 and self.split_bias_col[i] == k):
                 return
-        if not take:
+        if not take or (xbias and len(xbias) != len(self.segments)):      # (one bias form per launch)
             return
         LOG2E = 1.4426950408889634
         for i in take:
             sg = self.segments[i]
             nv, k = sg["v_end"] - sg["v_start"], sg["k"]
-            nb = (k + 2 + 31) // 32
-            bmax = max(float(self.seg_B[i].abs().max().item()), float(self.b2[sg["v_start"]:sg["v_end"]].abs().max().item()) * LOG2E)
+            nb = k // 32 if i in xbias else (k + 2 + 31) // 32
+            bmax = float(self.seg_B[i].abs().max().item())
+            if i not in xbias:
+                bmax = max(bmax, float(self.b2[sg["v_start"]:sg["v_end"]].abs().max().item()) * LOG2E)
             eB = pow2_below(2.0 ** 14, bmax)
             hmax = float((self.seg_B[i] * float(2.0 ** eB)).to(torch.float16).to(torch.float32).abs().max().item())
             s8 = 2.0 ** int(np.ceil(np.log2(max(hmax, 2.0 ** -100) / 127.0)))
@@ -426,6 +433,7 @@ class DeviceModel:
             self.mixed_t_scale.append(2.0 ** eT)
             self.mixed_descale.append(2.0 ** -(eT + eB))
             self.mixed_s8.append(s8)
+        self.b2_log2 = (self.b2 * LOG2E).contiguous() if xbias else None
         # stride of the packed hypothesis rows (jlm_mixed_t_stride): the segments' 128-byte blocks + JLM_MAX_SEGMENTS scale floats
         nbytes = sum(msg["ldb"] * 4 for msg in self.mixed_segments) + 4 * 8
         self.ld_tm = (nbytes + 15) // 16 * 4
@@ -445,6 +453,8 @@ class DeviceModel:
         if d is None:
             O = _ops.backend()
             t = dict(b2=self.b2, emb=self.emb, wt=self.wt, gate_bias=self.gate_bias)
+            if getattr(self, "b2_log2", None) is not None:
+                t["b2_log2"] = self.b2_log2
             i = dict(H=self.H, ldt=self.ldt, untied=int(self.mode == "untied"), self_norm=int(self.self_norm),
                      split_lstm=int(self.split_lstm), ld_emb=self.Epad, kpad=self.kpad, E=self.Epad,
                      n_t=(self.pmt.shape[0] if self.pmt is not None else 0))

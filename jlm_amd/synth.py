@@ -236,6 +236,7 @@ def build_fixture(root, name, exp_id=1):
       small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
       wide-{vtable,dsoftmax}                      V=2000 H=64, segments 200 / 100 / 50 (the mixed-row shapes, small vocabulary)
       wideh-vtable                                 the same with 200 / 100 / 36: the hybrid launch (mixed + split rows)
+      wide128-tied                                 tied, E = 128: mixed rows without bias columns (the form of the tied k = 256 models)
       mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
     """
@@ -249,6 +250,9 @@ def build_fixture(root, name, exp_id=1):
     elif size == "wide":
         scale = 0.1
         V, H, E, segs, alphabet = 2000, 64, 200, wide_segs(2000), 12
+    elif size == "wide128":             # tied, embedding 128: a contraction that fills its last block (biases outside the rows)
+        scale = 0.12
+        V, H, E, segs, alphabet = 2000, 64, 128, small_segs(2000), 12
     elif size == "wideh":
         scale = 0.1
         V, H, E, segs, alphabet = 2000, 64, 200, wideh_segs(2000), 12

@@ -170,7 +170,7 @@ class FakeLib:
                     bound = B if f == 0 else rmax
                     r = -2
                     if all_mixed:
-                        r = self.jlm_vocab_lse_mixed(m.mixed_segs, m.mixed_descale, m.mixed_s8, m.n_segs, p.Tm, p.ld_tm, p.part, rmax,
+                        r = self.jlm_vocab_lse_mixed(m.mixed_segs, m.mixed_descale, m.mixed_s8, m.mixed_bias2, m.n_segs, p.Tm, p.ld_tm, p.part, rmax,
                                                      p.max_parts, bound, ndev, stream)
                     elif hybrid:
                         r = self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs,
@@ -515,18 +515,20 @@ class FakeLib:
 
     def jlm_pack_mixed(self, src, rows, k, ld, bias, scale, bias_scale, s8, dst, ld_dst, stream):
         nb = ld_dst // 32
-        if rows < 0 or k <= 0 or ld < k or ld_dst % 32 or nb * 32 < k + 2 or nb > 8:
+        if rows < 0 or k <= 0 or ld < k or ld_dst % 32 or nb not in ((k + 2 + 31) // 32, (k + 31) // 32) or nb > 8:
             return -1
+        cols = k + 2 <= 32 * nb                    # room for the bias columns
         if rows == 0:
             return 0
         flat = view(src, (rows - 1) * ld + k, np.float32)
         x = np.zeros((rows, 32 * nb), dtype=np.float32)
         x[:, :k] = np.lib.stride_tricks.as_strided(flat, shape=(rows, k), strides=(4 * ld, 4)) * np.float32(scale)
         hi, h8, l8 = self._quant(x, np.float32(s8))
-        xb = (view(bias, rows, np.float32) * np.float32(bias_scale)) if _p(bias) else np.zeros(rows, dtype=np.float32)
-        bh = xb.astype(np.float16)
-        hi[:, k] = bh
-        hi[:, k + 1] = ((xb - bh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        if cols:
+            xb = (view(bias, rows, np.float32) * np.float32(bias_scale)) if _p(bias) else np.zeros(rows, dtype=np.float32)
+            bh = xb.astype(np.float16)
+            hi[:, k] = bh
+            hi[:, k + 1] = ((xb - bh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
         h8[:, k:] = 0
         l8[:, k:] = 0
         vh, v8, vl = self._mixed_view(dst, rows, nb)
@@ -538,7 +540,10 @@ class FakeLib:
     def jlm_mixed_t_stride(self, segs, n_segs):
         if n_segs < 1 or n_segs > 8:
             return -1
-        b = sum((segs[i].k + 2 + 31) // 32 * 128 for i in range(n_segs))
+        for i in range(n_segs):
+            if segs[i].ldb % 32 or segs[i].ldb // 32 not in ((segs[i].k + 2 + 31) // 32, (segs[i].k + 31) // 32):
+                return -1
+        b = sum(segs[i].ldb * 4 for i in range(n_segs))
         return (b + 4 * 8 + 15) // 16 * 4
 
     def jlm_pack_t_mixed(self, segs, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream):
@@ -554,7 +559,7 @@ class FakeLib:
         scales = view(_p(Tm), n * ld_tm, np.float32).reshape(n, ld_tm)[:, ld_tm - 8:]
         for i in range(n_segs):
             sg = segs[i]
-            nb = (sg.k + 2 + 31) // 32
+            nb = sg.ldb // 32
             Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g])
             x = np.zeros((n, 32 * nb), dtype=np.float32)
             x[:, :sg.k] = Tv * np.float32(float(t_scale[i]) * 1.4426950408889634)
@@ -562,8 +567,9 @@ class FakeLib:
             with np.errstate(divide="ignore"):
                 s_t = np.where(amax > 0, np.exp2(np.ceil(np.log2(np.maximum(amax, 1e-37) / 127.0))), 1.0).astype(np.float32)
             hi, h8, l8 = self._quant(x, s_t[:, None])
-            hi[:, sg.k] = np.float16(t_scale[i])
-            hi[:, sg.k + 1] = np.float16(float(t_scale[i]) / 2048.0)
+            if sg.k + 2 <= 32 * nb:
+                hi[:, sg.k] = np.float16(t_scale[i])
+                hi[:, sg.k + 1] = np.float16(float(t_scale[i]) / 2048.0)
             h8[:, sg.k:] = 0
             l8[:, sg.k:] = 0
             vh, v8, vl = self._mixed_view(_p(Tm) + off, n, nb, ld_tm * 4)
@@ -574,7 +580,7 @@ class FakeLib:
             off += nb * 128
         return 0
 
-    def _mixed_logits(self, sg, Tm, ld_tm, tm_off, slot, n, descale, s8):
+    def _mixed_logits(self, sg, Tm, ld_tm, tm_off, slot, n, descale, s8, bias2=None):
         """base-e logits [n, words] of a mixed segment: (hi.hi in f16 products + int8 cross terms x s_t s8 / 2048) descale ln 2"""
         nb, nv = sg.ldb // 32, sg.v_end - sg.v_start
         f = lambda v, dt: np.ascontiguousarray(v).view(dt).reshape(v.shape[0], -1).astype(np.float64)
@@ -584,17 +590,22 @@ class FakeLib:
         main = f(th, np.float16) @ f(bh, np.float16).T
         cross = f(t8, np.int8) @ f(bl, np.int8).T + f(tl, np.int8) @ f(b8, np.int8).T
         y2 = (main + cross * (s_t * (float(s8) / 2048.0))[:, None]).astype(np.float32) * np.float32(descale)
+        if sg.k + 2 > 32 * nb:                       # no bias columns: the biases (base-2 units) come separately
+            y2 = y2 + view(_p(bias2) + 4 * sg.v_start, nv, np.float32)[None, :]
         return y2.astype(np.float64) * 0.6931471805599453
 
-    def jlm_vocab_lse_mixed(self, segs, descale, s8, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream):
+    def jlm_vocab_lse_mixed(self, segs, descale, s8, bias2, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream):
         if n_segs < 1 or n_segs > max_parts or ld_tm != self.jlm_mixed_t_stride(segs, n_segs):
             return -1
+        xb = [segs[i].k + 2 > segs[i].ldb for i in range(n_segs)]
+        if any(xb) and (not all(xb) or not _p(bias2) or any((segs[i].ldb // 32) % 2 for i in range(n_segs))):
+            return -2
         n = _n(n_rows_max, n_dev)
         pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
         off = 0
         for i in range(n_segs):
             if n:
-                y = self._mixed_logits(segs[i], Tm, ld_tm, off, i, n, descale[i], s8[i])
+                y = self._mixed_logits(segs[i], Tm, ld_tm, off, i, n, descale[i], s8[i], bias2)
                 mx = y.max(axis=1)
                 pv[i, :n, 0] = mx
                 pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
@@ -969,6 +980,7 @@ class _FakeModel:
             m.mixed_t_scale = ctypes.cast(self.mts, ctypes.POINTER(ctypes.c_float))
             m.mixed_descale = ctypes.cast(self.mds, ctypes.POINTER(ctypes.c_float))
             m.mixed_s8 = ctypes.cast(self.ms8, ctypes.POINTER(ctypes.c_float))
+            m.mixed_bias2 = ptr("b2_log2")
 
 
 class _FakePlan:

@@ -132,7 +132,8 @@ def test_f32_pipe_path_agrees_with_split_path(fixture, fx, monkeypatch):
         np.testing.assert_allclose([v for v, _ in x], [v for v, _ in y], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("fixture,n_sent,beam", [("wide-vtable", 12, 7), ("wide-dsoftmax", 12, 7), ("wideh-vtable", 12, 7), ("mid-vtable", 64, 10)])
+@pytest.mark.parametrize("fixture,n_sent,beam", [("wide-vtable", 12, 7), ("wide-dsoftmax", 12, 7), ("wideh-vtable", 12, 7), ("wide128-tied", 12, 7),
+                                                 ("mid-vtable", 64, 10), ("mid-tied", 64, 10)])
 def test_mixed_rows_normaliser_agrees_with_split_rows(fixture, n_sent, beam, fx, monkeypatch):
     """Segments of width 200 / 100 / 50 run the full-vocabulary normaliser on mixed rows (f16 hi.hi + int8 cross terms,
     jlm_pack_t_mixed + jlm_vocab_lse_mixed, include/jlm_hip.h ABI 7) by default; JLM_LSE_MIXED=0 keeps every segment on its
@@ -146,6 +147,8 @@ def test_mixed_rows_normaliser_agrees_with_split_rows(fixture, n_sent, beam, fx,
     mixed = _decoder(f, "static")
     if fixture.startswith("wideh"):          # the short last segment stays on split rows: jlm_vocab_lse_hybrid
         assert mixed.model.dev.mixed_idx == [0, 1] and mixed.model.dev.ld_tm == 360
+    elif fixture.endswith("-tied"):          # a contraction that fills its last block: biases outside the rows (k = 128, 256)
+        assert mixed.model.dev.mixed_idx == [0] and mixed.model.dev.b2_log2 is not None
     else:
         assert mixed.model.dev.mixed_idx == [0, 1, 2] and mixed.model.dev.ld_tm == 424
     a = mixed.decode_batch(sents, beam_width=beam)

@@ -806,11 +806,11 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
         B_np = (rng.standard_normal((nv, k)) * 0.08).astype(np.float32)
         Bs.append(B_np)
         Bg = torch.as_tensor(B_np).cuda()
-        bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427)
+        bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427 if k % 32 else 0.0)
         eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
         hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
         s_b = 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
-        nb = (k + 2 + 31) // 32
+        nb = k // 32 if k % 32 == 0 else (k + 2 + 31) // 32          # a contraction that fills its last block: no bias columns
         dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device="cuda")
         assert L.jlm_pack_mixed(Bg.data_ptr(), nv, k, k, b2.data_ptr() + 4 * bounds[i], 2.0 ** eB, 2.0 ** eB * 1.4426950408889634,
                                 s_b, dst.data_ptr(), 32 * nb, _st()) == 0
@@ -822,7 +822,9 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
 
 
 @pytest.mark.parametrize("V,widths,bounds,R", [(3000, [200, 100, 52], [0, 700, 1900, 3000], 300), (50000, [200, 100, 52], [0, 12000, 30000, 50000], 2560),
-                                               (777, [64], [0, 777], 40), (5000, [252], [0, 5000], 513), (1000, [4, 36], [0, 300, 1000], 33)])
+                                               (777, [60], [0, 777], 40), (5000, [252], [0, 5000], 513), (1000, [4, 36], [0, 300, 1000], 33),
+                                               # contractions that fill their last block: biases from bias2 (tied k = 256; k = 128 / 64)
+                                               (50000, [256], [0, 50000], 2560), (4001, [256], [0, 4001], 300), (3000, [128, 64], [0, 1700, 3000], 70)])
 def test_vocab_lse_mixed(L, V, widths, bounds, R):
     """jlm_vocab_lse_mixed (f16 hi.hi + int8 cross terms, csrc/jlm_mixed.hip): log-sum-exp of T.B^T + b2 over the vocabulary
     against the f64 evaluation of the f32 operands; the logits behind it are good to ~1e-5 of the row's logit scale (a one-word
@@ -830,6 +832,8 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     rng = np.random.default_rng(V + R)
     b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
     segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    b2l = (b2 * 1.4426950408889634).contiguous()
+    bias2 = b2l.data_ptr() if widths[0] % 32 == 0 else None
     G = R + 9
     T_np = (np.tanh(rng.standard_normal((G, ldt))) * rng.uniform(0.05, 1.0, size=(G, 1))).astype(np.float32)
     T = torch.as_tensor(T_np).cuda()
@@ -840,7 +844,7 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
     Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
     assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
-    n = L.jlm_vocab_lse_mixed(segs, ds, s8, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
+    n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
     assert n >= len(widths), n
     torch.cuda.synchronize()
     p = part[:n, :R - 2].cpu().numpy().astype(np.float64)
@@ -865,7 +869,7 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
             Tm1 = torch.zeros((R, ld1), dtype=torch.float32, device="cuda")
             assert L.jlm_pack_t_mixed(one, (ctypes.c_float * 1)(ts[i]), 1, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
                                       Tm1.data_ptr(), ld1, _st()) == 0
-            n1 = L.jlm_vocab_lse_mixed(one, (ctypes.c_float * 1)(ds[i]), (ctypes.c_float * 1)(s8[i]), 1,
+            n1 = L.jlm_vocab_lse_mixed(one, (ctypes.c_float * 1)(ds[i]), (ctypes.c_float * 1)(s8[i]), bias2, 1,
                                        Tm1.data_ptr(), ld1, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
             assert n1 == 1
             torch.cuda.synchronize()

@@ -284,7 +284,7 @@ def test_beams_above_one_wave(fx, fake, name, kind, kw):
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax", "wideh-vtable"])
+@pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax", "wideh-vtable", "wide128-tied"])
 def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     """Segments of width 200 / 100 / 50 get mixed rows at load (DeviceModel._build_mixed), the plan its packed-row buffer, and the
     frame loop packs the live rows and calls the hybrid normaliser (include/jlm_hip.h ABI 7); results as the oracle's, and as
@@ -310,6 +310,9 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     if name.startswith("wideh"):
         assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
         assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128]
+    elif name == "wide128-tied":      # k = 128 fills its four blocks: no bias columns, the biases travel as b2_log2
+        assert m.mixed_idx == [0] and m.ld_tm == (4 * 128 + 32) // 4 and m.mixed_segments[0]["ldb"] == 128
+        assert m.b2_log2 is not None
     else:
         assert m.mixed_idx == [0, 1, 2] and m.ld_tm == (7 * 128 + 4 * 128 + 2 * 128 + 32) // 4
         assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128, 64]

@@ -137,7 +137,7 @@ def bench_lse_mixed(V, widths, R, tag):
     b2 = rnd(V, scale=0.05)
     for i, k in enumerate(widths):
         kp = (k + 3) // 4 * 4
-        nb = (kp + 2 + 31) // 32
+        nb = kp // 32 if kp % 32 == 0 else (kp + 2 + 31) // 32       # (k a multiple of 32: no bias columns, biases from bias2)
         nv = bounds[i + 1] - bounds[i]
         Bm = rnd(nv, kp, scale=0.05)
         dst = torch.zeros((nv, 32 * nb), device=dev)
@@ -148,6 +148,8 @@ def bench_lse_mixed(V, widths, R, tag):
         ts[i], ds[i], s8[i] = 2.0 ** 10, 2.0 ** -25, 2.0 ** 7
         off += kp
         flops += 2.0 * k * nv * R
+    b2l = b2 * 1.4426950408889634
+    bias2 = b2l.data_ptr() if widths[0] % 32 == 0 else None
     T = rnd(R, off)
     part = torch.empty((96, R, 2), device=dev)
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
@@ -156,7 +158,7 @@ def bench_lse_mixed(V, widths, R, tag):
     Tm = torch.zeros((R, ld_tm), device=dev)
     g = lambda: L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
-    f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
+    f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
     print("parts:", f())
     report("vocab_lse_mixed      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
     report("pack_t_mixed         %s R=%d" % (tag, R), 1.0, timeit(g))
@@ -332,6 +334,8 @@ if __name__ == "__main__":
                 bench_lse_mixed(V1, [k1], R, "seg-k%d" % k1)
         bench_lse_stat(50000, [256], R, "tied50k")
         bench_lse_split(50000, [256], R, "tied50k")
+        bench_lse_mixed(50000, [252], R, "tied50k")          # (the widest contraction with room for the bias columns: nb = 8)
+        bench_lse_mixed(50000, [256], R, "tied50k")          # the tied shape: biases from bias2
         bench_lse(12000, 200, R, "seg0")
         bench_lse(18000, 100, R, "seg1")
         bench_lse(20000, 50, R, "seg2")
@@ -348,5 +352,6 @@ if __name__ == "__main__":
     bench_lse(100000, 256, 20480, "tied100k-b20")
     bench_lse_stat(100000, [256], 20480, "tied100k-b20")
     bench_lse_split(100000, [256], 20480, "tied100k-b20")
+    bench_lse_mixed(100000, [256], 20480, "tied100k-b20")
     bench_gemm(4096, 4096, 4096, "square")
     bench_gemm_split(4096, 4096, 4096, "square")

@@ -1,5 +1,5 @@
 """Shader clock and workgroup durations of jlm_vocab_lse_mixed (a -DJLM_WGTIME build: JLM_HIP_LIB=build_prof/libjlm_hip_wgtime.so).
-Usage: python tools/probes/mixed_clock.py [k ...]   (one single-segment launch per k; JLM_MX_ROWS=32|64 picks the body)"""
+Usage: python tools/probes/mixed_clock.py [k ...]   (one single-segment launch per k)"""
 import ctypes, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -26,7 +26,7 @@ for k in ks:
     assert L.jlm_pack_t_mixed(seg, ts, 1, T.data_ptr(), kp, None, R, None, Tm.data_ptr(), ld_tm, None) == 0
     part = torch.empty((96, R, 2), device=dev)
     for _ in range(20):
-        n = L.jlm_vocab_lse_mixed(seg, ds, s8, 1, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, None, None)
+        n = L.jlm_vocab_lse_mixed(seg, ds, s8, None, 1, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, None, None)
     torch.cuda.synchronize()
     buf = np.zeros((1024, 4), dtype=np.uint64)
     assert L.jlm_prof_read_wg_mx(buf.ctypes.data) == 0
