@@ -95,9 +95,9 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     }
     const float csr = s_t * sg.cs;
     const float descale = sg.descale;
-    // (tried: starting the int accumulator at 0x4B400000 so that its bits read as the float 12582912 + sum, no v_cvt_f32_i32 per
-    //  logit -- the constant leaves again in the fold's offset.  Correct, and SLOWER: 29.9 vs 29.3 us at k = 100, 26.8 vs 26.1 at
-    //  k = 50 -- the block's first int8 instruction then reads its 16 accumulator inputs from registers instead of the inline 0)
+    // (tried: starting the int accumulator at 0x4B400000 so that its bits read as the float 12582912 + sum -- no v_cvt_f32_i32 per
+    //  logit, the constant leaves again in the fold's offset.  Interleaved A/B of two builds: 29.5 -> 28.5 us at k = 100, 26.4 -> 25.3
+    //  at k = 50, and nothing on the three-segment launch (69.0 vs 69.5 us); not kept.)
 
     // ---- 2. LDS-DMA of a tile: wave w fills row group w (8 rows) of every block j: one 1-KB piece per (w, j), lane = (row lane >> 3,
     //         slot lane & 7), source granule = slot ^ ((row >> 1) & 7) (the swizzle sits on the source, the LDS image is lane-linear)
