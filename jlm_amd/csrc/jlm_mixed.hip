@@ -366,6 +366,9 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         // measured (kbench, single-segment launches): a 32-word block costs 0.055 us x (its matrix instructions + ~6: combine,
         // fold, block start); here in the split kernel's units (a k-step of a 128-word tile = 12 instructions ~ 2 units)
         ctile[i] = mtt * (ns16 + 2 * nb + 3.0 * c0x2) / 6.0;
+        // (per-shape block costs fitted to single-segment launches -- 2.15 : 1.28 : 1 for k = 200 / 100 / 50 -- cut the three-segment
+        //  launch WORSE than this formula's 1.95 : 1.35 : 1 (72.6 vs 70.5 us); what is left between the columns is the XCDs' clocks:
+        //  equal cycles per workgroup within 2 %, 1.81-1.92 GHz from XCD to XCD on one chip -- tools/probes/mixed_wg_timeline.py)
         const int lds_i = 2 * 32 * mtt * nb * 128 + (xb ? 3 * 32 * mtt * 4 : 0);
         if (lds_i > lds_max) lds_max = lds_i;
         total += ctile[i] * ntiles[i];
