@@ -169,7 +169,7 @@ class Decoder():
 
         def prepare(idx):
             """host side of one chunk: lattice (native, releases the GIL) and, for vocab_select, its word lists"""
-            lat = BatchLattice(self._builder, [inputs[j] for j in idx], beam_width)
+            lat = BatchLattice(self._builder, [inputs[j] for j in idx], beam_width, pool=self._engine.staging_pool)
             self._check_cells(lat, idx, beam_width)
             if not vocab_select:
                 return idx, lat, None, None
@@ -181,6 +181,8 @@ class Decoder():
         def finish(idx, ticket):
             for j, r in zip(idx, self._engine.collect(ticket)):
                 out[j] = r
+            if ticket[1] is not self.last_lattice:        # (the lattice the caller may still look at keeps its arrays)
+                ticket[1].release()
             self._log_perf()
 
         def submit(item):

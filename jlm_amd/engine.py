@@ -61,8 +61,11 @@ def _round_up(x, m):
 class _Plan:
     """Device buffers of one decode shape + their torch.classes.jlm.Plan (the C structs of include/jlm_hip.h)."""
 
-    INT_ARRAYS = ("sent_len", "end_off", "node_start", "node_word", "sg_off", "sg_word", "sg_node", "g0", "cidx", "sidx",
-                  "sidx2", "vs_words", "vs_off", "di_words", "di_off", "dd_words", "dd_off")
+    # the four node-sized arrays LAST: lattices built into page-locked blocks (lattice.StagingPool) copy them to the device
+    # straight from there, and only the head [0, head_end) goes through this plan's staging block
+    BIG_ARRAYS = ("node_start", "node_word", "sg_word", "sg_node")
+    INT_ARRAYS = ("sent_len", "end_off", "sg_off", "g0", "cidx", "sidx", "sidx2", "vs_words", "vs_off", "di_words", "di_off", "dd_words",
+                  "dd_off")
 
     def __init__(self, eng, key, caps):
         torch, m, dev = eng.torch, eng.m, eng.device
@@ -77,11 +80,13 @@ class _Plan:
                      sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell, sidx2=ncell,
                      vs_words=caps["vs"], vs_off=B + 1, di_words=caps["di"], di_off=2 * ncell, dd_words=caps["dd"],
                      dd_off=ncell + 1)
-        names = self.INT_ARRAYS + (("di_wwords", "sg_wword") if perm else ())
+        names = self.INT_ARRAYS + (("di_wwords", "sg_wword") if perm else ()) + self.BIG_ARRAYS
         if perm:
             sizes.update(di_wwords=caps["di"], sg_wword=caps["nodes"])
         off, self.ioff = 0, {}
         for n in names:
+            if n == self.BIG_ARRAYS[0]:
+                self.head_end = off
             self.ioff[n] = off
             off += _round_up(max(sizes[n], 1), 4)
         self.isize = {n: sizes[n] for n in names}
@@ -177,6 +182,8 @@ class DecodeEngine:
         self.keep_n_live = False        # bench.py: read back every frame's live-row count with a timed decode
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"       # edge logits beside the normaliser
         self.blocking_sync = os.environ.get("JLM_BLOCKING_SYNC", "0") == "1"
+        from .lattice import StagingPool
+        self.staging_pool = None if os.environ.get("JLM_PINNED_LATTICE", "1") == "0" else StagingPool(self.torch, self.device.type == "cuda")
         self.plans = []
         # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
         # (beam step, LSTM step, T projection: two thirds of the launches, a third of the time, most CUs
@@ -290,11 +297,11 @@ class DecodeEngine:
         assert lat.n_frames <= p.F
         p._set("sent_len", lat.sent_len)
         p._set("end_off", lat.end_off)
-        p._set("node_start", lat.node_start)
-        p._set("node_word", lat.node_word)
         p._set("sg_off", lat.sg_off)
-        p._set("sg_word", lat.sg_word)
-        p._set("sg_node", lat.sg_node)
+        blk = getattr(lat, "_block", None)
+        if blk is None:
+            for name in p.BIG_ARRAYS:
+                p._set(name, getattr(lat, name))
         if vocab is not None:
             p._set("vs_words", vocab[0])
             p._set("vs_off", vocab[1])
@@ -306,7 +313,16 @@ class DecodeEngine:
             if perm:
                 p._set("di_wwords", dyn_lists[4])
                 p._set("sg_wword", dyn_lists[5])
-        p.dev_ints.copy_(p.host_ints, non_blocking=True)
+        if blk is None:
+            p.dev_ints.copy_(p.host_ints, non_blocking=True)
+        else:
+            # the head from the plan's staging block, the node arrays straight from the lattice's page-locked block
+            p.dev_ints[:p.head_end].copy_(p.host_ints[:p.head_end], non_blocking=True)
+            for name in p.BIG_ARRAYS:
+                n, o, d = int(getattr(lat, name).shape[0]), lat.block_off[name], p.ioff[name]
+                assert n <= p.isize[name], (name, n, p.isize[name])
+                if n:
+                    p.dev_ints[d:d + n].copy_(blk.tensor[o:o + n], non_blocking=True)
         p.cnt.zero_()
         p.n_live.zero_()
         # side stream for the edge logits: with one stream, and with two when the hardware queues are there (ROCm's default of

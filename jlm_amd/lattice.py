@@ -149,10 +149,45 @@ class LatticeBuilder:
         return end, start, word, lex
 
 
+class StagingPool:
+    """Page-locked int32 blocks for the lattice arrays that go to the device (node_start, node_word, sg_word, sg_node): the native
+    builder writes them where the H2D copy reads them -- no memcpy into a staging buffer on the enqueueing thread (3.5 MB per
+    256-sentence batch).  A block goes back to the pool when its batch has been read out (BatchLattice.release); blocks of lattices
+    that stay referenced (Decoder.last_lattice) are simply not returned.  Without a GPU the blocks are plain tensors (same code
+    path under the CPU tests)."""
+
+    class Block:
+        __slots__ = ("tensor", "np", "n")
+
+        def __init__(self, tensor):
+            self.tensor, self.np, self.n = tensor, tensor.numpy(), int(tensor.numel())
+
+    def __init__(self, torch, pinned):
+        self.torch, self.pinned = torch, bool(pinned)
+        self._free = {}
+        self._lock = threading.Lock()
+        self.allocated = 0
+
+    def get(self, n_ints):
+        n = 1 << max(16, int(n_ints - 1).bit_length())          # sizes in powers of two: a handful of distinct ones per process
+        with self._lock:
+            lst = self._free.get(n)
+            if lst:
+                return lst.pop()
+            self.allocated += 1
+        t = self.torch.empty(n, dtype=self.torch.int32, pin_memory=self.pinned)
+        return StagingPool.Block(t)
+
+    def put(self, blk):
+        with self._lock:
+            self._free.setdefault(blk.n, []).append(blk)
+
+
 class BatchLattice:
-    def __init__(self, builder, texts, beam):
+    def __init__(self, builder, texts, beam, pool=None):
         self.texts = list(texts)
         self.builder = builder
+        self._pool, self._block, self.block_off = pool, None, None
         B = len(self.texts)
         self.n_sent = B
         self.beam = int(beam)
@@ -162,6 +197,7 @@ class BatchLattice:
         if nat is not None:
             self._build_native(nat)
             return
+        self._pool = None
         ends, starts, words, lexs, sents = [], [], [], [], []
         for s, t in enumerate(self.texts):
             e, st, w, lx = builder.sentence_nodes(t)
@@ -212,19 +248,38 @@ class BatchLattice:
         mx = np.zeros(1, dtype=np.int32)
         cap = max(1024, int(text.size) * 48 + B)
         while True:
-            arrs = [np.empty(cap, dtype=np.int32) for _ in range(7)]
+            if self._pool is not None:
+                # the four arrays the device reads, at offsets 0, cap, 2 cap, 3 cap of ONE page-locked block
+                blk = self._pool.get(4 * cap)
+                dev = [blk.np[i * cap:(i + 1) * cap] for i in range(4)]
+                arrs = [dev[0], dev[1]] + [np.empty(cap, dtype=np.int32) for _ in range(3)] + [dev[2], dev[3]]
+            else:
+                blk = None
+                arrs = [np.empty(cap, dtype=np.int32) for _ in range(7)]
             n = lib.jlm_lattice_build(nat, _ptr(text), _ptr(t_off), B, F, cap, *[_ptr(a) for a in arrs[:5]],
                                       _ptr(self.end_off), _ptr(self.sg_off), _ptr(arrs[5]), _ptr(arrs[6]), _ptr(mx),
                                       self.builder.n_threads)
             if n <= cap:
                 break
+            if blk is not None:
+                self._pool.put(blk)
             cap = int(n)
         n = int(n)
+        if blk is not None:
+            self._block = blk
+            self.block_off = dict(node_start=0, node_word=cap, sg_node=2 * cap, sg_word=3 * cap)
         self.n_nodes = n
         self.node_start, self.node_word, self.node_lex, self.node_sent, self.node_end = (a[:n] for a in arrs[:5])
         ns = int(self.sg_off[-1])
         self.sg_node, self.sg_word = arrs[5][:ns], arrs[6][:ns]
         self.max_cands = int(mx[0]) * self.beam
+
+    def release(self):
+        """Give the page-locked block back (the batch has been read out; node_start / node_word / sg_* are dead from here on)."""
+        blk, self._block = self._block, None
+        if blk is not None and self._pool is not None:
+            self.node_start = self.node_word = self.sg_node = self.sg_word = None
+            self._pool.put(blk)
 
     # ---- per sentence views (used by vocabulary selection and by the tests)
     def frame_nodes(self, s, f):
