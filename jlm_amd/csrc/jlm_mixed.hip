@@ -335,7 +335,9 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     // per-block constant of the cost model below; swept on the three-segment launch (kbench, C0 x prologue cost): 0.5: 78-80 us,
     // 1: 72.7-73.4, 1.5: 72.2-72.6, 2: 69.8-72.3, 3: 72.3-73.2
     if (c0x2 < 0) { const char *e = getenv("JLM_MX_C0"); c0x2 = e ? (int)(2.0 * atof(e) + 0.5) : 4; }
-    if (np8 < 0) { const char *e = getenv("JLM_LSE_NP8"); np8 = e ? atoi(e) : 1; }
+    // the column count of a launch that has the chip to itself may use every CU (25 columns x 10 row tiles instead of 24: 67.3 vs
+    // 68.9 us, the decode 2.04 vs 2.06 ms per step); pipelined launches are capped by the CU share below that anyway.  1: multiples of 8
+    if (np8 < 0) { const char *e = getenv("JLM_MX_NP8"); np8 = e ? atoi(e) : 0; }
     int ntiles[JLM_MAX_SEGMENTS];
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
     long n_tiles_all = 0;
