@@ -390,6 +390,12 @@ def main():
             if vp:
                 roofline["frac_in_pipeline"] = round(vp["tflops"] / roofline["peak"], 4)
                 roofline["avg_launch_ms_in_pipeline"] = round(vp["avg_ms"], 4)
+                if eng.lse_share_pct and eng.lse_share_pct < 100:
+                    # the CUs the pipelined launch is cut for: columns x row tiles (jlm_decode_plan.lse_cu_share_pct, csrc/jlm_decode.hip)
+                    n_ptiles = (args.batch * args.beam + 255) // 256
+                    cus = max(1, 256 * eng.lse_share_pct // 100 // n_ptiles) * n_ptiles
+                    roofline["cus_in_pipeline"] = cus
+                    roofline["frac_in_pipeline_of_its_cus"] = round(vp["tflops"] / (roofline["peak"] * cus / 256.0), 4)
                 roofline["in_pipeline_note"] = ("the same launches timed inside the pipelined loop (%d batches in flight, the kernel on "
                                                 "%d%% of the CUs beside the other batches' kernels): events on each batch's own stream"
                                                 % (dec.pipeline_depth, eng.lse_share_pct or 100))
