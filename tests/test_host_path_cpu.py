@@ -335,3 +335,26 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     for g, g0 in zip(got, got0):
         assert [x for _, x in g] == [x for _, x in g0]
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in g0], rtol=1e-6, atol=2e-5)
+
+
+def test_lattice_blocks_return_to_the_pool(fx, fake):
+    """Lattices of a pipelined decode are built into pooled blocks (lattice.StagingPool; page-locked on a GPU box) and copied to the
+    device from there; a block goes back when its batch has been read out, the last chunk's lattice (Decoder.last_lattice, what
+    decode() builds backward_lookup from) keeps its arrays; JLM_PINNED_LATTICE=0 gives the same results through the staging copy."""
+    f = fx("small-tied")
+    dec = _decoder(f, "static")
+    pool = dec._engine.staging_pool
+    assert pool is not None
+    sents = synth.make_ragged_sentences(40, 2, 9, seed=11, alphabet=f["alphabet"])
+    dec.max_batch = 8                                   # five chunks
+    a = dec.decode_batch(sents, beam_width=5)
+    n_free = sum(len(v) for v in pool._free.values())
+    assert pool.allocated >= 2 and n_free == pool.allocated - 1          # every block but the last lattice's is back
+    assert dec.last_lattice.node_word is not None and dec.last_lattice._block is not None
+    dec.last_lattice.backward_lookup(0)                 # its arrays are alive
+    b = dec.decode_batch(sents, beam_width=5)           # blocks are reused
+    assert pool.allocated <= n_free + 2
+    dec._engine.staging_pool = None                     # the staging-copy path
+    c = dec.decode_batch(sents, beam_width=5)
+    for x, y, z in zip(a, b, c):
+        assert x == y == z
