@@ -283,7 +283,7 @@ class DeviceModel:
         if self.precision not in ("f16x3", "f32"):
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
-        self.mixed_idx, self.ld_tm, self.b2_log2 = [], 0, None
+        self.mixed_idx, self.ld_tm, self.b2_log2, self.mixed_spread = [], 0, None, []
         self.split_lstm = False
         self.um_split = None
         if self.precision == "f16x3" and (self.stationary_ok or self.mode == "untied"):
@@ -410,6 +410,19 @@ class DeviceModel:
             elif not (nv > 0 and k <= 64 and self.split_bias_col[i] == k):
                 return
         if not take or (xbias and len(xbias) != len(self.segments)):      # (one bias form per launch)
+            return
+        # The int8 planes carry ONE scale per segment (the power of two at or above max|hi| / 127): the quantisation step of a word's hi8
+        # is max|B| / 254 whatever the word's own size, so the error grows with the block's spread max|B| / rms B: Gaussian-like blocks
+        # (spread ~5) 8e-6 of the row's logit scale and 3e-7 on the log-sum-exp; 0.1 % entries at 30 sigma (spread 80) 1e-4 -- the
+        # parity bar itself -- and 5e-5 (measured: tests/test_gpu_kernels.py::test_vocab_lse_mixed_spread; numpy emulation of the scheme
+        # in tests/fake_hip.py).  Blocks with heavy tails stay on split rows, whose error does not depend on the distribution.
+        limit = float(os.environ.get("JLM_MIXED_MAX_SPREAD", "8"))
+        self.mixed_spread = []
+        for i in take:
+            blk = self.seg_B[i]
+            rms = float(blk.pow(2).mean().sqrt().item())
+            self.mixed_spread.append(float(blk.abs().max().item()) / rms if rms > 0.0 else float("inf"))
+        if max(self.mixed_spread) > limit:
             return
         LOG2E = 1.4426950408889634
         for i in take:

@@ -879,6 +879,56 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     assert worst <= 3e-5, worst
 
 
+@pytest.mark.parametrize("tails", ["gauss", "outliers", "student-t3"])
+def test_vocab_lse_mixed_spread(L, tails):
+    """What the ONE int8 scale per segment costs on heavy-tailed vocabulary blocks: the error of the mixed-row normaliser grows with
+    max|B| / rms B (the hi8 quantisation step is max|B| / 254 for every word) -- up to ~7e-7 x spread on the log-sum-exp; DeviceModel keeps
+    blocks with a spread above JLM_MIXED_MAX_SPREAD (8) on split rows (jlm_amd/model.py, _build_mixed)."""
+    rng = np.random.default_rng(7)
+    V, k, R = 12000, 200, 256
+    gen = {"gauss": lambda: rng.standard_normal((V, k)) * 0.08,
+           "outliers": lambda: rng.standard_normal((V, k)) * 0.08 * np.where(rng.random((V, k)) < 1e-3, 30.0, 1.0),
+           "student-t3": lambda: rng.standard_t(3, (V, k)) * 0.05}[tails]
+    B_np = gen().astype(np.float32)
+    spread = float(np.abs(B_np).max() / np.sqrt((B_np.astype(np.float64) ** 2).mean()))
+    b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    b2 = torch.as_tensor(b2_np).cuda()
+    bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np).max()) * 1.4427)
+    eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
+    hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
+    s_b = 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
+    nb = (k + 2 + 31) // 32
+    Bg = torch.as_tensor(B_np).cuda()
+    dst = torch.zeros((V, 32 * nb), dtype=torch.float32, device="cuda")
+    assert L.jlm_pack_mixed(Bg.data_ptr(), V, k, k, b2.data_ptr(), 2.0 ** eB, 2.0 ** eB * 1.4426950408889634, s_b, dst.data_ptr(), 32 * nb, _st()) == 0
+    import ctypes
+    seg = (_lib.Segment * 1)(_lib.Segment(0, V, k, 0, dst.data_ptr(), 32 * nb))
+    T_np = (np.tanh(rng.standard_normal((R, k))) * rng.uniform(0.05, 1.0, size=(R, 1))).astype(np.float32)
+    T = torch.as_tensor(T_np).cuda()
+    ld_tm = L.jlm_mixed_t_stride(seg, 1)
+    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")
+    eT = 10
+    assert L.jlm_pack_t_mixed(seg, (ctypes.c_float * 1)(2.0 ** eT), 1, T.data_ptr(), k, None, R, None, Tm.data_ptr(), ld_tm, _st()) == 0
+    part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
+    n = L.jlm_vocab_lse_mixed(seg, (ctypes.c_float * 1)(2.0 ** -(eT + eB)), (ctypes.c_float * 1)(s_b), None, 1, Tm.data_ptr(), ld_tm, part.data_ptr(),
+                              R, 96, R, None, _st())
+    assert n >= 1
+    torch.cuda.synchronize()
+    p = part[:n].cpu().numpy().astype(np.float64)
+    v = p[:, :, 0] + np.log(p[:, :, 1])
+    mx = v.max(axis=0)
+    lse = mx + np.log(np.exp(v - mx).sum(axis=0))
+    y = T_np.astype(np.float64) @ B_np.astype(np.float64).T + b2_np
+    ymax = y.max(axis=1)
+    ref = ymax + np.log(np.exp(y - ymax[:, None]).sum(axis=1))
+    err = float(np.abs(lse - ref).max())
+    assert err <= 1e-6 * spread, (tails, spread, err)
+    if tails == "gauss":
+        assert spread < 8 and err <= 2e-6, (spread, err)
+    else:
+        assert spread > 8, spread             # these are the blocks the loader keeps on split rows
+
+
 @pytest.mark.parametrize("V,bounds,R", [(50000, [0, 12000, 30000, 50000], 2560), (3100, [0, 700, 1900, 3100], 300)])
 def test_vocab_lse_hybrid(L, V, bounds, R):
     """jlm_vocab_lse_hybrid: the D-softmax* shapes in one launch -- k = 200 and k = 100 on mixed rows (int8 cross terms), k = 50 on

@@ -335,6 +335,12 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     for g, g0 in zip(got, got0):
         assert [x for _, x in g] == [x for _, x in g0]
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in g0], rtol=1e-6, atol=2e-5)
+    # heavy-tailed blocks stay on split rows: the guard compares max|B| / rms B with JLM_MIXED_MAX_SPREAD (Gaussian-like fixtures: ~4-5)
+    assert m.mixed_spread and all(3.0 < x < 8.0 for x in m.mixed_spread), m.mixed_spread
+    monkeypatch.delenv("JLM_LSE_MIXED")
+    monkeypatch.setenv("JLM_MIXED_MAX_SPREAD", "2")
+    dec2 = _decoder(f, "static")
+    assert dec2.model.dev.mixed_idx == [] and dec2.model.dev.ld_tm == 0 and dec2.model.dev.mixed_spread
 
 
 def test_lattice_blocks_return_to_the_pool(fx, fake):
