@@ -42,7 +42,7 @@ def test_beam_extremes(kind, beam, topN, fx):
 
 
 @pytest.mark.parametrize("fixture,kind", [("small-vtable", "static"), ("small-tied", "static-vs"), ("small-tied", "dynamic"),
-                                          ("small-untied", "static")])
+                                          ("small-untied", "static"), ("wide-vtable", "static"), ("wide128-tied", "static")])
 @pytest.mark.parametrize("beam", [100, 257])
 def test_beams_above_one_wave(fixture, kind, beam, fx):
     """beams above 64 (the reference has no limit, decoder.py:227-229): a lane of the sentence's wave owns several ranks in the
@@ -256,6 +256,35 @@ def test_operand_ranges_of_the_split_kernels(name, edit, tag, tmp_path):
     d, o = _pair(f, "static")
     if os.environ.get("JLM_PRECISION", "f16x3") == "f16x3":      # (the suite also runs under JLM_PRECISION=f32)
         assert d.model.dev.split_array is not None
+    sents = synth.make_ragged_sentences(6, 3, 15, seed=123, alphabet=f["alphabet"])
+    got = d.decode_batch(sents, beam_width=6)
+    for s, g in zip(sents, got):
+        _same(g, o.decode(s, beam_width=6), (tag, s))
+
+
+def _heavy_tails(w):
+    rs = np.random.RandomState(9)
+    for key in list(w):
+        if key.startswith("LM") and not isinstance(w[key], list):
+            w[key] = (w[key] * np.where(rs.rand(*w[key].shape) < 2e-3, 25.0, 1.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,edit,tag,mixed", [
+    ("wide-vtable", _scale_out(16.0, 1.0 / 16.0), "large output embeddings, small projection", True),
+    ("wide-vtable", _big_bias, "biases spread over +-40", True),
+    ("wide-vtable", _zero_rows, "zero embedding rows and projection columns", True),
+    ("wide128-tied", _big_bias, "biases spread over +-40 (biases outside the rows)", True),
+    ("wide128-tied", _scale_out(1.0 / 64.0, 64.0), "small embeddings, large projection", True),
+    ("wide-vtable", _heavy_tails, "0.2 % of the embedding entries x 25: the spread guard keeps the model on split rows", False),
+], ids=lambda v: v if isinstance(v, str) else getattr(v, "__name__", "edit") if callable(v) else str(v))
+def test_operand_ranges_of_the_mixed_kernels(name, edit, tag, mixed, tmp_path):
+    """The mixed-row normaliser takes its power-of-two scales (2^eB, the int8 scale s8, 2^eT) from the weights' ranges and only
+    serves blocks without heavy tails (DeviceModel._build_mixed): the decode stays on the oracle whatever the ranges are."""
+    if os.environ.get("JLM_PRECISION", "f16x3") != "f16x3" or os.environ.get("JLM_LSE_MIXED", "1") == "0":
+        pytest.skip("the suite is running without the mixed rows")
+    f = _rescaled_fixture(tmp_path, name, edit)
+    d, o = _pair(f, "static")
+    assert bool(d.model.dev.mixed_idx) == mixed, (d.model.dev.mixed_idx, d.model.dev.mixed_spread)
     sents = synth.make_ragged_sentences(6, 3, 15, seed=123, alphabet=f["alphabet"])
     got = d.decode_batch(sents, beam_width=6)
     for s, g in zip(sents, got):
