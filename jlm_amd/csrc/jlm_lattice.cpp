@@ -190,16 +190,19 @@ extern "C" int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text
     (void)ncell;
     *max_nodes_per_cell = mx;
     if (total > node_cap) return total;
-    parallel_for(B, n_threads, [&](int s) {
-        SentMatches &x = sm[s];
-        const int L = text_off[s + 1] - text_off[s];
-        // the root: frame 0's only node
-        {
-            const int32_t id = end_off[s];
-            node_start[id] = -1; node_word[id] = t.eos_word; node_lex[id] = -1; node_sent[id] = s; node_end[id] = 0;
-        }
-        size_t k = 0;
-        for (int e = 1; e <= L && e < F; ++e) {
+    // cells in MEMORY order (frame-major, sentence-minor): every output array is written front to back -- sentence by sentence the
+    // 37 k runs of a batch landed 35 KB apart in seven arrays: 1.07 ms of a 1.65-ms build
+    std::vector<uint32_t> kpos(B, 0), qpos(B, 0);
+    for (int s = 0; s < B; ++s) {                          // the roots: frame 0's only nodes
+        const int32_t id = end_off[s];
+        node_start[id] = -1; node_word[id] = t.eos_word; node_lex[id] = -1; node_sent[id] = s; node_end[id] = 0;
+    }
+    for (int e = 1; e < F; ++e)
+        for (int s = 0; s < B; ++s) {
+            const int L = text_off[s + 1] - text_off[s];
+            if (e > L) continue;
+            SentMatches &x = sm[s];
+            uint32_t k = kpos[s];
             int32_t id = end_off[(int64_t)e * B + s];
             for (; k < x.by_end.size() && x.m[x.by_end[k]].end == e; ++k) {
                 Match &m = x.m[x.by_end[k]];
@@ -214,19 +217,24 @@ extern "C" int64_t jlm_lattice_build(const jlm_lexicon *lx, const uint32_t *text
                     }
                 }
             }
+            kpos[s] = k;
         }
-        // nodes grouped by the cell they START in, ascending node id inside a cell: a start's matches in length order ARE in
-        // ascending id order (a longer reading ends in a later frame, i.e. a later cell)
-        size_t q = 0;
-        for (int i = 0; i < L && i < F; ++i) {
+    // nodes grouped by the cell they START in, ascending node id inside a cell: a start's matches in length order ARE in
+    // ascending id order (a longer reading ends in a later frame, i.e. a later cell)
+    for (int i = 0; i + 1 < F; ++i)
+        for (int s = 0; s < B; ++s) {
+            const int L = text_off[s + 1] - text_off[s];
+            if (i >= L) continue;
+            const SentMatches &x = sm[s];
+            uint32_t q = qpos[s];
             int32_t o = sg_off[(int64_t)i * B + s];
             for (; q < x.m.size() && x.m[q].start == i; ++q) {
                 const Match &m = x.m[q];
                 const int32_t c = match_count(t, m);
                 for (int32_t r = 0; r < c; ++r, ++o) { sg_node[o] = m.first_id + r; sg_word[o] = node_word[m.first_id + r]; }
             }
+            qpos[s] = q;
         }
-    });
     return total;
 }
 

@@ -249,10 +249,11 @@ class BatchLattice:
         cap = max(1024, int(text.size) * 48 + B)
         while True:
             if self._pool is not None:
-                # the four arrays the device reads, at offsets 0, cap, 2 cap, 3 cap of ONE page-locked block
-                blk = self._pool.get(4 * cap)
-                dev = [blk.np[i * cap:(i + 1) * cap] for i in range(4)]
-                arrs = [dev[0], dev[1]] + [np.empty(cap, dtype=np.int32) for _ in range(3)] + [dev[2], dev[3]]
+                # the four arrays the device reads at offsets 0, cap, 2 cap, 3 cap of ONE page-locked block; the three host-only ones
+                # behind them (a pooled block is touched memory: fresh np.empty arrays cost a page fault per 4 KB on every build)
+                blk = self._pool.get(7 * cap)
+                dev = [blk.np[i * cap:(i + 1) * cap] for i in range(7)]
+                arrs = [dev[0], dev[1], dev[4], dev[5], dev[6], dev[2], dev[3]]
             else:
                 blk = None
                 arrs = [np.empty(cap, dtype=np.int32) for _ in range(7)]
@@ -278,7 +279,7 @@ class BatchLattice:
         """Give the page-locked block back (the batch has been read out; node_start / node_word / sg_* are dead from here on)."""
         blk, self._block = self._block, None
         if blk is not None and self._pool is not None:
-            self.node_start = self.node_word = self.sg_node = self.sg_word = None
+            self.node_start = self.node_word = self.sg_node = self.sg_word = self.node_lex = self.node_sent = self.node_end = None
             self._pool.put(blk)
 
     # ---- per sentence views (used by vocabulary selection and by the tests)
