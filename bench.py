@@ -329,7 +329,7 @@ def main():
             try:
                 for _ in range(n):
                     inflight.append(eng.submit(lat, ekind, topN=10, timing=timing, **ekw))
-                    if len(inflight) > dec.pipeline_depth:
+                    if len(inflight) > dec.depth_for(args.batch, args.beam):
                         fin(inflight.popleft())
                 while inflight:
                     fin(inflight.popleft())
@@ -412,7 +412,7 @@ def main():
                     roofline["frac_in_pipeline_of_its_cus"] = round(vp["tflops"] / (roofline["peak"] * cus / 256.0), 4)
                 roofline["in_pipeline_note"] = ("the same launches timed inside the pipelined loop (%d batches in flight, the kernel on "
                                                 "%d%% of the CUs beside the other batches' kernels): events on each batch's own stream"
-                                                % (dec.pipeline_depth, eng.lse_share_pct or 100))
+                                                % (dec.depth_for(args.batch, args.beam), eng.lse_share_pct or 100))
             if gp and gate_obj:
                 gate_obj["mfma_util_pct_in_pipeline"] = round(100.0 * gp["tflops"] / gate_obj["peak"], 2)
                 gate_obj["avg_launch_ms_in_pipeline"] = round(gp["avg_ms"], 4)

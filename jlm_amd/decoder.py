@@ -89,7 +89,7 @@ class Decoder():
         self.model = LSTM_Model(experiment_id, comp, device=device)
         self._builder = LatticeBuilder(self.full_lexicon, self.full_reading_dict, self.w2i)
         self._engine = DecodeEngine(self.model.dev)
-        self.pipeline_depth = self._engine.n_streams      # chunks in flight in decode_batch
+        self.pipeline_depth = self._engine.n_streams      # chunks in flight in decode_batch (see depth_for)
         self.lattice_vocab = None
         self.backward_lookup = None
         self.perf_sen = 0
@@ -194,7 +194,8 @@ class Decoder():
 
         workers = 1 if (samples and random_sampling) else self.prefetch_workers
         try:
-            self._run_pipeline(self._prefetched(prepare, chunks, workers), len(chunks), submit, finish)
+            self._run_pipeline(self._prefetched(prepare, chunks, workers), len(chunks), submit, finish,
+                               depth=self.depth_for(max(len(c) for c in chunks), beam_width))
         except _CellTooLarge as e:
             # the sentences named take the host-side beam search, everything else goes through the device again
             heavy = set(e.sentences)
@@ -233,7 +234,13 @@ class Decoder():
         per_sentence = np.diff(np.asarray(lat.end_off)).reshape(lat.n_frames, lat.n_sent).max(axis=0)
         raise _CellTooLarge([idx[k] for k in range(lat.n_sent) if int(per_sentence[k]) * beam_width > limit])
 
-    def _run_pipeline(self, prepared, n_chunks, submit, finish):
+    def depth_for(self, n_sent, beam_width):
+        """Chunks in flight for chunks of n_sent sentences: four (one per stream) while a chunk's frame is a few thousand rows and its
+        kernels leave room for the others', three above 8 192 rows (BASELINE configs[2]: 1 024 sentences x beam 20 -- 41.8 vs 43.4 ms
+        per step; the vocabulary kernel alone takes 1.8 ms there and a fourth batch only adds to the queue)."""
+        return min(self.pipeline_depth, 3) if int(n_sent) * int(beam_width or 1) > 8192 else self.pipeline_depth
+
+    def _run_pipeline(self, prepared, n_chunks, submit, finish, depth=None):
         """The device pipeline of decode_batch: ``submit`` every prepared chunk (enqueue upload + frame loop + read-back: no
         waiting), ``finish`` them in order (wait for the batch, build its n-best lists).  ``pipeline_depth`` + 1 chunks are in
         flight at most (the engine alternates streams; a chunk owns its plan's buffers until finished).
@@ -252,19 +259,19 @@ class Decoder():
             gc.disable()
         self._engine.pipelined = n_chunks > 1          # more than one batch in flight: the vocabulary kernel leaves CUs to the others
         try:
-            self._run_pipeline_nogc(prepared, n_chunks, submit, finish)
+            self._run_pipeline_nogc(prepared, n_chunks, submit, finish, depth or self.pipeline_depth)
         finally:
             self._engine.pipelined = False
             if pause_gc:
                 gc.enable()
 
-    def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish):
+    def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish, depth):
         if n_chunks <= 2 or not self.collector_thread:
             inflight = deque()
             try:
                 for item in prepared:
                     inflight.append(submit(item))
-                    if len(inflight) > self.pipeline_depth:
+                    if len(inflight) > depth:
                         finish(*inflight.popleft())
                 while inflight:
                     finish(*inflight.popleft())
@@ -278,7 +285,7 @@ class Decoder():
             return
         import queue
         import threading
-        q, slots, failed = queue.Queue(), threading.Semaphore(self.pipeline_depth + 1), []
+        q, slots, failed = queue.Queue(), threading.Semaphore(depth + 1), []
 
         def collector():
             while True:

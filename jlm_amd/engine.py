@@ -166,7 +166,7 @@ class _Plan:
 
 class DecodeEngine:
     _stream_pool = {}              # device index -> launch streams shared by all engines of the process
-    MAX_PLANS = 4                  # plans kept regardless of their size (two or three are in flight at a time)
+    MAX_PLANS = 6                  # plans kept regardless of their size (up to four are in flight at a time, one is being read out)
     MAX_PLANS_SMALL = 48           # ... and as many more as fit PLAN_BYTES of device memory
     PLAN_BYTES = 4 << 30
 
@@ -188,12 +188,14 @@ class DecodeEngine:
         # Consecutive batches go to alternating HIP streams: the latency-bound kernels of batch i+1
         # (beam step, LSTM step, T projection: two thirds of the launches, a third of the time, most CUs
         # idle) fill in beside the vocabulary kernel of batch i.  JLM_STREAMS=1 keeps one stream.
+        # (round 3: FOUR batches in flight -- 1.95-1.98 against 2.04-2.06 ms per step once the mixed-row normaliser left more of
+        # a frame to the latency-bound kernels; five: 2.36 -- Decoder.depth_for keeps three for batches above 8 192 rows)
         # THREE batches in flight on three streams, edge logits on the batch's own stream: 2.14-2.22 ms per step against
         # 2.32-2.36 with two streams + a side stream each (tools/ab_streams.py).  A frame of one batch is a chain of dependent
         # launches (beam step, LSTM step, T projection, vocabulary kernel: every one of them on the critical path of the step,
         # tools/probes/skip_kernel.sh) and the chains of three batches fill each other's gaps better than those of two; side
         # streams on top (six streams, fork / join events across them) cost more than the overlap buys: 3.3 ms.
-        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "3")))
+        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "4")))
         self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
