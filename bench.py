@@ -390,7 +390,7 @@ def main():
         line_extra["device_resident_note"] = ("same K steps with the batch's lattice (CSR) already resident in HBM: launch sequence "
                                               "+ n-best traces back on the host, no lattice build / upload / string read-out")
         roofline, gate_obj = measure_kernels(dec, lat, ekind, ekw, min(args.steps, 20), full_vocab=(args.decoder == "static"))
-        # the same kernels inside the pipelined loop (three batches in flight): events on each batch's own stream
+        # the same kernels inside the pipelined loop (four batches in flight): events on each batch's own stream
         if roofline and args.decoder == "static" and eng.n_streams >= 2:
             sink = {"n_live": [], "gate_gemm": [], "vocab_lse": []}
             eng.keep_n_live = True

@@ -4,7 +4,7 @@ import sys
 
 
 def _want_hw_queues(n=8):
-    """The decode engine keeps three HIP streams busy (three batches in flight; JLM_STREAMS=2: two, each with a
+    """The decode engine keeps four HIP streams busy (four batches in flight; JLM_STREAMS=2: two, each with a
     side stream for its edge logits).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4,
     one of them the null stream's); streams that share a queue serialise, and with 4 queues a side
     stream lands on the other batch's queue -- the two-stream overlap is gone (3.8 instead of 2.8 ms per

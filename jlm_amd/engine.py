@@ -328,7 +328,7 @@ class DecodeEngine:
         p.cnt.zero_()
         p.n_live.zero_()
         # side stream for the edge logits: with one stream, and with two when the hardware queues are there (ROCm's default of
-        # four is not enough: jlm_amd/__init__.py); with the default three streams they run on the batch's own stream
+        # four is not enough: jlm_amd/__init__.py); with three or more streams (the default is four) they run on the batch's own stream
         from . import hw_queues_ok
         side = self.use_side and self.device.type == "cuda" and (
             self.n_streams < 2 or (self.n_streams == 2 and hw_queues_ok()) or os.environ.get("JLM_SIDE") == "1")
