@@ -195,7 +195,10 @@ class DecodeEngine:
         # launches (beam step, LSTM step, T projection, vocabulary kernel: every one of them on the critical path of the step,
         # tools/probes/skip_kernel.sh) and the chains of three batches fill each other's gaps better than those of two; side
         # streams on top (six streams, fork / join events across them) cost more than the overlap buys: 3.3 ms.
-        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "4")))
+        # four streams need more than ROCm's default of four hardware queues (one is the null stream's): there they run 2.31 ms per
+        # step against 2.06 with three (jlm_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 when it still can)
+        from . import hw_queues_ok as _hwq
+        self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "4" if _hwq() else "3")))
         self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
