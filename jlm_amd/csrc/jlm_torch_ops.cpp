@@ -177,7 +177,7 @@ struct JlmPlan : torch::CustomClassHolder {
     std::vector<hipEvent_t> events;         // JLM_EVENTS_PER_FRAME per frame, created on first timed decode
     // JLM_GRAPH=1: the launch sequence of a decode shape, captured on its second use and replayed (decode_frames)
     std::map<std::array<long, 8>, hipGraphExec_t> graphs;
-    std::set<std::array<long, 8>> seen;
+    std::set<std::array<long, 8>> seen, no_graph;
     int timed_frames = 0;                   // frames of the last timed decode (0: the last decode was not timed)
     int device = -1;
 
@@ -280,20 +280,21 @@ int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intr
         const std::array<long, 8> key = {(long)n_frames, (long)vs_max, (long)di_max, (long)dd_max, (long)lse_cu_share_pct,
                                          (long)(side_s != nullptr), (long)(intptr_t)main.stream(), (long)(intptr_t)&model->m};
         auto it = pl.graphs.find(key);
-        if (it == pl.graphs.end() && pl.seen.count(key)) {
+        if (it == pl.graphs.end() && pl.seen.count(key) && !pl.no_graph.count(key)) {
+            // a capture that cannot start or does not end cleanly (seen with four batches in flight: hipStreamBeginCapture refuses
+            // while the thread's other streams are busy) leaves this shape on the eager path for good -- nothing was launched
             hipGraph_t graph = nullptr;
-            jlm_check((int)hipStreamBeginCapture(main.stream(), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-            const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, nullptr);
-            const hipError_t e = hipStreamEndCapture(main.stream(), &graph);
-            if (rc == 0 && e == hipSuccess && graph) {
-                hipGraphExec_t exec = nullptr;
-                jlm_check((int)hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
-                (void)hipGraphDestroy(graph);
-                it = pl.graphs.emplace(key, exec).first;
-            } else {
-                if (graph) (void)hipGraphDestroy(graph);
-                TORCH_CHECK(false, "jlm.decode_frames: graph capture failed (rc ", rc, ", ", hipGetErrorString(e), ")");
+            bool ok = hipStreamBeginCapture(main.stream(), hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, nullptr);
+                const hipError_t e = hipStreamEndCapture(main.stream(), &graph);
+                ok = rc == 0 && e == hipSuccess && graph;
             }
+            hipGraphExec_t exec = nullptr;
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) it = pl.graphs.emplace(key, exec).first;
+            else { (void)hipGetLastError(); pl.no_graph.insert(key); }
         }
         if (it != pl.graphs.end()) {
             jlm_check((int)hipGraphLaunch(it->second, main.stream()), "hipGraphLaunch");
