@@ -11,9 +11,12 @@
 // 32 x 32 block that is 2 + 2 matrix instructions instead of 6, and on this chip -- where these loops are bound by the clock the
 // power governor grants under matrix load, not by issue slots -- a pure MFMA stream of that mix runs in 0.64 of
 // the three-pass stream's time (tools/probes/mfma_mix_rate.hip: 2.50 vs 3.78 ms for equal work on random operands).
-// Error: the quantisation steps are 2^-8 of the row / segment maximum on terms that are 2^-11 of the product: ~1e-6 rms, < 1e-5
-// worst relative to a row's logit scale on the BASELINE models (bar: 1e-4; three f16 passes: 5e-7), and the errors of different
-// words are independent, so the log-normaliser -- what the decode consumes -- moves by < 1e-8.
+// Error: the quantisation steps are 2^-8 of the row / segment maximum on terms that are 2^-11 of the product -- products good to
+// ~2^-20 of |t||b| where three f16 passes give 2^-23.  Measured on the BASELINE-shaped fixtures (Gaussian-like blocks): logits
+// within 8e-6 of the row's logit scale (bar: 1e-4), the log-normaliser -- what the decode consumes -- within 3e-7, path scores
+// within 3e-7 of the oracle like the split form; on peaked distributions (logits of +-10 .. +-20) the scores move by 5e-5 .. 3e-4
+// where the split form's move by 5e-6 .. 3e-5, and heavy-tailed blocks lose more (one int8 scale per segment): DeviceModel keeps
+// those on split rows (JLM_MIXED_MAX_SPREAD).  DESIGN.md 6c.1.
 //
 // Row format ("mixed rows"), per 32 k-values one 128-byte block:
 //      [ 32 x f16 hi | 32 x int8 hi8 | 32 x int8 lo8 ]      = 8 granules of 16 bytes: 0-3 hi (8 k each), 4-5 hi8, 6-7 lo8
@@ -23,7 +26,7 @@
 //
 // Kernel: rows-stationary like vocab_lse_split8_kernel -- a workgroup of 8 waves keeps 256 hypothesis rows' operands in
 // registers (32 rows per wave: f16 hi, int8 hi8, int8 lo8) and streams its vocabulary column through LDS -- but in tiles of
-// 64 words with the WHOLE contraction of a tile resident (two buffers of NB x 8 KB): one barrier per tile, no chunks; LDS-DMA
+// 64 .. 256 words with the WHOLE contraction of a tile resident (two buffers of up to 64 KB): one barrier per tile, no chunks; LDS-DMA
 // by buffer loads (counted lgkmcnt waits, jlm_gate.hip), fragment registers refilled in place behind the MFMA that read them.
 #include "jlm_common.h"
 #include <stdlib.h>
