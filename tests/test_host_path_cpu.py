@@ -364,3 +364,12 @@ def test_lattice_blocks_return_to_the_pool(fx, fake):
     c = dec.decode_batch(sents, beam_width=5)
     for x, y, z in zip(a, b, c):
         assert x == y == z
+
+
+def test_chunks_in_flight_rule(fx, fake):
+    """Decoder.depth_for: one chunk per launch stream in flight, three at most for chunks above 8 192 hypothesis rows."""
+    dec = _decoder(fx("small-tied"), "static")
+    n = dec._engine.n_streams
+    assert dec.pipeline_depth == n
+    assert dec.depth_for(256, 10) == n and dec.depth_for(1024, 8) == n
+    assert dec.depth_for(1024, 20) == min(n, 3) and dec.depth_for(8192, 10) == min(n, 3)
