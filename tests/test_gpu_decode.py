@@ -196,10 +196,11 @@ def test_timed_frame_loop_equals_fast_frame_loop(fixture, kind, kw, fx):
 
 
 @pytest.mark.parametrize("fixture,kind,kw", [("small-vtable", "static", {}), ("small-tied", "static", {"vocab_select": True}),
-                                             ("small-tied", "dynamic", {"vocab_select": True})])
+                                             ("small-tied", "dynamic", {"vocab_select": True}),
+                                             ("wide-vtable", "static", {})])         # mixed rows (Tm of the plans reused in flight)
 def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
-    """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- three batches in flight
-    on three streams, frame-loop op, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
+    """Race hunt (tools/probes/soak_race.py at full size): 24 ragged chunks through the pipelined path -- one batch in flight per
+    launch stream, page-locked lattice blocks handed back to the pool and reused, frame-loop op, lattice prefetch threads, plans reused while others are in flight -- against one chunk at
     a time on one stream, timed (no side stream either).  Same kernels, same operands: bit-identical results."""
     f = fx(fixture)
     dec = _decoder(f, kind)
@@ -207,8 +208,10 @@ def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
     dec.perf_timing = False
     sents = synth.make_ragged_sentences(24 * 48, 1, 22, seed=123, alphabet=f["alphabet"])
     keep = (dec.max_batch, eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers)
+    share = eng.lse_share_pct
     try:
         dec.max_batch, dec.prefetch_workers = 48, 3
+        eng.lse_share_pct = 0        # the CU share moves the normaliser's column cuts (summation order) while another batch is in flight
         fast = dec.decode_batch(sents, beam_width=8, **kw)
         chunks = dec._chunks(sents, 8)                     # the same device batches (dealt by decreasing length), one at a time
         eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = 1, True, 0, 1
@@ -218,6 +221,7 @@ def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
                 slow[j] = r
     finally:
         dec.max_batch, eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = keep
+        eng.lse_share_pct = share
     assert len(fast) == len(slow) == len(sents)
     assert fast == slow
 

@@ -1,4 +1,4 @@
-"""Race hunt: many ragged chunks through the pipelined product path (three batches in flight on three streams, frame-loop op,
+"""Race hunt: many ragged chunks through the pipelined product path (one batch in flight per launch stream, page-locked lattice blocks reused, frame-loop op,
 lattice prefetch threads, plans reused while others are in flight) against the SAME device batches decoded one at a time on one
 stream, timed.  Same kernels, same operands: every n-best list and every score must be bit-identical."""
 import os, sys, tempfile, time
