@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 7
+#define JLM_ABI_VERSION 8
 #define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
@@ -481,6 +481,18 @@ typedef struct {
 int jlm_decode_frames(const jlm_decode_model *model_host, const jlm_decode_plan *plan_host,
                       const jlm_lattice *lat_host, const jlm_beam_state *st_host,
                       void *stream, void *side_stream, void *const *events);
+
+/* ABI 8: probe of the full-vocabulary normaliser, for the load-time calibration of the mixed rows (jlm_amd/model.py
+ * DeviceModel._calibrate_mixed; the reference computes every logit in float64, decoder/model.py:141-193,15-20 -- which
+ * int8 cross terms can follow only as far as the model's logit range lets them).  Runs `steps` LSTM steps (jlm_lstm_step_xg)
+ * of `rows` hypotheses from the zero state -- row g = t * rows + r is hypothesis r after t steps: rowlist[g] = g,
+ * prev[g] = g - rows (negative in block 1), word[g] = the word step t consumes; h, c [(steps + 1) * rows, H], T
+ * [(steps + 1) * rows, ldt] -- then the T projection of the last block and its normaliser slices into part [max_parts][rows][2]:
+ * form 0 = jlm_vocab_lse_split, form 1 = what jlm_decode_frames launches with the model's mixed rows (jlm_pack_t_mixed into
+ * Tm [rows][ld_tm] + jlm_vocab_lse_mixed / jlm_vocab_lse_hybrid).  Returns the number of slices (>= 1), -2 for a model
+ * without that form, -1 / a hipError_t as the launchers do. */
+int jlm_lse_probe(const jlm_decode_model *model_host, const int *rowlist, const int *prev, const int *word, int steps, int rows,
+                  void *h, float *c, float *T, void *Tm, int ld_tm, int form, float *part, int max_parts, void *stream);
 
 #ifdef __cplusplus
 }

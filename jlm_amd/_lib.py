@@ -103,6 +103,7 @@ _SIGS = {
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
     "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P, P], c_int),
+    "jlm_lse_probe": ([POINTER(DecodeModel), P, P, P, c_int, c_int, P, P, P, P, c_int, c_int, P, c_int, P], c_int),
 }
 EXPORTS = sorted(_SIGS)
 
@@ -130,7 +131,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 7:
+        if l.jlm_abi_version() != 8:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -192,13 +192,8 @@ extern "C" int jlm_edge_logits_perm(const jlm_segment *segs_host, int n_segs, co
     if (n_groups <= 0) return 0;
     size_t lds = wl_lds_bytes(beam, ldt);
     if (lds > 160 * 1024) return -1;
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr = lds;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(wordlist_kernel<0>), (int)lds)) return rc;
     hipLaunchKernelGGL(wordlist_kernel<0>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
                        g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, wl_out, edge, nullptr, nullptr, nullptr, 0, beam);
     JLM_LAUNCH_CHECK();
@@ -235,13 +230,8 @@ extern "C" int jlm_wordlist_lse_perm(const jlm_segment *segs_host, int n_segs, c
     }
     size_t lds = wl_lds_bytes(beam, ldt);
     if (lds > 160 * 1024) return -1;
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr = lds;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(wordlist_kernel<1>), (int)lds)) return rc;
     hipLaunchKernelGGL(wordlist_kernel<1>, dim3(n_groups), dim3(WL_THREADS), lds, (hipStream_t)stream, t, b2, T, ldt,
                        g0, cnt, cnt_idx, wl, wl_w, wl_off, wl_idx, wl_base, nullptr, nullptr, run_max, run_sum, lse, merge, beam);
     JLM_LAUNCH_CHECK();
@@ -522,12 +512,9 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     if (lds > 160 * 1024) return -1;
     const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
                    : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;
-    static size_t attr[3] = {0, 0, 0};
-    if (lds > 64 * 1024 && lds > attr[mode]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr[mode] = lds;
-    }
+    static JlmLdsGrant grant[3];
+    if (lds > 64 * 1024)
+        if (int rc = jlm_grant_lds(grant[mode], fn, (int)lds)) return rc;
     if (mode == 0) hipLaunchKernelGGL(beam_step_kernel<0>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);
     else if (mode == 1) hipLaunchKernelGGL(beam_step_kernel<1>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);
     else hipLaunchKernelGGL(beam_step_kernel<2>, dim3(lat.n_sent), dim3(64), lds, (hipStream_t)stream, lat, st, frame, max_cands);

@@ -15,6 +15,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// Kernel attributes (the dynamic-LDS size a kernel may be launched with) are per DEVICE, and the launchers are called from several
+// host threads: every launch site's record of what it has already been granted is keyed by the current device and guarded by
+// one lock.  -3: the size could not be set (include/jlm_hip.h).
+#include <mutex>
+#define JLM_MAX_DEVICES 16
+struct JlmLdsGrant { int bytes[JLM_MAX_DEVICES]; };          // one zero-initialised static per (launch site, kernel)
+static inline int jlm_grant_lds(JlmLdsGrant &g, const void *fn, int bytes) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= JLM_MAX_DEVICES) return -3;
+    const std::lock_guard<std::mutex> lock(mu);
+    if (bytes > g.bytes[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -3;
+        g.bytes[dev] = bytes;
+    }
+    return 0;
+}
+
 struct SegTable {
     int n;
     jlm_segment s[JLM_MAX_SEGMENTS];

@@ -229,3 +229,35 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
     if (join) JLM_HIP(hipStreamWaitEvent(main_s, join, 0));
     return jlm_backtrace(lat, &st, p->out_nodes, p->out_len, p->out_score, p->stride, stream);
 }
+
+// ABI 8: the full-vocabulary normaliser of a few PROBE rows, in the form asked for -- what DeviceModel's load-time calibration
+// of the mixed rows runs (jlm_amd/model.py _calibrate_mixed): `steps` LSTM steps from the zero state over given words, the T
+// projection of the last step's rows, then jlm_vocab_lse_split (form 0) or exactly what jlm_decode_frames launches for a model
+// with mixed rows (form 1: jlm_pack_t_mixed + jlm_vocab_lse_mixed / _hybrid).  Row g = t * rows + r is hypothesis r after t
+// steps; rowlist[g] = g, prev[g] = g - rows (< 0 for block 1: zero state), word[g] = the word consumed by step t.
+extern "C" int jlm_lse_probe(const jlm_decode_model *m, const int *rowlist, const int *prev, const int *word, int steps, int rows,
+                             void *h, float *c, float *T, void *Tm, int ld_tm, int form, float *part, int max_parts, void *stream) {
+    if (steps < 1 || rows < 1 || !m->split_lstm || !m->wt8 || m->untied || m->self_norm || !m->split_segs || !m->pmt_split) return -2;
+    for (int t = 1; t <= steps; ++t)
+        JLM_TRY(jlm_lstm_step_xg(h, c, m->H, h, c, rowlist + (size_t)t * rows, prev, word, m->wt8, m->xgate8, m->H, m->gate_descale,
+                                 m->h_scale, nullptr, rows, nullptr, stream));
+    const int *rl = rowlist + (size_t)steps * rows;
+    JLM_TRY(jlm_gemm_nt_split(h, m->H, rl, m->pmt_split, m->H, nullptr, T, m->ldt, rl, nullptr, m->t_descale, rows, m->n_t, m->H,
+                              nullptr, stream));
+    if (form == 0)
+        return jlm_vocab_lse_split(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->n_segs, m->b2, T, m->ldt, rl,
+                                   part, rows, max_parts, rows, nullptr, stream);
+    if (!m->mixed_segs || !Tm) return -2;
+    jlm_segment only[JLM_MAX_SEGMENTS];
+    float only_ts[JLM_MAX_SEGMENTS];
+    int n_only = 0;
+    for (int i = 0; i < m->n_segs; ++i)
+        if (m->mixed_segs[i].B) { only[n_only] = m->mixed_segs[i]; only_ts[n_only++] = m->mixed_t_scale[i]; }
+    if (!n_only || jlm_mixed_t_stride(only, n_only) != ld_tm) return -1;
+    JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
+    if (n_only == m->n_segs)
+        return jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, m->n_segs, Tm, ld_tm, part, rows, max_parts,
+                                   rows, nullptr, stream);
+    return jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs, m->mixed_descale,
+                                m->mixed_s8, m->n_segs, m->b2, T, m->ldt, Tm, ld_tm, rl, part, rows, max_parts, rows, nullptr, stream);
+}

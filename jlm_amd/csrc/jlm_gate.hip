@@ -718,16 +718,12 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
                                 float h_scale, float *h_f32_out, int n_rows_max, const int *n_dev, void *stream) {
     if (H <= 0 || H % 32 != 0 || ld_state % 16 != 0 || ld_state < H) return -1;
     if (n_rows_max <= 0) return 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gate_xg_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        for (const void *k : gate_u16_variants()) {
-            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-        }
-        attr_done = true;
+    static JlmLdsGrant grant_base, grant_u16[16];
+    if (int rc = jlm_grant_lds(grant_base, reinterpret_cast<const void *>(gate_xg_kernel), GT_LDS_BYTES)) return rc;
+    {
+        int vi = 0;
+        for (const void *k : gate_u16_variants())
+            if (int rc = jlm_grant_lds(grant_u16[vi++ & 15], k, GT_LDS_BYTES)) return rc;
     }
     GateXgArgs a;
     a.h = reinterpret_cast<const float *>(h_in); a.c_in = c_in; a.h_out = reinterpret_cast<float *>(h_out); a.c_out = c_out;

@@ -481,14 +481,10 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm2_kernel(ARows A, BRows B, 
 
 template <class Cfg, class ARows, class BRows, class Epi>
 static int launch_gemm2(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
-    static bool attr_done = false;
     auto kern = gemm2_kernel<Cfg, ARows, BRows, Epi>;
     constexpr int lds = Lds2<Cfg>::BYTES;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(kern), lds)) return rc;
     TileMap tm;
     tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
     tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
@@ -722,14 +718,10 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_split3_kernel(ARows A, BRo
 
 template <class Cfg, class ARows, class BRows, class Epi, int NST>
 static int launch_gemm_split3(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
-    static bool attr_done = false;
     auto kern = gemm_split3_kernel<Cfg, ARows, BRows, Epi, NST>;
     constexpr int lds = Lds2<Cfg>::BYTES / 2 * NST;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(kern), lds)) return rc;
     TileMap tm;
     tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
     tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;
@@ -742,14 +734,10 @@ static int launch_gemm_split3(const ARows &A, const BRows &B, int K, const Epi &
 
 template <class Cfg, class ARows, class BRows, class Epi>
 static int launch_gemm_split(const ARows &A, const BRows &B, int K, const Epi &epi, int xcd, hipStream_t st) {
-    static bool attr_done = false;
     auto kern = gemm_split_kernel<Cfg, ARows, BRows, Epi>;
     constexpr int lds = Lds2<Cfg>::BYTES;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(kern), lds)) return rc;
     TileMap tm;
     tm.tiles_m = (A.nrows + Cfg::BM - 1) / Cfg::BM;
     tm.tiles_n = (B.nrows + Cfg::BN - 1) / Cfg::BN;

@@ -99,9 +99,12 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
     const int lane = threadIdx.x & 63;
     const float *trow = T + (size_t)g * ldt;
     unsigned char *orow = Tm + (size_t)r * ld_tm * 4;          // COMPACT: packed row r = hypothesis row rows[r]
+    // (the launcher admits at most 64 groups -- 32 blocks -- per row: ONE pass, so every segment's maximum is reduced over all of
+    //  the lanes that hold it before anything is quantised)
     int total = 0;
     for (int si = 0; si < a.n_segs; ++si) total += 2 * a.seg[si].nb;
-    for (int grp0 = 0; grp0 < total; grp0 += 64) {
+    {
+        const int grp0 = 0;
         const int grp = grp0 + lane;
         int si = 0, base = 0;                         // the group's segment
         while (si + 1 < a.n_segs && grp >= base + 2 * a.seg[si].nb) { base += 2 * a.seg[si].nb; ++si; }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
                 *reinterpret_cast<float *>(orow + ld_tm * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sj) = x > 0.0f ? __int_as_float(bt) : 1.0f;
             }
         }
-        if (!act) continue;
+        if (!act) return;
         const float want = smax * (1.0f / 127.0f);
         const int bits = (__float_as_int(want) + 0x007fffff) & 0x7f800000;
         const float s_t = smax > 0.0f ? __int_as_float(bits) : 1.0f;
@@ -291,15 +294,19 @@ static int mx_seg_blocks(const jlm_segment &sg) {
     return (nb == (sg.k + 2 + 31) / 32 || nb == (sg.k + 31) / 32) ? nb : -1;
 }
 
-// Row stride (4-byte units) of the packed rows for these segments: the segments' blocks + JLM_MAX_SEGMENTS scale floats
+// Row stride (4-byte units) of the packed rows for these segments: the segments' blocks + JLM_MAX_SEGMENTS scale floats.
+// -2: more than MX_MAX_ROW_BLOCKS blocks per row in total (the packer holds a row's 16-value groups in the 64 lanes of one wave)
+#define MX_MAX_ROW_BLOCKS 32
 extern "C" int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS) return -1;
-    int b = 0;
+    int b = 0, blocks = 0;
     for (int i = 0; i < n_segs; ++i) {
         const int nb = mx_seg_blocks(segs_host[i]);
         if (nb < 0) return -1;
         b += nb * 128;
+        blocks += nb;
     }
+    if (blocks > MX_MAX_ROW_BLOCKS) return -2;
     return (b + 4 * JLM_MAX_SEGMENTS + 15) / 16 * 4;
 }
 
@@ -307,7 +314,12 @@ extern "C" int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs) {
 // t_scale[i] = 2^eT_i (a power of two: x = T 2^eT log2 e).
 extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
                                 int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream) {
-    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || ld_tm != jlm_mixed_t_stride(segs_host, n_segs)) return -1;
+    if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4) return -1;
+    {
+        const int want = jlm_mixed_t_stride(segs_host, n_segs);
+        if (want == -2) return -2;
+        if (ld_tm != want) return -1;
+    }
     if (n_rows_max <= 0) return 0;
     MxTArgs a;
     a.n_segs = n_segs;
@@ -450,13 +462,10 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         if (xbias) { if (nb != 8) which = 3; }
         else if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4))) which = 1;
     }
-    static int attr[4] = {0, 0, 0, 0};
+    static JlmLdsGrant grant[4];
     const void *fns[4] = {reinterpret_cast<const void *>(MX_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MX_KERNEL_GENERIC),
                           reinterpret_cast<const void *>(MX_KERNEL_TIED), reinterpret_cast<const void *>(MX_KERNEL_GENERIC_XB)};
-    if (lds > attr[which]) {
-        if (hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
-        attr[which] = lds;
-    }
+    if (int rc = jlm_grant_lds(grant[which], fns[which], lds)) return rc;
     const dim3 grid(n_cols * n_ptiles), block(512);
     float2 *part2 = reinterpret_cast<float2 *>(part);
     hipStream_t st = (hipStream_t)stream;

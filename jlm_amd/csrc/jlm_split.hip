@@ -934,15 +934,9 @@ extern "C" int jlm_vocab_lse_split(const jlm_segment *segs_host, const float *t_
     const int given = n_sub;
     if (given > max_parts) return -1;
     const int lds = (2 * 128 * 64 + 3 * 128) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_split8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
+    static JlmLdsGrant grant4, grant8;
+    if (int rc = jlm_grant_lds(grant4, reinterpret_cast<const void *>(vocab_lse_split_kernel), lds)) return rc;
+    if (int rc = jlm_grant_lds(grant8, reinterpret_cast<const void *>(vocab_lse_split8_kernel), lds)) return rc;
     const int grid = np * n_ptiles;
     if (nw == 8)
         hipLaunchKernelGGL(vocab_lse_split8_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a, T, ldt, rows,
@@ -1125,12 +1119,8 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
     a.n_cols = n_cols;
     a.n_sub = n_sub;
     if (n_sub > max_parts) return -1;
-    static int attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(vocab_lse_hybrid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -3;
-        attr = lds;
-    }
+    static JlmLdsGrant grant;
+    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(vocab_lse_hybrid_kernel), lds)) return rc;
     hipLaunchKernelGGL(vocab_lse_hybrid_kernel, dim3(n_cols * n_ptiles), dim3(512), lds, (hipStream_t)stream, h, T, ldt,
                        reinterpret_cast<const float *>(Tm), ld_tm, rows, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
@@ -1322,13 +1312,8 @@ extern "C" int jlm_wordlist_lse_split(const jlm_segment *seg_host, float t_scale
     hipStream_t st = (hipStream_t)stream;
 #define JLM_WLS_LAUNCH(N)                                                                                                  \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_lse_split_kernel<N>),                          \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
-                return -3;                                                                                                 \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        static JlmLdsGrant grant;                                                                                          \
+        if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(wordlist_lse_split_kernel<N>), lds)) return rc;          \
         hipLaunchKernelGGL(wordlist_lse_split_kernel<N>, dim3(n_groups, (beam + 31) / 32), dim3(256), lds, st, sg, t_scale, descale, b2, T, ldt, \
                            g0, cnt, cnt_idx, wl, wl_off, wl_idx, wl_base, run_max, run_sum, lse, merge, beam);             \
     } while (0)
@@ -1482,13 +1467,8 @@ extern "C" int jlm_wordlist_merge_split(const jlm_segment *seg_host, float t_sca
 #define JLM_WLM_LAUNCH(N)                                                                                                  \
     do {                                                                                                                   \
         const int lds = (WLM_MAX_WORDS * ((N + 3) / 4) * 64 + 2 * WLM_MAX_WORDS) * 4;                                                      \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wordlist_merge_split_kernel<N>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                        \
-                return -3;                                                                                                 \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        static JlmLdsGrant grant;                                                                                          \
+        if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(wordlist_merge_split_kernel<N>), lds)) return rc;          \
         hipLaunchKernelGGL(wordlist_merge_split_kernel<N>, dim3(n_sent), dim3(256), lds, st, sg, t_scale, descale, b2, T,  \
                            ldt, cnt, n_sent, beam, n_old_frames, wl, wl_off, wl_base, run_max, run_sum, lse);              \
     } while (0)

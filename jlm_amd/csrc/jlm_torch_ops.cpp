@@ -398,6 +398,27 @@ void dequant_u8(const Tensor &code, int64_t rows, int64_t k, int64_t ld_code, co
               "jlm_dequant_u8");
 }
 
+// the normaliser slices of a few probe rows in one of its forms (jlm_lse_probe, include/jlm_hip.h ABI 8): -> number of slices, -2
+// when the model has no such form
+int64_t lse_probe(const c10::intrusive_ptr<JlmModel> &model, const Tensor &rowlist, const Tensor &prev, const Tensor &word, int64_t steps,
+                  int64_t rows, const Tensor &h, const Tensor &c, const Tensor &T, const OptTensor &Tm, int64_t ld_tm, int64_t form,
+                  const Tensor &part, int64_t max_parts) {
+    const int64_t G = (steps + 1) * rows;
+    TORCH_CHECK(steps >= 1 && rows >= 1 && rowlist.numel() >= G && prev.numel() >= G && word.numel() >= G, "jlm.lse_probe: index arrays");
+    TORCH_CHECK(rowlist.scalar_type() == at::kInt && prev.scalar_type() == at::kInt && word.scalar_type() == at::kInt, "jlm.lse_probe: int32 indices");
+    TORCH_CHECK(h.numel() >= G * model->m.H && c.numel() >= G * model->m.H && T.numel() >= G * model->m.ldt, "jlm.lse_probe: state buffers");
+    TORCH_CHECK(part.numel() >= max_parts * rows * 2 && max_parts >= 1, "jlm.lse_probe: slice buffer");
+    TORCH_CHECK(!Tm.has_value() || !Tm->defined() || Tm->numel() >= rows * ld_tm, "jlm.lse_probe: packed-row buffer");
+    const c10::hip::HIPGuard device_guard(h.device().index());
+    const std::lock_guard<std::mutex> lock(g_enqueue_mutex);
+    const int rc = jlm_lse_probe(&model->m, ptr<const int>(rowlist, "rowlist"), ptr<const int>(prev, "prev"), ptr<const int>(word, "word"),
+                                 (int)steps, (int)rows, ptr<void>(h, "h"), ptr<float>(c, "c"), ptr<float>(T, "T"), optr<void>(Tm, "Tm"),
+                                 (int)ld_tm, (int)form, ptr<float>(part, "part"), (int)max_parts, stream_of(h));
+    if (rc == -2 || rc >= 1) return rc;
+    jlm_check(rc == 0 ? -1 : rc, "jlm_lse_probe");
+    return rc;
+}
+
 int64_t abi_version() { return jlm_abi_version(); }
 int64_t beam_step_max_cands(int64_t beam, int64_t n_frames, int64_t mode) { return jlm_beam_step_max_cands((int)beam, (int)n_frames, (int)mode); }
 
@@ -423,6 +444,8 @@ TORCH_LIBRARY(jlm, m) {
     m.def("pack_mixed(Tensor src, int src_off, int rows, int k, int ld, Tensor bias, int bias_off, float scale, float bias_scale, float s8, "
           "Tensor(a!) dst, int ld_dst) -> ()", pack_mixed);
     m.def("dequant_u8(Tensor code, int rows, int k, int ld_code, Tensor codebook, Tensor(a!) dst, int ld_dst) -> ()", dequant_u8);
+    m.def("lse_probe(__torch__.torch.classes.jlm.Model model, Tensor rowlist, Tensor prev, Tensor word, int steps, int rows, Tensor(a!) h, "
+          "Tensor(b!) c, Tensor(c!) T, Tensor? Tm, int ld_tm, int form, Tensor(d!) part, int max_parts) -> int", lse_probe);
     m.def("abi_version() -> int", abi_version);
     m.def("beam_step_max_cands(int beam, int n_frames, int mode) -> int", beam_step_max_cands);
 }

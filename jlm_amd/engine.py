@@ -31,6 +31,7 @@ csrc/jlm_decode.hip): no host work between the frames.  Replaying a captured hip
 slower everywhere once the loop was native and is gone.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -202,7 +203,18 @@ class DecodeEngine:
         self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
-        self.pipelined = False          # set by the caller around a pipelined sequence of submits (Decoder.decode_batch)
+        # `pipelined`: set by the caller around a pipelined sequence of submits (Decoder.decode_batch).  Per THREAD: two threads inside
+        # decode_batch on the same decoder must not clear each other's flag (it decides the CU share, i.e. the vocabulary kernel's
+        # column cuts, of every batch the thread submits meanwhile)
+        self._tls = threading.local()
+
+    @property
+    def pipelined(self):
+        return getattr(self._tls, "pipelined", False)
+
+    @pipelined.setter
+    def pipelined(self, v):
+        self._tls.pipelined = bool(v)
 
     def _ctx(self):
         return self.m._ctx()
@@ -219,7 +231,10 @@ class DecodeEngine:
                 self.plans.append(self.plans.pop(i))
                 return p
         caps = {k: _round_up(int(v * 1.25) + 64, 1024) for k, v in need.items()}
-        caps["cands"] = max(_round_up(need["cands"], 256), 1024)
+        # (at least 1 024 where the beam step's LDS takes that many: wide beams over many frames take fewer -- a batch that passed
+        #  Decoder._check_cells must also pass the launcher's LDS formula)
+        lim = int(ops.backend().beam_step_max_cands(int(lat.beam), fkey, 2 if kind == "dynamic" else (1 if self.m.self_norm else 0)))
+        caps["cands"] = max(_round_up(need["cands"], 256), min(1024, lim) if lim > 0 else 1024)
         self.plans = [p for p in self.plans if p.busy or p.key != key or p.fits(need)]
         p = _Plan(self, key, caps)
         # Least recently used idle plans go when the set outgrows its budget: a count for the big batch plans (hundreds

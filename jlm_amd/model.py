@@ -380,6 +380,67 @@ class DeviceModel:
                 del wt8
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
+            self._calibrate_mixed()
+
+    CALIB_ROWS, CALIB_STEPS, CALIB_SEED = 256, 3, 20240929
+
+    def _calibrate_mixed(self):
+        """Load-time calibration of the mixed rows ON THIS MODEL (round 4).  The int8 cross terms are good to ~2^-20 of |t||b| per
+        product (three f16 passes: 2^-23), so the error of the log-normaliser grows with the model's logit range and with how peaked
+        its next-word distributions are -- neither of which the blocks' spread (``_build_mixed``) sees: output embeddings x 20
+        (logits of +-20) leave the spread at 5 and move path scores by 4e-5 .. 3e-4 against a tolerance of 2e-5.  So the model is
+        asked: ``CALIB_ROWS`` hypotheses take ``CALIB_STEPS`` LSTM steps over seeded random words from the zero state (the
+        model's own dynamics give the T rows their real size and direction), and the full-vocabulary normaliser of those rows runs
+        in both forms -- the very kernels the decode launches (torch.ops.jlm.lse_probe -> jlm_lse_probe, include/jlm_hip.h ABI 8).
+        The root-mean-square difference of the two log-normalisers is the per-frame error the mixed rows add to a path score (the
+        split form's own error is 10x below it wherever it matters); above ``JLM_MIXED_MAX_LSE_RMS`` the model stays on split
+        rows.  Measured on the trained-model-like fixtures (numpy emulation and GPU): the worst path score of 20-kana sentences moves
+        by ~10 x this rms, so the default 1.0e-6 keeps scores inside 1e-5, half the test suite's tolerance.  ``mixed_calib`` records the measurement either way (bench.py prints it)."""
+        self.mixed_calib = None
+        if not getattr(self, "mixed_idx", None) or not self.split_lstm or self.pmt_split is None or self.mode == "untied":
+            return
+        limit = float(os.environ.get("JLM_MIXED_MAX_LSE_RMS", "1.0e-6"))
+        if not (limit > 0.0):
+            return
+        torch, O = self.torch, _ops.backend()
+        R, S, H = self.CALIB_ROWS, self.CALIB_STEPS, self.H
+        G = (S + 1) * R
+        rng = np.random.RandomState(self.CALIB_SEED)
+        word = np.zeros(G, dtype=np.int32)
+        word[R:] = rng.randint(0, self.V, size=S * R)
+        dev = self.device
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        rowlist, prev, word = i32(np.arange(G)), i32(np.arange(G) - R), i32(word)
+        max_parts = 128
+        dm = self.decode_model()
+        lse = []
+        with self._ctx():
+            for form in (0, 1):
+                h = torch.zeros((G, H), dtype=torch.float32, device=dev)
+                c = torch.zeros((G, H), dtype=torch.float32, device=dev)
+                T = torch.zeros((G, self.ldt), dtype=torch.float32, device=dev)
+                Tm = torch.zeros((R, self.ld_tm), dtype=torch.float32, device=dev)
+                part = torch.zeros((max_parts, R, 2), dtype=torch.float32, device=dev)
+                n = int(O.lse_probe(dm, rowlist, prev, word, S, R, h, c, T, Tm, self.ld_tm, form, part, max_parts))
+                if n < 1:
+                    return                               # a model the probe does not cover: the spread gate alone decides
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                p = part[:n].double().cpu().numpy()
+                with np.errstate(divide="ignore"):
+                    v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
+                mx = v.max(axis=0)
+                lse.append(mx + np.log(np.exp(v - mx).sum(axis=0)))
+        d = lse[1] - lse[0]
+        rms, worst = float(np.sqrt(np.mean(d * d))), float(np.abs(d).max())
+        keep = bool(np.isfinite(rms) and rms <= limit)
+        self.mixed_calib = dict(rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst, limit=limit, kept=keep,
+                                lse_mean=float(np.mean(lse[0])))
+        if not keep:
+            self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []
+            self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [], [], []
+            self.ld_tm, self.b2_log2 = 0, None
+            self._decode_model = None
 
     # (k + 2 -> 32-k blocks, 16-k f16 steps) with inlined mixed-row bodies: k = 200, 100, 50 (csrc/jlm_mixed.hip MX_KERNEL_DSOFTMAX; the
     # first two also in csrc/jlm_split.hip vocab_lse_hybrid_kernel, beside split-row bodies for other short segments)
@@ -410,6 +471,13 @@ class DeviceModel:
             elif not (nv > 0 and k <= 64 and self.split_bias_col[i] == k):
                 return
         if not take or (xbias and len(xbias) != len(self.segments)):      # (one bias form per launch)
+            return
+        # the packer of the hypothesis rows holds a row's blocks in one wave: 32 blocks per row at most (jlm_mixed_t_stride: -2)
+        if sum((self.segments[i]["k"] // 32) if i in xbias else (self.segments[i]["k"] + 2 + 31) // 32 for i in take) > 32:
+            return
+        # the hybrid launch (mixed + split segments) hosts mixed bodies for k = 200 and 100 only: any other mix stays on split rows
+        if len(take) != len(self.segments) and any(((self.segments[i]["k"] + 2 + 31) // 32, (self.segments[i]["k"] + 2 + 15) // 16)
+                                                   not in ((7, 13), (4, 7)) for i in take):
             return
         # The int8 planes carry ONE scale per segment (the power of two at or above max|hi| / 127): the quantisation step of a word's hi8
         # is max|B| / 254 whatever the word's own size, so the error grows with the block's spread max|B| / rms B: Gaussian-like blocks

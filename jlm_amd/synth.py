@@ -128,12 +128,59 @@ def make_weights(cfg, seed=7, scale=0.05):
     return weights
 
 
-def write_experiment(root, exp_id, cfg, seed=7, scale=0.05):
+def _output_blocks(weights):
+    """(key, index-or-None) of every output-embedding block of a weight dict (LM, the D_softmax block list, LM0..)"""
+    out = []
+    for key in sorted(weights):
+        if key.startswith("LM"):
+            if isinstance(weights[key], list):
+                out += [(key, i) for i in range(len(weights[key]))]
+            else:
+                out.append((key, None))
+    return out
+
+
+def shape_weights(weights, cfg, shape, seed=7):
+    """Statistics a TRAINED model has and N(0, 0.05^2) draws do not (the reference ships no weights; its claims are about trained
+    language models, README.md:6,15,72).  In place, on top of make_weights' draws, from a stream of its own:
+
+      peaked<N>  output embeddings x N (N = 10 if absent): logits of +-N (peaked next-word distributions), and a unigram-like bias
+                 b2[w] = -log(w + 8) (the lexicon is sorted by frequency, reference data.py:33,44: frequent words first)
+      heavy      output-embedding blocks redrawn from Student-t(3) at the same standard deviation: max|B| / rms B in the hundreds
+                 (outlier rows and columns, as trained embeddings have), same unigram-like bias
+    """
+    if not shape:
+        return weights
+    rng = np.random.RandomState(seed + 1000)
+    V = cfg["vocab_size"]
+    if shape.startswith("peaked"):
+        mult = np.float32(float(shape[6:]) if len(shape) > 6 else 10.0)
+        for key, i in _output_blocks(weights):
+            if i is None:
+                weights[key] = weights[key] * mult
+            else:
+                weights[key][i] = weights[key][i] * mult
+    elif shape == "heavy":
+        for key, i in _output_blocks(weights):
+            blk = weights[key] if i is None else weights[key][i]
+            std = float(blk.std())
+            new = (rng.standard_t(3, size=blk.shape) * (std / np.sqrt(3.0))).astype(np.float32)
+            if i is None:
+                weights[key] = new
+            else:
+                weights[key][i] = new
+    else:
+        raise ValueError(shape)
+    weights["b2"] = (-np.log(np.arange(V, dtype=np.float64) + 8.0)).astype(np.float32)
+    return weights
+
+
+def write_experiment(root, exp_id, cfg, seed=7, scale=0.05, shape=None):
     d = os.path.join(root, "train", "experiments", str(exp_id))
     os.makedirs(os.path.join(d, "weights"), exist_ok=True)
     with open(os.path.join(d, "config.json"), "wt") as f:
         f.write(json.dumps(cfg))
-    weights = make_weights(cfg, seed, scale)
+    weights = shape_weights(make_weights(cfg, seed, scale), cfg, shape, seed)
     with open(os.path.join(d, "weights", "lstm_weights.pkl"), "wb") as f:
         pickle.dump(weights, f)
     return weights
@@ -239,11 +286,16 @@ def build_fixture(root, name, exp_id=1):
       wide128-tied                                 tied, E = 128: mixed rows without bias columns (the form of the tied k = 256 models)
       mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
+      peaked-{vtable,tied} / peaked20-{vtable,tied} / heavy-{vtable,tied}
+                                                  the mid-* models with trained-model-like output embeddings (shape_weights): logits
+                                                  of +-10 / +-20 and a unigram-like bias; Student-t(3) blocks
     """
     parts = name.split("-")
     size, mode = parts[0], parts[1]
     self_norm = len(parts) > 2 and parts[2] == "sn"
-    alphabet, scale = 80, 0.05
+    alphabet, scale, shape = 80, 0.05, None
+    if size in ("peaked", "peaked20", "heavy"):
+        shape, size = size, "mid"
     if size == "small":
         scale = 0.25                      # keeps the tiny model's logits O(1)
         V, H, E, segs, alphabet = 2000, 64, 32, small_segs(2000), 12
@@ -264,7 +316,7 @@ def build_fixture(root, name, exp_id=1):
         raise ValueError(name)
     cfg = make_config(V, H, E, mode, segs, self_norm)
     lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet)
-    write_experiment(root, exp_id, cfg, scale=scale)
+    write_experiment(root, exp_id, cfg, scale=scale, shape=shape)
     if size == "small":
         write_arpa(root, lexicon, V)      # the n-gram baseline's model file (decoder/model_ngram.py reads data/lm3)
     return cfg, lexicon, reading_dict, alphabet

@@ -43,7 +43,41 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 7
+        return 8
+
+    def jlm_lse_probe(self, m, rowlist, prev, word, steps, rows, h, c, T, Tm, ld_tm, form, part, max_parts, stream):
+        """ABI 8 (csrc/jlm_decode.hip): `steps` LSTM steps from the zero state, T of the last block, its normaliser slices"""
+        if steps < 1 or rows < 1 or not m.split_lstm or not m.wt8 or m.untied or m.self_norm or not m.split_segs or not m.pmt_split:
+            return -2
+        for t in range(1, steps + 1):
+            rc = self.jlm_lstm_step_xg(h, c, m.H, h, c, _p(rowlist) + 4 * t * rows, prev, word, m.wt8, m.xgate8, m.H, m.gate_descale,
+                                       m.h_scale, None, rows, None, stream)
+            if rc:
+                return rc
+        rl = _p(rowlist) + 4 * steps * rows
+        rc = self.jlm_gemm_nt_split(h, m.H, rl, m.pmt_split, m.H, None, T, m.ldt, rl, None, m.t_descale, rows, m.n_t, m.H, None, stream)
+        if rc:
+            return rc
+        if form == 0:
+            return self.jlm_vocab_lse_split(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.n_segs, m.b2, T, m.ldt, rl,
+                                            part, rows, max_parts, rows, None, stream)
+        if not m.mixed_segs or not _p(Tm):
+            return -2
+        from jlm_amd import _lib
+        idx = [i for i in range(m.n_segs) if m.mixed_segs[i].B]
+        if not idx:
+            return -1
+        only = (_lib.Segment * len(idx))(*[m.mixed_segs[i] for i in idx])
+        if self.jlm_mixed_t_stride(only, len(idx)) != ld_tm:
+            return -1
+        rc = self.jlm_pack_t_mixed(only, [m.mixed_t_scale[i] for i in idx], len(idx), T, m.ldt, rl, rows, None, Tm, ld_tm, stream)
+        if rc:
+            return rc
+        if len(idx) == m.n_segs:
+            return self.jlm_vocab_lse_mixed(m.mixed_segs, m.mixed_descale, m.mixed_s8, m.mixed_bias2, m.n_segs, Tm, ld_tm, part, rows,
+                                            max_parts, rows, None, stream)
+        return self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs, m.mixed_descale,
+                                         m.mixed_s8, m.n_segs, m.b2, T, m.ldt, Tm, ld_tm, rl, part, rows, max_parts, rows, None, stream)
 
     def jlm_beam_step_max_cands(self, beam, n_frames, mode):
         """the launcher's LDS formula (csrc/jlm_beam.hip, beam_step_lds_bytes)"""
@@ -544,12 +578,19 @@ class FakeLib:
             if segs[i].ldb % 32 or segs[i].ldb // 32 not in ((segs[i].k + 2 + 31) // 32, (segs[i].k + 31) // 32):
                 return -1
         b = sum(segs[i].ldb * 4 for i in range(n_segs))
+        if b // 128 > 32:
+            return -2
         return (b + 4 * 8 + 15) // 16 * 4
 
     def jlm_pack_t_mixed(self, segs, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream):
         """packed row r (COMPACT) = hypothesis row rows[r]; per segment the blocks of x = T 2^eT log2 e, the bias constants at
         f16 columns k, k + 1, and the row's int8 scale per segment in the last 8 floats of the row"""
-        if n_segs < 1 or n_segs > 8 or ldt % 4 or ld_tm != self.jlm_mixed_t_stride(segs, n_segs):
+        if n_segs < 1 or n_segs > 8 or ldt % 4:
+            return -1
+        want = self.jlm_mixed_t_stride(segs, n_segs)
+        if want == -2:
+            return -2
+        if ld_tm != want:
             return -1
         n = _n(n_rows_max, n_dev)
         if n <= 0:
@@ -1047,6 +1088,14 @@ class FakeOps:
     def frame_times(self, plan):
         import torch
         return torch.full((plan.timed_frames, 5), 1e-3, dtype=torch.float64)
+
+    def lse_probe(self, model, rowlist, prev, word, steps, rows, h, c, T, Tm, ld_tm, form, part, max_parts):
+        o = self._o
+        rc = self.lib.jlm_lse_probe(model.m, o(rowlist), o(prev), o(word), int(steps), int(rows), o(h), o(c), o(T), o(Tm), int(ld_tm),
+                                    int(form), o(part), int(max_parts), 0)
+        if rc == -2 or rc >= 1:
+            return rc
+        self._chk(rc if rc else -1, "jlm_lse_probe")
 
     def lstm_step(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E, n_rows_max, n_dev):
         o = self._o

@@ -1,0 +1,149 @@
+"""GPU: the kernel that IS on the hot path -- jlm_vocab_lse_mixed (f16 hi.hi + int8 cross terms; csrc/jlm_mixed.hip), fed by
+jlm_pack_t_mixed -- against the golden vectors captured from the reference (tests/golden/lm_steps.npz; reference
+decoder/model.py:106-123, 141-193), on the Gaussian fixtures AND on the trained-model-like ones (peaked logits, heavy tails).
+
+Same debug view as tests/test_gpu_split_logits.py: over a ONE-word vocabulary range the kernel's log-sum-exp is that word's logit,
+so the production kernel is launched once per sampled column with a one-word segment table (its hypothesis rows packed for that
+segment by the production packer); then the full-vocabulary launch against the reference's logsumexp(y) = y[col] - log(pred[col]).
+The mixed rows are built here whatever the load-time gates would decide (JLM_MIXED_MAX_SPREAD / JLM_MIXED_MAX_LSE_RMS lifted): what
+the gates decide is tested in test_mixed_row_gates_follow_the_models_logit_range below."""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from jlm_amd import _lib, config as jconfig            # noqa: E402
+from tests import golden_cases as gc                      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+N_COLS = 48
+FIXTURES = ["mid-vtable", "mid-tied", "peaked-vtable", "peaked20-vtable", "peaked-tied", "peaked20-tied", "heavy-vtable"]
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _lse_of_parts(part, n_parts, rows):
+    p = part[:n_parts, :rows].cpu().numpy().astype(np.float64)
+    with np.errstate(divide="ignore"):
+        v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
+    mx = v.max(axis=0)
+    return mx + np.log(np.exp(v - mx).sum(axis=0))
+
+
+def _model(name, fx, monkeypatch, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    f = fx(name)
+    jconfig.set_root(f["root"])
+    from jlm_amd.model import LSTM_Model
+    return f, LSTM_Model(1).dev
+
+
+def _step_rows(m, L, cfg, rows):
+    """the golden step sequence through the production step kernels -> (T [G, ldt], compact list of the last block's rows)"""
+    idx, _subset, cols, h0, c0 = gc.lm_inputs(cfg, rows)
+    steps, H, ldt, dev = gc.LM_STEPS, m.H, m.ldt, m.device
+    G = rows * (steps + 1)
+    hf = torch.zeros((G, H), dtype=torch.float32, device=dev)
+    hf[:rows] = torch.as_tensor(h0, dtype=torch.float32)
+    hs = torch.zeros_like(hf)
+    assert L.jlm_pack_split_f16(hf.data_ptr(), rows, H, H, float(m.h_scale), hs.data_ptr(), H, _st()) == 0
+    cs = torch.zeros((G, H), dtype=torch.float32, device=dev)
+    cs[:rows] = torch.as_tensor(c0, dtype=torch.float32)
+    T = torch.zeros((G, ldt), dtype=torch.float32, device=dev)
+    prev = torch.arange(G, dtype=torch.int32, device=dev) - rows
+    word = torch.zeros(G, dtype=torch.int32, device=dev)
+    for t in range(steps):
+        word[rows * (t + 1):rows * (t + 2)] = torch.as_tensor(idx[t], dtype=torch.int32)
+    for t in range(steps):
+        r = torch.arange(rows * (t + 1), rows * (t + 2), dtype=torch.int32, device=dev)
+        assert L.jlm_lstm_step_xg(hs.data_ptr(), cs.data_ptr(), H, hs.data_ptr(), cs.data_ptr(), r.data_ptr(), prev.data_ptr(),
+                                  word.data_ptr(), m.wt8.data_ptr(), m.xgate8.data_ptr(), H, float(m.gate_descale),
+                                  float(m.h_scale), None, rows, None, _st()) == 0
+        assert L.jlm_gemm_nt_split(hs.data_ptr(), H, r.data_ptr(), m.pmt_split.data_ptr(), H, None, T.data_ptr(), ldt,
+                                   r.data_ptr(), None, float(m.t_descale), rows, m.pmt.shape[0], H, None, _st()) == 0
+    torch.cuda.synchronize()
+    last = torch.arange(rows * steps, rows * (steps + 1), dtype=torch.int32, device=dev)
+    return T, last, cols
+
+
+def _mixed_lse(m, L, segs, ts, ds, s8, bias2, T, last, rows, part):
+    """pack the rows for exactly these segments, run the mixed normaliser on them -> log-sum-exp per row"""
+    n = len(segs)
+    arr = (_lib.Segment * n)(*segs)
+    ld_tm = L.jlm_mixed_t_stride(arr, n)
+    assert ld_tm > 0
+    Tm = torch.zeros((rows, ld_tm), dtype=torch.float32, device=m.device)
+    assert L.jlm_pack_t_mixed(arr, (ctypes.c_float * n)(*ts), n, T.data_ptr(), m.ldt, last.data_ptr(), rows, None, Tm.data_ptr(), ld_tm,
+                              _st()) == 0
+    r = L.jlm_vocab_lse_mixed(arr, (ctypes.c_float * n)(*ds), (ctypes.c_float * n)(*s8), bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(),
+                              rows, part.shape[0], rows, None, _st())
+    assert r >= 1, r
+    torch.cuda.synchronize()
+    return _lse_of_parts(part, r, rows)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_mixed_kernel_step_logits_within_1e4_of_reference(name, fx, golden_lm, monkeypatch):
+    f, m = _model(name, fx, monkeypatch, JLM_MIXED_MAX_SPREAD="1e30", JLM_MIXED_MAX_LSE_RMS="0", JLM_LSE_MIXED="1")
+    assert m.mixed_idx == list(range(m.n_segs)), "every segment of these fixtures has a mixed-row shape"
+    L = _lib.lib()
+    bias2 = m.b2_log2.data_ptr() if m.b2_log2 is not None else None
+    worst_rel, worst_abs, worst_lse = 0.0, 0.0, 0.0
+    for rows in gc.LM_ROWS:
+        T, last, cols = _step_rows(m, L, f["cfg"], rows)
+        key = "%s/full/R%d" % (name, rows)
+        yref_all, pref_all = golden_lm[key + "/y"], golden_lm[key + "/pred"]
+        pick = np.unique(np.linspace(0, len(cols) - 1, N_COLS).astype(int))
+        part = torch.zeros((128, rows, 2), dtype=torch.float32, device=m.device)
+        y = np.zeros((rows, len(pick)))
+        for j, ci in enumerate(pick):
+            w = int(cols[ci])
+            i = next(q for q, sg in enumerate(m.mixed_segments) if sg["v_start"] <= w < sg["v_end"])
+            sg = m.mixed_segments[i]
+            one = _lib.Segment(w, w + 1, sg["k"], sg["t_off"], m.seg_mixed[i].data_ptr() + 4 * sg["ldb"] * (w - sg["v_start"]), sg["ldb"])
+            y[:, j] = _mixed_lse(m, L, [one], [m.mixed_t_scale[i]], [m.mixed_descale[i]], [m.mixed_s8[i]], bias2, T, last, rows, part)
+        yref = yref_all[:, pick]
+        scale = np.abs(yref_all).max(axis=1, keepdims=True)
+        rel = np.abs(y - yref) / scale
+        worst_rel = max(worst_rel, float(rel.max()))
+        assert rel.max() <= 1e-4, (key, rel.max())
+        # element-wise as well: |dy| <= 1e-4 max(|y|, 1)
+        el = np.abs(y - yref) / np.maximum(np.abs(yref), 1.0)
+        worst_abs = max(worst_abs, float(el.max()))
+        assert el.max() <= 1e-4, (key, el.max())
+        # the full-vocabulary launch: every segment, equal-cost columns, the fold across sub-ranges
+        segs = [_lib.Segment(sg["v_start"], sg["v_end"], sg["k"], sg["t_off"], m.seg_mixed[i].data_ptr(), sg["ldb"])
+                for i, sg in enumerate(m.mixed_segments)]
+        lse = _mixed_lse(m, L, segs, m.mixed_t_scale, m.mixed_descale, m.mixed_s8, bias2, T, last, rows, part)
+        lse_ref = np.median(yref_all.astype(np.float64) - np.log(pref_all.astype(np.float64)), axis=1)
+        worst_lse = max(worst_lse, float(np.abs(lse - lse_ref).max()))
+        assert np.abs(lse - lse_ref).max() <= 1e-4 * max(1.0, np.abs(lse_ref).max()), (key, np.abs(lse - lse_ref).max())
+    print("%s: mixed kernel vs reference: logits %.2e of the row scale, %.2e element-wise; log-sum-exp %.2e absolute" % (
+        name, worst_rel, worst_abs, worst_lse))
+
+
+# fixture -> does the DEFAULT load keep the mixed rows?  (the peaked20 models' path scores would move by 4e-5 .. 1e-4 on them)
+GATES = [("mid-vtable", True), ("mid-tied", True), ("peaked-vtable", True), ("peaked20-vtable", False), ("peaked20-tied", False),
+         ("heavy-vtable", False)]
+
+
+@pytest.mark.parametrize("name,kept", GATES)
+def test_mixed_row_gates_follow_the_models_logit_range(name, kept, fx, monkeypatch):
+    """DeviceModel._build_mixed (spread of the blocks) and ._calibrate_mixed (the model's own log-normalisers in both forms, at load):
+    Gaussian and moderately peaked models keep the int8 fast path, models whose logits reach +-20 and heavy-tailed blocks fall
+    back to split rows -- on the default settings, which is what every golden decode test runs with."""
+    for k in ("JLM_MIXED_MAX_SPREAD", "JLM_MIXED_MAX_LSE_RMS", "JLM_LSE_MIXED"):
+        monkeypatch.delenv(k, raising=False)
+    _f, m = _model(name, fx, monkeypatch)
+    cal = m.mixed_calib
+    print(name, "spread", ["%.1f" % x for x in m.mixed_spread], "calibration", cal)
+    assert bool(m.mixed_idx) == kept, (name, m.mixed_spread, cal)
+    if cal is not None:
+        assert cal["kept"] == kept
+        assert np.isfinite(cal["lse_rms_diff"])
+    if name == "mid-vtable":
+        assert cal is not None and cal["lse_rms_diff"] < 5e-7, cal          # the headline model is far inside the limit

@@ -307,6 +307,9 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     monkeypatch.setattr(lib, "jlm_pack_t_mixed", pack_t, raising=False)
     dec = _decoder(f, "static")
     m = dec.model.dev
+    # the load-time calibration (DeviceModel._calibrate_mixed) has run the normaliser once in each form on its probe rows
+    assert calls["hybrid"] == calls["pack_t"] == 1 and m.mixed_calib["kept"] and m.mixed_calib["lse_rms_diff"] < 1e-6, m.mixed_calib
+    calls["hybrid"] = calls["pack_t"] = 0
     if name.startswith("wideh"):
         assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
         assert [sg["ldb"] for sg in m.mixed_segments] == [224, 128]
@@ -373,3 +376,28 @@ def test_chunks_in_flight_rule(fx, fake):
     assert dec.pipeline_depth == n
     assert dec.depth_for(256, 10) == n and dec.depth_for(1024, 8) == n
     assert dec.depth_for(1024, 20) == min(n, 3) and dec.depth_for(8192, 10) == min(n, 3)
+
+
+def test_packed_rows_take_32_blocks_at_most(tmp_path, fake):
+    """jlm_pack_t_mixed holds a hypothesis row's 16-value groups in the 64 lanes of one wave: segment tables above 32 blocks per row are
+    rejected by the real library (-2: jlm_mixed_t_stride, jlm_pack_t_mixed -- host-side checks, no GPU needed) and by its numpy
+    double, and DeviceModel keeps such a model on split rows (five segments of k = 200: 35 blocks)."""
+    import ctypes
+    from jlm_amd import _lib
+    real = ctypes.CDLL(_lib.LIB_PATH)
+    mk = lambda n: (_lib.Segment * n)(*[_lib.Segment(100 * i, 100 * (i + 1), 200, 200 * i, None, 224) for i in range(n)])
+    for lib_ in (real, fake):
+        assert lib_.jlm_mixed_t_stride(mk(4), 4) == (4 * 7 * 128 + 32) // 4
+        assert lib_.jlm_mixed_t_stride(mk(5), 5) == -2
+    ts = (ctypes.c_float * 5)(*[1.0] * 5)
+    real.jlm_pack_t_mixed.restype = ctypes.c_int
+    assert real.jlm_pack_t_mixed(mk(5), ts, 5, None, 1000, None, 4, None, None, (5 * 7 * 128 + 32) // 4, None) == -2
+    V = 1000
+    segs = [(200, 200 * i, 200 * (i + 1) if i < 4 else None) for i in range(5)]
+    cfg = synth.make_config(V, 64, 200, "vtable", segs)
+    synth.write_lexicon(str(tmp_path), V, alphabet=12)
+    synth.write_experiment(str(tmp_path), 1, cfg, scale=0.1)
+    jconfig.set_root(str(tmp_path))
+    from jlm_amd.model import LSTM_Model
+    m = LSTM_Model(1).dev
+    assert m.split_array is not None and m.mixed_idx == [] and m.ld_tm == 0 and m.mixed_calib is None

@@ -6,7 +6,8 @@ import pytest
 from oracle import jlm_oracle as orc
 from tests import golden_cases as gc
 
-FAST_DECODE = [c for c in gc.DECODE_CASES if not c[0].startswith(("mid-tied/static", "big-"))] + \
+SHAPED_FULL = [c for c in gc.DECODE_CASES if c[1] in gc.SHAPED_FIXTURES and c[0].endswith("/static")]
+FAST_DECODE = [c for c in gc.DECODE_CASES if not c[0].startswith(("mid-tied/static", "big-")) and c not in SHAPED_FULL] + \
               [c for c in gc.DECODE_CASES if c[0] == "mid-tied/static-vs"]
 FAST_DECODE = list({c[0]: c for c in FAST_DECODE}.values())
 
@@ -72,6 +73,13 @@ def test_decode_config0_sample_matches_reference(fx, golden_decode):
     100-sentence golden set (the full set is replayed on the GPU box)."""
     case = [c for c in gc.DECODE_CASES if c[0] == "mid-tied/static"][0]
     _run_case(case, fx, golden_decode, limit=3)
+
+
+@pytest.mark.parametrize("case", SHAPED_FULL, ids=[c[0] for c in SHAPED_FULL])
+def test_decode_shaped_sample_matches_reference(case, fx, golden_decode):
+    """The BASELINE-size models with trained-model-like statistics (peaked logits, heavy-tailed blocks): the first sentences of
+    each 24-sentence golden set (the full sets are replayed on the GPU box)."""
+    _run_case(case, fx, golden_decode, limit=5)
 
 
 def test_dynamic_requires_vocab_select(fx):
