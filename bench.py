@@ -42,6 +42,7 @@ sys.path.insert(0, REPO)
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2516.6       # v_mfma_f32_32x32x16_f16, dense: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
 SPLIT_PASSES = 3                    # f16x3: hi.hi + hi.lo + lo.hi per f32-grade product
+HBM_PEAK_BYTES_PER_S = 8.0e12       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured by a float4 copy)
 CONFIG5_SENTENCES = 8192
 
 
@@ -49,6 +50,15 @@ def kernel_source_sha256():
     """Identity of the kernels the committed PMC traffic figure was measured on (profiles/traffic_latest.json)."""
     h = hashlib.sha256()
     for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_body.h", "jlm_common.h"):
+        with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def gate_source_sha256():
+    """Identity of the LSTM-step kernel the committed PMC traffic figure was measured on"""
+    h = hashlib.sha256()
+    for f in ("jlm_gate.hip", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -223,7 +233,10 @@ def main():
                      "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                      else "gemm2_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
-            peak = F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if split else F32_MFMA_PEAK_TFLOPS
+            # `peak` prices ALGORITHMIC flops against the ceiling of the instructions the kernel issues: three f16 passes per
+            # f32-grade product on split rows (dense f16 / 3); on mixed rows one f16 pass + two int8 passes at twice the k per
+            # instruction = the time of TWO f16 passes (dense f16 / 2)
+            peak = (F16_MFMA_PEAK_TFLOPS / 2.0 if mixed else F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES) if split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_note = None, "not measured in this run (tools/gpu_traffic.sh + tools/traffic_report.py write profiles/traffic_latest.json)"
             tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
             if split and m.stationary_ok and os.path.exists(tpath):
@@ -235,8 +248,11 @@ def main():
                     traffic_note = ("profiles/traffic_latest.json was measured on other kernel sources / another fixture: omitted "
                                     "(its figure: %s bytes per call)" % tj.get("vocab_lse_hbm_bytes_per_call"))
             ex = v["tflops"] / m.flops_per_row_vocab * exec_per_row_vocab if split else v["tflops"]
+            form = ("mixed" if mixed else "hybrid" if (split and getattr(m, "mixed_idx", [])) else "split" if split else "f32")
             roofline = {"kernel": kname, "bound": "mfma", "achieved": round(v["tflops"], 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(v["tflops"] / peak, 4),
+                        "lse_form": form, "lse_form_calibration": getattr(m, "mixed_calib", None),
+                        "lse_form_spread": [round(x, 2) for x in getattr(m, "mixed_spread", [])],
                         "frac_of_dense_f16": round(ex / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
                         "frac_of_dense_f16_algorithmic": round(v["tflops"] / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
                         "executed_tflops": round(ex, 1),
@@ -244,21 +260,34 @@ def main():
                         "avg_launch_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                         "flops_per_launch": v["flops_per_launch"],
                         "mfma_dtype": (("f16 hi.hi (v_mfma_f32_32x32x16_f16) + int8 cross terms (v_mfma_i32_32x32x32_i8): 4 matrix instructions per "
-                                        "32 k-values instead of the split form's 6.  `peak` stays %.1f dense f16 / %d -- the pricing of rounds 1-2 "
-                                        "(three f16 passes per f32-grade product), so `frac` compares across rounds; the scheme's own ceiling is "
-                                        "dense f16 / 2 (`frac_of_scheme_peak`); frac_of_dense_f16 prices the executed instructions at 32 cycles each"
+                                        "32 k-values instead of the split form's 6.  `peak` = %.1f dense f16 / 2: the ceiling of the instructions issued "
+                                        "(round 4; rounds 1-3 priced every form at dense f16 / %d = three f16 passes per f32-grade product -- that figure "
+                                        "is kept as `frac_f16x3_pricing`); frac_of_dense_f16 prices the executed instructions at 32 cycles each"
                                         % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES)) if mixed else
                                        "f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): `peak` = %.1f dense f16 / %d passes prices "
                                        "ALGORITHMIC flops; frac_of_dense_f16 prices the executed ones (3 passes, k padded to 16)"
                                        % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES) if split else "f32 (v_mfma_f32_32x32x2_f32)"),
                         "measured": "HIP events around every launch of the dominant kernel on its stream, in a repeat of the timed decode"}
-            if mixed:
-                roofline["frac_of_scheme_peak"] = round(v["tflops"] / (F16_MFMA_PEAK_TFLOPS / 2.0), 4)
+            if split:
+                roofline["frac_f16x3_pricing"] = round(v["tflops"] / (F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES), 4)
+            # the same fraction from the rocprofv3 kernel statistics tracked under profiles/ (average duration of this kernel in a
+            # profiled run of this command: tools/gpu_prof.sh + tools/rocprof_report.py), when they were taken on these sources
+            rpath = os.path.join(REPO, "profiles", "rocprof_latest.json")
+            roofline["frac_rocprof"], roofline["rocprof_avg_launch_ms"] = None, None
+            if os.path.exists(rpath):
+                with open(rpath) as rf_:
+                    rj = json.load(rf_)
+                if rj.get("source_sha256") == kernel_source_sha256() and rj.get("fixture") == fixture and rj.get("vocab_lse_avg_us"):
+                    roofline["rocprof_avg_launch_ms"] = round(rj["vocab_lse_avg_us"] * 1e-3, 4)
+                    roofline["frac_rocprof"] = round(v["flops_per_launch"] / (rj["vocab_lse_avg_us"] * 1e-6) / 1e12 / peak, 4)
+                    roofline["rocprof_source"] = rj.get("note")
+                else:
+                    roofline["rocprof_source"] = "profiles/rocprof_latest.json was taken on other kernel sources / another fixture: omitted"
             if not full_vocab:
                 # the vocabulary-selected / per-frame-deduplicated decoders run this kernel over a sub-problem whose size is
                 # decided on the device each frame: the full-vocabulary flop count does not apply, so nothing is priced
-                for k in ("achieved", "frac", "frac_of_dense_f16", "frac_of_dense_f16_algorithmic", "frac_of_scheme_peak", "executed_tflops",
-                          "flops_per_launch", "traffic"):
+                for k in ("achieved", "frac", "frac_of_dense_f16", "frac_of_dense_f16_algorithmic", "frac_f16x3_pricing", "frac_rocprof",
+                          "executed_tflops", "flops_per_launch", "traffic"):
                     if k in roofline:
                         roofline[k] = None
                 roofline["note"] = ("decoder=%s works on a per-frame selected sub-problem (rows x columns decided on the device): "
@@ -277,6 +306,22 @@ def main():
                         "reference_step_counted_tflops": round(counted, 1),
                         "reference_step_counted": "2*(H+E)*4H per row, one pass (the reference's step, model.py:125-131), not executed work",
                         "avg_launch_ms": round(g["avg_ms"], 4), "launches": g["launches"]}
+            if gsplit:
+                # the byte side of the same launch (the kernel is co-bound by bytes at R = 2 560): algorithmic = per live row one
+                # 8-KB table row + the gathered state row and cell row in (2 x 2 KB) + the new state and cell rows out (2 x 2 KB),
+                # plus the 4 H x H split gate matrix once; measured = PMC (profiles/traffic_latest.json, as for the vocabulary kernel)
+                rows_avg = float(rows[:g["launches"]].mean()) if g["launches"] else 0.0
+                alg = rows_avg * (4 * H * 4 + 4 * H * 4) + 4 * H * H * 4
+                gate_obj["hbm_bytes_algorithmic"] = int(alg)
+                gate_obj["hbm_bytes_per_launch"], gate_obj["hbm_frac"] = None, None
+                tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+                if os.path.exists(tpath):
+                    with open(tpath) as tf:
+                        tj = json.load(tf)
+                    if tj.get("gate_source_sha256") == gate_source_sha256() and tj.get("fixture") == fixture and tj.get("gate_hbm_bytes_per_call"):
+                        gate_obj["hbm_bytes_per_launch"] = int(tj["gate_hbm_bytes_per_call"])
+                        gate_obj["hbm_frac"] = round(tj["gate_hbm_bytes_per_call"] / (g["avg_ms"] * 1e-3) / HBM_PEAK_BYTES_PER_S, 4)
+                        gate_obj["hbm_note"] = "PMC bytes per launch / HIP-event launch time / 8 TB/s (MI355X_MICROARCH.md: ~6.3 TB/s achievable)"
         return roofline, gate_obj
 
     cpu = None
@@ -390,6 +435,30 @@ def main():
         line_extra["device_resident_note"] = ("same K steps with the batch's lattice (CSR) already resident in HBM: launch sequence "
                                               "+ n-best traces back on the host, no lattice build / upload / string read-out")
         roofline, gate_obj = measure_kernels(dec, lat, ekind, ekw, min(args.steps, 20), full_vocab=(args.decoder == "static"))
+        if roofline and args.decoder == "static":
+            # consistency of the two clocks: the dominant kernel's solo launches of one step cannot take longer than the step
+            per_step = roofline["launches"] / float(min(args.steps, 20))
+            roofline["solo_launch_ms_per_step"] = round(roofline["avg_launch_ms"] * per_step, 4)
+            assert roofline["solo_launch_ms_per_step"] <= line_extra["device_resident_ms_per_step"], (
+                "dominant kernel: %.3f ms of solo launches per step against a %.3f ms step" % (
+                    roofline["solo_launch_ms_per_step"], line_extra["device_resident_ms_per_step"]))
+        if roofline and args.decoder == "static" and roofline.get("lse_form") in ("mixed", "hybrid"):
+            # the same launches on SPLIT rows (three f16 passes; what a model the load-time gates keep off the int8 planes runs)
+            os.environ["JLM_LSE_MIXED"] = "0"
+            try:
+                _rs, _cs, _as, dec_s = make_decoder(args.fixture, "static")
+                dec_s.max_batch = args.batch
+                lat_s = BatchLattice(dec_s._builder, sents, args.beam)
+                rf_s, _g = measure_kernels(dec_s, lat_s, "static", {}, 5)
+                if rf_s:
+                    roofline["split_rows_avg_launch_ms"] = rf_s["avg_launch_ms"]
+                    roofline["split_rows_frac"] = rf_s["frac"]
+                    roofline["split_rows_note"] = ("JLM_LSE_MIXED=0: the same model and rows through jlm_vocab_lse_split (peak = dense f16 / 3); "
+                                                   "what DeviceModel._calibrate_mixed / the spread gate fall back to")
+                del dec_s, lat_s
+            finally:
+                del os.environ["JLM_LSE_MIXED"]
+                jconfig.set_root(root)
         # the same kernels inside the pipelined loop (four batches in flight): events on each batch's own stream
         if roofline and args.decoder == "static" and eng.n_streams >= 2:
             sink = {"n_live": [], "gate_gemm": [], "vocab_lse": []}

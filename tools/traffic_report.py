@@ -27,7 +27,10 @@ if len(sys.argv) > 2:
            [r for r in rows if "vocab_lse_split" in r[0] or "vocab_lse_hybrid" in r[0]])
     if lse:
         import bench
+        gate = [r for r in rows if "gate_xg" in r[0]]
         json.dump({"kernel": lse[0][0].strip(), "vocab_lse_hbm_bytes_per_call": int(lse[0][5]),
+                   "gate_kernel": gate[0][0].strip() if gate else None, "gate_hbm_bytes_per_call": int(gate[0][5]) if gate else None,
+                   "gate_source_sha256": bench.gate_source_sha256(),
                    "fixture": "mid-vtable", "source_sha256": bench.kernel_source_sha256(),
                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_traffic.sh), FETCH_SIZE doubled as "
                            "MI355X_MICROARCH.md prescribes for gfx950 wide coalesced reads; " + os.path.basename(sys.argv[1])},
