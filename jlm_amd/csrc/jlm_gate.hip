@@ -30,6 +30,7 @@
 // line at kernel start (+5 us: the loop is not bound by L2 misses -- with every operand L2-resident and no DMA at all a
 // k-step still takes 0.8 us); a whole-k-step register double buffer (spills at 3 hypothesis blocks).
 #include "jlm_common.h"
+#include "jlm_gate.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -55,25 +56,13 @@ extern "C" int jlm_prof_read_gate(unsigned long long *out) {
 
 namespace {
 
-constexpr int GT_BM = 160;                               // hypotheses per tile (5 blocks of 32)
-constexpr int GT_BN = 128;                               // gate columns per tile (4 blocks of 32 = 32 units)
 constexpr int GT_STAGES = 4;
 constexpr int GT_STAGE_FLOATS = (GT_BM + GT_BN) * 32;    // one 32-value k-step of both operands: 36 KB
 constexpr int GT_LDS_BYTES = GT_STAGES * GT_STAGE_FLOATS * 4;
 
 __device__ float gate_zero_page[64];
 
-struct GateXgArgs {
-    const float *h; const float *c_in; float *h_out; float *c_out; int ld;
-    float *h_f32;                                        // optional plain f32 copy of h' (untied models: T is the state itself)
-    const int *rows, *prev, *word;
-    const float *wt; const float *xg;
-    int H; float descale, h_scale;
-    int nrows; const int *ndev;
-    int tiles_m, tiles_n;
-};
 
-template <int N> using IC = std::integral_constant<int, N>;
 
 // NB hypothesis blocks of MFMA work, NP LDS-DMA pieces (8 rows x 128 B each) per stage for this wave.
 template <int NB, int NP>
@@ -379,8 +368,6 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
 // code (in-order LDS returns), never a drain.  Stage kt + 1 is read DURING k-step kt, so it must have landed at the
 // barrier at the START of k-step kt; the slot refilled behind that barrier is the one of stage kt - 1 (stage kt's last
 // reads are still in the queue there): three stages resident + one being filled, two k-steps of DMA lead.
-template <class F, int... I>
-__device__ __forceinline__ void gate_for_each_ic(F &&f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
 
 template <int NB, int NP, int NK, int BS, int ABL>
 __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0, const int n0, const int M, const int wave,
@@ -638,6 +625,7 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
 #endif
 }
 
+
 __device__ __forceinline__ bool gate_tile_of_block(const GateXgArgs &a, int &m0, int &n0, int &M) {
     const int b = blockIdx.x;
     int tm, tn;
@@ -733,8 +721,23 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     a.nrows = n_rows_max; a.ndev = n_dev;
     a.tiles_m = (n_rows_max + GT_BM - 1) / GT_BM;
     a.tiles_n = 4 * H / GT_BN;
-    static const int variant = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : 1;
-    if (variant == 1 && H == 512) {
+    a.cx = 0;
+    // JLM_GATE_V: 2 the W-stationary persistent kernel (csrc/jlm_gate_ws.hip: H = 512, a row list, gate-column tiles divisible over the 8
+    // XCDs); 1 one tile per workgroup, refill-in-place pipeline (round 3); 0 the round-2 loop (every H).  Default: 2 from 8 192 rows
+    // (two or more tiles per workgroup: 77.5 vs 82 us at 10 240 rows, 155 vs 167 at 20 480 -- tools/gpu_gate_ws.sh), else 1 (one tile
+    // per CU: 23.5 vs 27.5 us at 2 560 rows -- a single tile pays for loading its gate fragments and gets nothing back)
+    static const int variant_env = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : -1;
+    const int variant = variant_env >= 0 ? variant_env : (n_rows_max >= 8192 ? 2 : 1);
+    static const int ws_l = getenv("JLM_GATE_WS_L") ? atoi(getenv("JLM_GATE_WS_L")) : 3;
+    if (variant == 2 && H == 512 && rows && (a.tiles_n & 7) == 0) {
+        const int per_col = 256 / a.tiles_n;                       // row-tile sequences per gate-column tile: one resident workgroup per CU
+        const int Q = a.tiles_m < per_col ? a.tiles_m : per_col;
+        // gate-column tiles per XCD: fabric bytes ~ (16 / cx) x rows x 2 KB of state + (cx / 16) x 8 XCDs x 4 MB of gate matrix
+        static const int ws_cx = getenv("JLM_GATE_WS_CX") ? atoi(getenv("JLM_GATE_WS_CX")) : 0;
+        a.cx = ws_cx ? ws_cx : 4;                                  // (measured 2 / 4 / 8 / 16 at 10 240 and 20 480 rows: 4 by 2-4 %)
+        if (a.cx > a.tiles_n || a.tiles_n % a.cx || 32 % a.cx) a.cx = 2;
+        if (int rc = jlm_gate::ws_launch(a, ws_l == 3 ? 3 : 7, Q, (hipStream_t)stream)) return rc;
+    } else if (variant >= 1 && H == 512) {
         void *params[] = {&a};
         hipError_t e = hipLaunchKernel(gate_u16_selected(), dim3(a.tiles_m * a.tiles_n), dim3(512), params, GT_LDS_BYTES, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;

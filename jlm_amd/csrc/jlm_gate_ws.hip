@@ -1,0 +1,431 @@
+// jlm_gate_ws.hip -- the fused LSTM step of the decode, W-stationary persistent form (round 4; jlm_lstm_step_xg's default
+// at H = 512: csrc/jlm_gate.hip picks).  Reference: decoder/model.py:125-139 with the state gather of decoder/decoder.py:206-218.
+//
+// Its own translation unit because it is compiled with  -mllvm -amdgpu-mfma-vgpr-form : the wave's 256 accumulation registers hold
+// its slice of the gate matrix for the whole kernel, so the MFMA accumulators must live in the architectural VGPRs -- left to its
+// heuristics hipcc puts them in a[0:79], copies pieces of the gate matrix out of the way (v_accvgpr_read / write around loads that
+// are still in flight) and spills them to scratch.
+#include "jlm_gate.h"
+
+// Per-workgroup timeline (-DJLM_PROFILE builds only, tools/probes/gate_ws_profile.py): wave 0 stamps the 100 MHz wall clock at
+// kernel start [0], after the index loads [1], when the first stage has landed [2], and per tile t at the end of its k-steps
+// [3 + 2 t] and of its cell update [4 + 2 t]; [30], [31]: shader clock at [2] and [3].
+#ifdef JLM_PROFILE
+static __device__ unsigned long long jlm_gate_ws_time[256][32];
+#define JLM_WS_T(i) do { if (threadIdx.x == 0 && (i) < 30) { jlm_gate_ws_time[blockIdx.x & 255][i] = wall_clock64(); \
+    if ((i) == 2 || (i) == 3) jlm_gate_ws_time[blockIdx.x & 255][(i) == 2 ? 30 : 31] = clock64(); } } while (0)
+extern "C" int jlm_prof_read_gate_ws(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_gate_ws_time), sizeof(jlm_gate_ws_time)) == hipSuccess ? 0 : -1;
+}
+#else
+#define JLM_WS_T(i) (void)0
+#endif
+
+namespace {
+
+__device__ float gate_dump_page[4 * 256 + 8];              // where the stores of hypothesis rows past the edge go
+
+// Round 4: the W-STATIONARY, PERSISTENT form of the same step (gate_ws_kernel; H = 512).
+//
+// What the per-workgroup timeline of gate_xg_u16_kernel says (profiles/r03_a_gate_timeline.txt): of the 21.5 us a 160 x 128 tile
+// costs at ANY number of rows, the sixteen k-steps take 14.2 (1 311 cycles each against the 960 their MFMAs need: two waves per
+// SIMD trading the matrix pipe, 36 KB of LDS-DMA and 8 x 17 fragment reads per k-step, one 8-wave barrier) and 7 lie outside the
+// loop -- index chains, first ring stages, epilogue, launch gaps -- with nothing overlapping them; and every one of the 16 row
+// tiles that share a gate-column tile stages the same 256 KB slice of the gate matrix through its LDS again.  Here:
+//   * a workgroup is FOUR waves, one per SIMD, each owning one 32-column gate block of the tile for the whole kernel: its slice
+//     of the gate matrix (32 columns x 512 k x two f16 planes = 64 KB) is loaded ONCE, straight from L2 into the wave's 256
+//     accumulation registers (global_load_dwordx4 a[..]: AGPRs are legal MFMA A operands on gfx950), and stays there while the
+//     workgroup walks its row tiles (grid = 256 workgroups = 16 column tiles x 16 row-tile sequences: 8 tiles each at 20 480 rows);
+//   * only the hypothesis rows go through LDS: 20 KB per 32-value k-step instead of 36, five 1-KB pieces per wave, an 8-slot
+//     ring (all 160 KB; 16 k-steps = two laps, so slot numbers are compile-time constants) filled seven k-steps ahead;
+//   * every wave multiplies ALL five hypothesis blocks of the tile by its gate block: 15 MFMAs per half k-step and wave with
+//     10 fragment reads (the gate fragments are registers), refilled in place behind the MFMA that read them last;
+//   * the ring does not stop at a tile's end: the first seven stages of the NEXT tile are requested under the last seven
+//     k-steps of this one (its row indices under the first ones), so a tile's epilogue is followed by the next tile's first MFMA;
+//   * the epilogue takes its operands (one 128-byte table line and the old cell state per hypothesis) block by block, two
+//     blocks in flight, the first two requested under the last two k-steps; stores go through buffer descriptors (rows past
+//     the edge are dropped by the range check, not branched around) so that the number of vector-memory operations in flight
+//     is known at every wait: every wait below is a COUNTED s_waitcnt vmcnt(n), n derived at compile time from the issue
+//     order (ws_* functions), never a drain.
+// In the first tile the gate-matrix loads ride in the same in-order queue, four per k-step, seven k-steps ahead like the ring.
+constexpr int WS_NB = 5;                                  // hypothesis blocks of a tile, all of them on every wave
+constexpr int WS_NP = 5;                                  // LDS-DMA pieces (8 rows x 128 B) per wave and stage: 20 pieces = 160 rows
+constexpr int WS_STAGE_FLOATS = GT_BM * 32;               // one 32-value k-step of 160 hypothesis rows: 20 KB
+constexpr int WS_NK = 16;                                 // k-steps (H = 512)
+#ifndef WS_ABL
+#define WS_ABL 0      // measurement builds (results wrong): 1 no LDS-DMA in the k-steps, 2 no fragment reads in the k-steps, 4 no MFMAs, 8 no barrier
+#endif
+constexpr int WS_ST = 3;                                  // stores per hypothesis block and lane that every launch issues (c, h hi, h lo)
+
+// ---- the issue order of a tile's vector-memory operations, and the counted waits that follow from it ----
+// k-step j issues, in this order:  D  the 5 pieces of stage j + L (of the next tile from j = 16 - L on);
+//                                  X  the tile's extra loads: j = 0 row ids of the epilogue (5; first tile: in the prologue),
+//                                     j = 1 row ids of the next tile's pieces (5), j = 3 prev / word of the epilogue rows (10; first
+//                                     tile: prologue), j = 4 prev of the next tile's piece rows (5), j = 14 / 15 the epilogue operands
+//                                     of blocks 0 / 1 (5 each);
+//                                  W  first tile only: the 4 gate-matrix loads of k-step j + L + 1 (while there is one).
+constexpr int ws_x(bool first, int j) {
+    return j == 0 ? (first ? 0 : 5) : j == 1 ? 5 : j == 3 ? (first ? 0 : 10) : j == 4 ? 5 : (j == 14 || j == 15) ? 5 : 0;
+}
+constexpr int ws_w(bool first, int L, int j) { return (first && j + L + 1 < WS_NK) ? 4 : 0; }
+constexpr int ws_issued(bool first, int L, int j) { return WS_NP + ws_x(first, j) + ws_w(first, L, j); }
+constexpr int ws_sum(bool first, int L, int j0, int j1) {      // operations issued by k-steps j0 .. j1 - 1
+    int n = 0;
+    for (int j = j0; j < j1; ++j) n += ws_issued(first, L, j);
+    return n;
+}
+constexpr int ws_clamp(int n) { return n > 63 ? 63 : n; }       // (the counter has six bits; a smaller count only waits longer)
+// top of k-step kt: stage kt + 1 has landed.  Prologue of the first tile: W0 D0 W1 D1 .. W(L-1) D(L-1) W(L).
+constexpr int ws_top(bool first, int L, int kt) {
+    if (kt + 1 < L) return first ? ws_clamp(9 * (L - 2 - kt) + 4 + ws_sum(first, L, 0, kt)) : 63;     // (later tiles: requested under the
+    const int j = kt + 1 - L;                                                                       //  tile before, landed behind its epilogue)
+    return ws_clamp(ws_x(first, j) + ws_w(first, L, j) + ws_sum(first, L, j + 1, kt));
+}
+// behind D of k-step 3: the epilogue's row ids (X of k-step 0) are there
+constexpr int ws_wait_eg(int L) { return ws_clamp(ws_w(false, L, 0) + ws_sum(false, L, 1, 3) + WS_NP); }
+// behind D of k-step 4: the next tile's piece row ids (X of k-step 1)
+constexpr int ws_wait_rn(bool first, int L) { return ws_clamp(ws_w(first, L, 1) + ws_sum(first, L, 2, 4) + WS_NP); }
+// in front of D of k-step 16 - L: prev of the next tile's piece rows (X of k-step 4)
+constexpr int ws_wait_ppn(bool first, int L) { return ws_clamp(ws_w(first, L, 4) + ws_sum(first, L, 5, WS_NK - L)); }
+// behind D of k-step 14: prev / word of the epilogue rows (X of k-step 3; first tile: prologue)
+constexpr int ws_wait_epew(int L) { return ws_clamp(ws_w(false, L, 3) + ws_sum(false, L, 4, 14) + WS_NP); }
+static_assert(ws_top(false, 7, 8) == 40 && ws_top(false, 7, 3) == 63 && ws_top(true, 7, 0) == 49 && ws_wait_eg(7) == 20, "issue-order bookkeeping");
+
+// (a struct with member templates, not lambdas: clang rejects inline-asm operands that name captured locals inside a GENERIC lambda)
+template <int L, bool HF32>
+struct GateWs {
+    static constexpr int S = L + 1;                       // ring slots
+    static_assert(S == 8 || S == 4, "16 k-steps must be whole laps of the ring");
+    static constexpr int OOB_ROW = 0x7fffffff;
+    const GateXgArgs &a;
+    float *smem;
+    int lane, wave, li, hf, lrow, lslot, H, ld, M, Q, n0, u0, tiles_m, tm;
+    __amdgpu_buffer_rsrc_t rs_h;
+    float *dump;
+    const float *wrow;
+    f16x8 W[2 * WS_NK][2];                                // the wave's gate block: MFMA A operand of k16-step s (plane 0 = hi, 1 = lo)
+    int goff[2][2];                                       // fragment offsets (floats) inside a stage
+    int eg[WS_NB], ep[WS_NB], ew[WS_NB];                  // epilogue: global row, predecessor row, word of the lane's hypothesis in each block
+    bool eok[WS_NB];
+    int vidx[WS_NP], voff[WS_NP];                         // LDS-DMA pieces of this wave: row index (or OOB) and swizzled byte offset
+    int rn[WS_NP];                                        // next tile: piece row ids, then their predecessors
+    bool nok[WS_NP];
+    f32x16 acc[WS_NB];
+    f16x8 B[WS_NB][2];                                    // fragments of ONE half step, refilled in place (plane 0 hi, 1 lo)
+    f32x4 xg[2][4], cp[2];                                // epilogue operands, two blocks in flight
+
+    __device__ __forceinline__ GateWs(const GateXgArgs &a_, float *smem_) : a(a_), smem(smem_) {}
+
+    __device__ __forceinline__ int piece_row(int m0, int i) const { return m0 + 8 * (WS_NP * wave + i) + lrow; }
+
+    template <int KT>
+    __device__ __forceinline__ void load_w() {            // the four loads of k-step KT (two k16-steps x two planes)
+        asm volatile("global_load_dwordx4 %0, %4, off offset:%5\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:%6\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:%7\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:%8"
+                     : "=&a"(W[2 * KT][0]), "=&a"(W[2 * KT][1]), "=&a"(W[2 * KT + 1][0]), "=&a"(W[2 * KT + 1][1])
+                     : "v"(wrow), "n"(KT * 128), "n"(KT * 128 + 16), "n"(KT * 128 + 64), "n"(KT * 128 + 80) : "memory");
+    }
+    template <int SG>
+    __device__ __forceinline__ void issue() {             // stage SG (mod 16) of whatever tile vidx describes
+        float *base = smem + (SG & (S - 1)) * WS_STAGE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < WS_NP; ++i)
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + 8 * (WS_NP * wave + i) * 32),
+                                                        16, vidx[i], voff[i], (SG & (WS_NK - 1)) * 128, 0, 0);
+    }
+    __device__ __forceinline__ void rdB(int stage, int st, int nb, int p) {
+        if ((WS_ABL & 2) && !(stage == 0 && st == 0)) { asm volatile("" : "+v"(B[nb][p])); return; }
+        B[nb][p] = *reinterpret_cast<const f16x8 *>(smem + (stage & (S - 1)) * WS_STAGE_FLOATS + nb * 1024 + goff[st][p]);
+    }
+    // one 128-byte table line (4 gates x the lane's 4 units) + the old cell state of block nb -> slot
+    __device__ __forceinline__ void load_ops(int nb, int slot) {
+        const float *xrp = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * wave + 4 * hf;
+        const float *cpp = a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+        asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                     "global_load_dwordx4 %1, %5, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %5, off offset:64\n\t"
+                     "global_load_dwordx4 %3, %5, off offset:96\n\t"
+                     "global_load_dwordx4 %4, %6, off"
+                     : "=&v"(xg[slot][0]), "=&v"(xg[slot][1]), "=&v"(xg[slot][2]), "=&v"(xg[slot][3]), "=&v"(cp[slot])
+                     : "v"(xrp), "v"(cpp) : "memory");
+    }
+    template <int N>
+    __device__ __forceinline__ void wait_ops(int slot) {
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(xg[slot][0]), "+v"(xg[slot][1]), "+v"(xg[slot][2]), "+v"(xg[slot][3]), "+v"(cp[slot]) : "n"(N) : "memory");
+    }
+    template <int N>
+    __device__ __forceinline__ void wait_int(int &v) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+    __device__ __forceinline__ void load_int(int &dst, const int *src) { asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(src) : "memory"); }
+    template <bool FIRST, int KT>
+    __device__ __forceinline__ void top() {               // stage KT + 1 landed (this wave's pieces), every wave through k-step KT - 1
+        if constexpr (FIRST) {
+            // the gate-matrix registers of this k-step are "produced" here: their loads are older than the stage waited for
+            asm volatile("s_waitcnt vmcnt(%4)"
+                         : "+a"(W[2 * KT][0]), "+a"(W[2 * KT][1]), "+a"(W[2 * KT + 1][0]), "+a"(W[2 * KT + 1][1])
+                         : "n"(ws_top(true, L, KT)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ws_top(false, L, KT)) : "memory");
+        }
+        if constexpr (!(WS_ABL & 8)) asm volatile("s_barrier" ::: "memory");
+    }
+
+    // one half step (k-step KT, half ST): 15 MFMAs;  group 1  W_lo . B_hi[nb];  group 2  W_hi . B_hi[nb], B_hi[nb] refilled behind
+    // its MFMA;  group 3  W_hi . B_lo[nb], B_lo[nb] refilled.  The refill is the NEXT half step's fragment (stage KT + 1 from half 1)
+    template <int KT, int ST, int DMA, bool ZERO>         // DMA: stage to request behind the first MFMA (-1: none); ZERO: the tile's first half step
+    __device__ __forceinline__ void half() {
+        constexpr int NKT = ST == 0 ? KT : KT + 1, NST = 1 - ST;       // the half step the refills belong to (KT + 1 = 16: next tile's stage 0)
+        const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < WS_NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * KT + ST][1], B[nb][0], ZERO ? zf : acc[nb], 0, 0, 0);
+            if constexpr (DMA >= 0 && !(WS_ABL & 1)) { if (nb == 0) issue<DMA>(); }
+        }
+#pragma unroll
+        for (int nb = 0; nb < WS_NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * KT + ST][0], B[nb][0], acc[nb], 0, 0, 0);
+            rdB(NKT, NST, nb, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < WS_NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * KT + ST][0], B[nb][1], acc[nb], 0, 0, 0);
+            rdB(NKT, NST, nb, 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * WS_NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i == 0 && DMA >= 0 && !(WS_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, WS_NP, 0);
+            if (i >= WS_NB && !(WS_ABL & 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <bool FIRST, int KT>
+    __device__ __forceinline__ void kstep(int m0, int m0n, bool has_next) {
+        top<FIRST, KT>();
+        if constexpr (KT == 0 && FIRST) JLM_WS_T(2);
+        if constexpr (KT == 0 && FIRST) {
+            // the very first fragments (stage 0 landed: it is older than stage 1)
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) { rdB(0, 0, nb, 0); rdB(0, 0, nb, 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // in front of the first stage of the NEXT tile: its piece rows' predecessors have arrived -> the pieces' row indices
+        if constexpr (KT == WS_NK - L) {
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) wait_int<ws_wait_ppn(FIRST, L)>(rn[i]);
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) vidx[i] = (nok[i] && rn[i] >= 0) ? rn[i] : OOB_ROW;
+        }
+        half<KT, 0, (KT + L) & (WS_NK - 1), KT == 0>();
+        // ---- the k-step's extra loads (X), then the first tile's gate-matrix loads (W)
+        if constexpr (KT == 0 && !FIRST) {
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) {
+                const int r = m0 + 32 * nb + li;
+                eok[nb] = r < M;
+                load_int(eg[nb], a.rows + (eok[nb] ? r : M - 1));
+            }
+        }
+        if constexpr (KT == 1) {
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) {
+                const int r = piece_row(m0n, i);
+                nok[i] = has_next && r < M;
+                load_int(rn[i], a.rows + (nok[i] ? r : M - 1));
+            }
+        }
+        if constexpr (KT == 3 && !FIRST) {
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) wait_int<ws_wait_eg(L)>(eg[nb]);
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) {
+                load_int(ep[nb], a.prev + eg[nb]);
+                load_int(ew[nb], a.word + eg[nb]);
+            }
+        }
+        if constexpr (KT == 4) {
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) wait_int<ws_wait_rn(FIRST, L)>(rn[i]);
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) load_int(rn[i], a.prev + rn[i]);
+        }
+        if constexpr (KT == 14) {
+            if constexpr (!FIRST) {
+#pragma unroll
+                for (int nb = 0; nb < WS_NB; ++nb) { wait_int<ws_wait_epew(L)>(ep[nb]); wait_int<ws_wait_epew(L)>(ew[nb]); }
+            }
+            load_ops(0, 0);
+        }
+        if constexpr (KT == 15) load_ops(1, 1);
+        if constexpr (FIRST && KT + L + 1 < WS_NK) load_w<(KT + L + 1) & (WS_NK - 1)>();
+        __builtin_amdgcn_sched_barrier(0);
+        half<KT, 1, -1, false>();
+    }
+
+    // cell update of block NBK in registers; operands two blocks ahead.  acc[nb][4 gate + e] + table = pre-activation (x 1 / descale) of
+    // gate `gate`, unit u0 + e, hypothesis li of block nb
+    template <int NBK>
+    __device__ __forceinline__ void cell() {
+        constexpr int sl = NBK & 1;
+        // younger than this block's operands: the next block's (5), and what was issued between them (stores, the block after)
+        constexpr int younger = NBK == 0 ? 10 : NBK == 1 ? 5 + WS_ST : NBK == 4 ? 2 * WS_ST : 2 * WS_ST + 5;
+        wait_ops<younger>(sl);
+        f32x4 xq[4], cq;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[sl][g4];
+        cq = cp[sl];
+        if constexpr (NBK + 2 < WS_NB) {
+            asm volatile("" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(cq));       // (copied out before the slot is requested again)
+            load_ops(NBK + 2, sl);
+        }
+        const float ds = a.descale;
+        const int g = eok[NBK] ? eg[NBK] : -1;
+        f32x4 cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = jlm_sigmoid((acc[NBK][e] + xq[0][e]) * ds), gf = jlm_sigmoid((acc[NBK][4 + e] + xq[1][e]) * ds);
+            const float go = jlm_sigmoid((acc[NBK][8 + e] + xq[2][e]) * ds), gg = jlm_tanh((acc[NBK][12 + e] + xq[3][e]) * ds);
+            cn[e] = (ep[NBK] >= 0 ? cq[e] : 0.0f) * gf + gg * gi;
+            hn[e] = jlm_tanh(cn[e]) * go;
+        }
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 hi4, lo4;
+        jlm_split4(hn, a.h_scale, hi4, lo4);
+        // (rows past the edge store into the dump page: the stores are issued all the same)
+        float *crow = g >= 0 ? a.c_out + (size_t)g * ld + u0 : dump;
+        *reinterpret_cast<f32x4 *>(crow) = cn;
+        // units u0 .. u0+3 = one half of an 8-value block [8 x f16 hi][8 x f16 lo] of the split row
+        _Float16 *blk = g >= 0 ? reinterpret_cast<_Float16 *>(a.h_out + (size_t)g * ld + (u0 & ~7)) + (u0 & 7) : reinterpret_cast<_Float16 *>(dump);
+        *reinterpret_cast<f16x4 *>(blk) = hi4;
+        *reinterpret_cast<f16x4 *>(g >= 0 ? blk + 8 : blk + 4) = lo4;
+        if constexpr (HF32) *reinterpret_cast<f32x4 *>(g >= 0 ? a.h_f32 + (size_t)g * ld + u0 : dump) = hn;
+    }
+
+    // one tile: sixteen k-steps, then the cell update of its five blocks
+    template <bool FIRST>
+    __device__ __forceinline__ void tile(bool has_next, int t_no) {
+        const int m0 = tm * GT_BM;
+        const int m0n = (tm + Q) * GT_BM;                 // the next tile of this workgroup (past the edge: every row masked)
+        gate_for_each_ic([&](auto ktc) { this->template kstep<FIRST, decltype(ktc)::value>(m0, m0n, has_next); },
+                         std::make_integer_sequence<int, WS_NK>{});
+        JLM_WS_T(3 + 2 * t_no);
+        gate_for_each_ic([&](auto nbc) { this->template cell<decltype(nbc)::value>(); }, std::make_integer_sequence<int, WS_NB>{});
+        JLM_WS_T(4 + 2 * t_no);
+    }
+
+    __device__ __forceinline__ void run() {
+        JLM_WS_T(0);
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);            // = the wave's gate block
+        li = lane & 31; hf = lane >> 5;
+        lrow = lane >> 3; lslot = lane & 7;
+        H = a.H; ld = a.ld;
+        // tile map (block b runs on XCD b % 8, observed; speed only).  The gate matrix is read once per workgroup, so what the map
+        // has to keep small is the fabric traffic of the STATE rows: an XCD whose workgroups cover `cx` of the 16 gate-column tiles
+        // brings a hypothesis row into its L2 once for all of them -- 16 / cx XCDs fetch each row (2 KB) and each XCD fetches
+        // cx / 16 of the gate matrix (4 MB).  cx = tiles_n (every column tile of a row tile on ONE XCD) when the launch has many
+        // rows, fewer for few rows (the launcher picks: a.cx); grids below 256 workgroups keep the plain order.
+        const int b = blockIdx.x;
+        int tn, q;
+        if ((int)gridDim.x == 256 && a.cx >= 2) {
+            const int x = b & 7, jb = b >> 3;             // XCD, workgroup inside it (32 per XCD)
+            const int gc = a.tiles_n / a.cx;              // column groups; XCD x = (row group, column group)
+            const int cg = x % gc, rg = x / gc, per = 32 / a.cx;
+            tn = cg * a.cx + jb % a.cx;
+            q = rg * per + jb / a.cx;
+            Q = 256 / a.tiles_n;
+        } else {
+            Q = (int)gridDim.x / a.tiles_n;
+            tn = b % a.tiles_n;
+            q = b / a.tiles_n;
+        }
+        M = a.ndev ? min(*a.ndev, a.nrows) : a.nrows;
+        tiles_m = (M + GT_BM - 1) / GT_BM;
+        if (q >= tiles_m) return;
+        n0 = tn * GT_BN;
+        u0 = (n0 >> 2) + 8 * wave + 4 * hf;               // the lane's four hidden units
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
+        // stores are issued by EVERY lane, always (the number of vector-memory operations in flight is known at every wait): a
+        // hypothesis row past the edge writes into the lane's own 16 bytes of a dump page instead
+        dump = gate_dump_page + 4 * (int)threadIdx.x;
+        wrow = a.wt + (size_t)(n0 + 32 * wave + li) * H + hf * 8;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * hf + p) ^ ((li >> 1) & 7)) * 4);
+#pragma unroll
+        for (int i = 0; i < WS_NP; ++i) {
+            const int row = 8 * (WS_NP * wave + i) + lrow;
+            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+        }
+        // ---- prologue (first tile): every index by ordinary loads, nothing asynchronous is in flight yet (a.rows != NULL: the
+        //      launcher sends calls without a row list to gate_xg_u16_kernel).  (Requesting the first gate fragments in front of
+        //      the index loads was measured and is slower: the two dependent index round trips then queue behind 128 KB per CU.)
+        tm = q;
+        {
+            const int m0 = tm * GT_BM;
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) {
+                const int r = m0 + 32 * nb + li;
+                eok[nb] = r < M;
+                eg[nb] = a.rows[eok[nb] ? r : M - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) {
+                const int r = piece_row(m0, i);
+                nok[i] = r < M;
+                rn[i] = a.rows[nok[i] ? r : M - 1];
+            }
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) {
+                ep[nb] = a.prev[eg[nb]];
+                ew[nb] = a.word[eg[nb]];
+            }
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) {
+                const int p = a.prev[rn[i]];
+                vidx[i] = (nok[i] && p >= 0) ? p : OOB_ROW;
+            }
+            // "used" here: with LDS-DMA pieces in flight hipcc waits vmcnt(0) in front of the first use of an ordinary load's result
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) { asm volatile("" : "+v"(eg[nb])); asm volatile("" : "+v"(ep[nb])); asm volatile("" : "+v"(ew[nb])); }
+#pragma unroll
+            for (int i = 0; i < WS_NP; ++i) asm volatile("" : "+v"(vidx[i]));
+        }
+        JLM_WS_T(1);
+        // W0 D0 W1 D1 ... W(L-1) D(L-1) W(L)
+        gate_for_each_ic([&](auto sc) {
+            constexpr int SG = decltype(sc)::value;
+            this->template load_w<SG>();
+            if constexpr (SG < L) this->template issue<SG>();
+        }, std::make_integer_sequence<int, L + 1>{});
+        tile<true>(tm + Q < tiles_m, 0);
+        tm += Q;
+        for (int t_no = 1; tm < tiles_m; tm += Q, ++t_no) tile<false>(tm + Q < tiles_m, t_no);
+    }
+};
+
+template <int L, bool HF32>
+__global__ __launch_bounds__(256, 1) void gate_ws_kernel(GateXgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    GateWs<L, HF32> k(a, smem);
+    k.run();
+}
+
+
+}  // namespace
+
+int jlm_gate::ws_launch(const GateXgArgs &a, int L, int Q, hipStream_t stream) {
+    const bool hf32 = a.h_f32 != nullptr;
+    const void *fn = L == 3 ? (hf32 ? reinterpret_cast<const void *>(gate_ws_kernel<3, true>) : reinterpret_cast<const void *>(gate_ws_kernel<3, false>))
+                            : (hf32 ? reinterpret_cast<const void *>(gate_ws_kernel<7, true>) : reinterpret_cast<const void *>(gate_ws_kernel<7, false>));
+    const int lds = (L + 1) * WS_STAGE_FLOATS * 4;
+    static JlmLdsGrant grant[4];
+    if (int rc = jlm_grant_lds(grant[(L == 3 ? 0 : 2) + (hf32 ? 1 : 0)], fn, lds)) return rc;
+    GateXgArgs args = a;
+    void *params[] = {&args};
+    hipError_t e = hipLaunchKernel(fn, dim3(a.tiles_n * Q), dim3(256), params, lds, stream);
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -203,7 +203,10 @@ def test_lstm_step_split(L, H, E, R, use_rows):
 
 
 @pytest.mark.parametrize("H,R,use_rows", [(64, 10, False), (64, 200, True), (512, 700, True), (512, 2560, True), (128, 161, True),
-                                         (512, 159, False)])
+                                         (512, 159, False),
+                                         # the W-stationary persistent kernel (H = 512 with a row list): one tile per workgroup at 2 560 rows; two
+                                         # or three tiles per workgroup (first / middle / last tile of a sequence); eight (BASELINE configs[2])
+                                         (512, 5200, True), (512, 20480, True), (512, 1, True)])
 def test_lstm_step_xg(L, H, R, use_rows):
     """jlm_lstm_step_xg (one 160 x 128 tile per CU, gate-interleave-8 order, table rows as accumulator start values)
     against the f64 restatement on the ORIGINAL f32 operands and against the numpy double fed the same split rows;
