@@ -207,6 +207,7 @@ class DecodeEngine:
         # decode_batch on the same decoder must not clear each other's flag (it decides the CU share, i.e. the vocabulary kernel's
         # column cuts, of every batch the thread submits meanwhile)
         self._tls = threading.local()
+        self._submit_lock = threading.RLock()
 
     @property
     def pipelined(self):
@@ -259,7 +260,7 @@ class DecodeEngine:
         timing="inflight": the same events recorded on the batch's own stream of the PIPELINED submit -- a kernel's time
         then includes what it loses to the other batches in flight (bench.py: `frac_in_pipeline`)."""
         torch = self.torch
-        with self._ctx():
+        with self._submit_lock, self._ctx():          # (the plan list and the stream rotation are shared by every submitting thread)
             if self.device.type != "cuda" or self.n_streams < 2 or (timing and timing != "inflight"):
                 return self._submit(lat, kind, vocab, dyn_lists, topN, timing)
             if len(self._streams) != self.n_streams:
