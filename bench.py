@@ -58,7 +58,7 @@ def kernel_source_sha256():
 def gate_source_sha256():
     """Identity of the LSTM-step kernel the committed PMC traffic figure was measured on"""
     h = hashlib.sha256()
-    for f in ("jlm_gate.hip", "jlm_common.h"):
+    for f in ("jlm_gate.hip", "jlm_gate_ws.hip", "jlm_gate.h", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -418,6 +418,12 @@ def main():
         line_extra["host_cpu_ms_per_step"] = round(cpu_s / args.steps * 1e3, 3)
         line_extra["host_cpu_note"] = ("process CPU time (all threads of this rank: calling thread, lattice workers, HIP runtime) per "
                                        "step of the timed region; %.2f CPUs busy on average, %d usable" % (cpu_s / dt, jlm_amd.usable_cpus()))
+        from jlm_amd import numa as _numa
+        _node, _cpus = dec._numa if getattr(dec, "_numa", None) is not None else _numa.worker_cpus(torch.cuda.current_device())
+        line_extra["host_cpus"] = {"usable_by_this_rank": jlm_amd.usable_cpus(), "ranks_on_this_node": int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
+                                   "lattice_workers": dec.prefetch_workers, "gpu_numa_node": _node, "workers_pinned_to_cpus": len(_cpus),
+                                   "note": "usable = affinity mask capped by the cgroup quota, divided by the ranks of the node (jlm_amd.usable_cpus); "
+                                           "the lattice workers pin themselves to the CPUs of their GPU's NUMA node (jlm_amd/numa.py; 0 = sysfs names none)"}
         assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
         del out        # ~300 k list objects: kept alive they make every later full garbage collection (the loops below) slower
         total_chars_per_step = sum_over_ranks(float(chars_per_step))

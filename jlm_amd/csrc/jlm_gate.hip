@@ -626,6 +626,350 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
 }
 
 
+
+// =====================================================================================================================
+// Round 4: the same tile, PERSISTENT (gate_pu_kernel; H = 512, launches of two or more row tiles per CU).
+//
+// gate_xg_u16_kernel costs 21.5 us per 160 x 128 tile at any number of rows: 14.2 in its sixteen k-steps, the rest -- index
+// chains 0.8, first ring stages 1.7, cell update 2.5, the gap until the next workgroup of the CU is running ~2.3 -- with the
+// matrix pipe idle (profiles/r03_a_gate_timeline.txt, r03_a_gate_kbench_ab.txt).  Here a workgroup keeps its gate-column tile
+// and walks the row tiles q, q + Q, ... (grid = 256: 16 column tiles x Q = 16 sequences) with the k-step loop of the kernel
+// above, and the RING DOES NOT STOP at a tile's end: the last three k-steps of a tile request stages 0 .. 2 of the next one
+// and read its first fragments, the row indices of the next tile's state pieces are fetched under the first k-steps, the
+// epilogue's own indices of a tile under ITS first k-steps -- a tile's cell update is followed by the next tile's first MFMA.
+// Every wait is a counted s_waitcnt vmcnt(n) derived at compile time from the issue order (pu_* functions, the scheme of
+// csrc/jlm_gate_ws.hip); stores are issued by every lane (rows past the edge: a dump page) so that the count is exact.
+constexpr int PU_ST = 3;                                  // stores per hypothesis block and lane that every launch issues (c, h hi, h lo)
+__device__ float gate_pu_dump_page[4 * 512 + 8];
+
+// issue order of a tile's vector-memory operations, per wave type (NB hypothesis blocks, NP pieces per stage).  k-step j issues
+//   D  the NP pieces of stage j + 3 (of the NEXT tile from j = 13 on);
+//   X  j = 0: the epilogue's row ids (NB; first tile: prologue), j = 1: row ids of the next tile's state pieces (NP - 2), j = 2: prev /
+//      word of the epilogue rows (2 NB; first tile: prologue), j = 3: prev of the next tile's piece rows (NP - 2), j = 5 + wave: the
+//      epilogue operands (5 NB: table line quads + old cell state);
+// and the cell update behind k-step 15 issues PU_ST stores per block.
+constexpr int pu_x(bool first, int nb, int np, int j) {
+    return j == 0 ? (first ? 0 : nb) : j == 1 ? np - 2 : j == 2 ? (first ? 0 : 2 * nb) : j == 3 ? np - 2 : 0;
+}
+constexpr int pu_issued(bool first, int nb, int np, int j) { return np + pu_x(first, nb, np, j); }
+// operations issued behind the D of k-step j0 up to (not including) the top of k-step j1 of the same tile, the epilogue operands
+// (5 NB loads at k-step 5 + wave, a run-time position: the waits that can see them exist in two forms) not counted
+constexpr int pu_between(bool first, int nb, int np, int j0, int j1) {
+    int n = pu_x(first, nb, np, j0);
+    for (int j = j0 + 1; j < j1; ++j) n += pu_issued(first, nb, np, j);
+    return n;
+}
+constexpr int pu_clamp(int n) { return n > 63 ? 63 : n; }
+// top of k-step kt: stage kt + 1 has landed.  It was requested in k-step kt - 2 -- of the tile before for kt < 2 (the first tile: in
+// the prologue, D0 D1 D2 back to back), with that tile's cell-update stores in between
+constexpr int pu_top(bool first, int nb, int np, int kt) {
+    if (kt >= 2) return pu_between(first, nb, np, kt - 2, kt);
+    if (first) return np * (1 - kt) + (kt == 1 ? pu_issued(true, nb, np, 0) : 0);
+    // (the tile before is never a "first" tile as far as k-steps 13 .. 15 go: their X is the same in both)
+    int n = pu_x(false, nb, np, 14 + kt);
+    for (int j = 15 + kt; j < 16; ++j) n += pu_issued(false, nb, np, j);
+    n += nb * PU_ST;
+    for (int j = 0; j < kt; ++j) n += pu_issued(false, nb, np, j);
+    return n;
+}
+static_assert(pu_top(true, 3, 4, 0) == 4 && pu_top(true, 3, 4, 1) == 4 && pu_top(false, 3, 4, 5) == 2 + 4 && pu_top(false, 2, 5, 0) == 5 + 6 &&
+              pu_top(false, 3, 4, 1) == 9 + 4 + 3, "issue-order bookkeeping");
+
+template <int NB, int NP, int BS, bool HF32>
+struct GatePu {
+    static constexpr int NK = 16, S = GT_STAGES, NS = NP - 2;
+    static constexpr int OOB_ROW = 0x7fffffff;
+    const GateXgArgs &a;
+    float *smem;
+    int lane, wave, gb, hb0, li, hf, lrow, lslot, H, ld, M, Q, n0, u0, tiles_m, tm, xg_at;
+    __amdgpu_buffer_rsrc_t rs_w, rs_h;
+    float *dump;
+    int goff[2][2], w_off, h_off;
+    int eg[NB], ep[NB], ew[NB];
+    bool eok[NB];
+    int vidx[NP], voff[NP], dst[NP];
+    int rn[NS];
+    bool nok[NS];
+    f32x16 acc[NB];
+    f16x8 A[2][2], B[BS][NB][2];
+    f32x4 xg[NB][4], cp[NB];
+
+    __device__ __forceinline__ GatePu(const GateXgArgs &a_, float *smem_) : a(a_), smem(smem_) {}
+    __device__ __forceinline__ int piece_index(int i) const { return (NP == 4) ? 2 * wave + i : 8 + 3 * (wave - 4) + i; }
+
+    template <int SG>
+    __device__ __forceinline__ void issue() {
+        float *base = smem + (SG & (S - 1)) * GT_STAGE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < 2)
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                                                            (SG & (NK - 1)) * 128, 0, 0);
+            else
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                                                            (SG & (NK - 1)) * 128, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void issue_at(int sg) {     // the prologue's stages (a run-time stage number: folded after inlining)
+        float *base = smem + (sg & (S - 1)) * GT_STAGE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < 2)
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                                                            sg * 128, 0, 0);
+            else
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                                                            sg * 128, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void rdA(int stage, int st, int p) {
+        A[st][p] = *reinterpret_cast<const f16x8 *>(smem + (stage & (S - 1)) * GT_STAGE_FLOATS + w_off + goff[st][p]);
+    }
+    __device__ __forceinline__ void rdB(int stage, int st, int nb, int p) {
+        B[st % BS][nb][p] = *reinterpret_cast<const f16x8 *>(smem + (stage & (S - 1)) * GT_STAGE_FLOATS + h_off + nb * 1024 + goff[st][p]);
+    }
+    __device__ __forceinline__ void load_int(int &d, const int *src) { asm volatile("global_load_dword %0, %1, off" : "=&v"(d) : "v"(src) : "memory"); }
+    template <int N>
+    __device__ __forceinline__ void wait_int(int &v) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+    __device__ __forceinline__ void load_ops() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float *xrp = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * gb + 4 * hf;
+            const float *cpp = a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+            asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                         "global_load_dwordx4 %1, %5, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %5, off offset:64\n\t"
+                         "global_load_dwordx4 %3, %5, off offset:96\n\t"
+                         "global_load_dwordx4 %4, %6, off"
+                         : "=&v"(xg[nb][0]), "=&v"(xg[nb][1]), "=&v"(xg[nb][2]), "=&v"(xg[nb][3]), "=&v"(cp[nb])
+                         : "v"(xrp), "v"(cpp) : "memory");
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void wait_ops() {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(xg[nb][0]), "+v"(xg[nb][1]), "+v"(xg[nb][2]), "+v"(xg[nb][3]), "+v"(cp[nb]) : "n"(N) : "memory");
+    }
+
+    // one half step (k-step KT, half ST) of gate_xg_body_u: 3 NB MFMAs, the fragment registers refilled in place behind them -- A with
+    // half ST of k-step KT + 1 (KT + 1 = 16: stage 0 of the next tile), B with the same (BS = 2) or with the NEXT half step (BS = 1)
+    template <int KT, int ST, int DMA, bool ZERO>
+    __device__ __forceinline__ void half() {
+        constexpr int BKT = (BS == 2) ? KT + 1 : (ST == 0 ? KT : KT + 1), BST = (BS == 2) ? ST : 1 - ST;
+        const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ST][1], B[ST % BS][nb][0], ZERO ? zf : acc[nb], 0, 0, 0);
+            if constexpr (DMA >= 0) { if (nb == 0) issue<DMA>(); }
+        }
+        rdA(KT + 1, ST, 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ST][0], B[ST % BS][nb][0], acc[nb], 0, 0, 0);
+            rdB(BKT, BST, nb, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ST][0], B[ST % BS][nb][1], acc[nb], 0, 0, 0);
+            rdB(BKT, BST, nb, 1);
+        }
+        rdA(KT + 1, ST, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i == 0 && DMA >= 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+            if (i == NB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i >= NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i == 3 * NB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    template <bool FIRST, int KT>
+    __device__ __forceinline__ void kstep(int m0, int m0n, bool has_next) {
+        // the epilogue operands (5 NB loads behind the D of k-step xg_at) are younger than the stage waited for when they went out in
+        // k-step KT - 2 or KT - 1
+        constexpr int base = pu_top(FIRST, NB, NP, KT);
+        if (KT >= 2 && (unsigned)(KT - 1 - xg_at) < 2u) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(pu_clamp(base + 5 * NB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(pu_clamp(base)) : "memory");
+        if constexpr (KT == 0 && FIRST) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                rdA(0, st, 1); rdA(0, st, 0);
+                if (st < BS) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) { rdB(0, st, nb, 0); rdB(0, st, nb, 1); }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KT == 13) {
+            // in front of the next tile's first stage: its state pieces' predecessors (X of k-step 3); younger: the rest of that X is
+            // this very group, then k-steps 4 .. 12 and, among them, the epilogue operands
+#pragma unroll
+            for (int i = 0; i < NS; ++i) wait_int<pu_clamp(9 * NP)>(rn[i]);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) vidx[2 + i] = (nok[i] && rn[i] >= 0) ? rn[i] : OOB_ROW;
+        }
+        half<KT, 0, (KT + 3) & (NK - 1), KT == 0>();
+        if constexpr (KT == 0 && !FIRST) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int r = m0 + 32 * (hb0 + nb) + li;
+                eok[nb] = r < M;
+                load_int(eg[nb], a.rows + (eok[nb] ? r : M - 1));
+            }
+        }
+        if constexpr (KT == 1) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int r = m0n + 8 * piece_index(i) + lrow;
+                nok[i] = has_next && r < M;
+                load_int(rn[i], a.rows + (nok[i] ? r : M - 1));
+            }
+        }
+        if constexpr (KT == 2 && !FIRST) {
+            // behind D of k-step 2: the row ids (X of k-step 0); younger: k-step 1, D of k-step 2
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wait_int<pu_clamp(pu_issued(false, NB, NP, 1) + NP)>(eg[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                load_int(ep[nb], a.prev + eg[nb]);
+                load_int(ew[nb], a.word + eg[nb]);
+            }
+        }
+        if constexpr (KT == 3) {
+            // behind D of k-step 3: the next tile's piece row ids (X of k-step 1); younger: k-step 2, D of k-step 3
+#pragma unroll
+            for (int i = 0; i < NS; ++i) wait_int<pu_clamp(pu_issued(FIRST, NB, NP, 2) + NP)>(rn[i]);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) load_int(rn[i], a.prev + rn[i]);
+        }
+        if constexpr (KT >= 5 && KT <= 12) {
+            if (KT == xg_at) {
+                if constexpr (!FIRST) {
+                    // prev / word of the epilogue rows (X of k-step 2); younger: k-steps 3 .. KT - 1, D of k-step KT
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        wait_int<pu_clamp(pu_between(false, NB, NP, 2, KT) - 2 * NB + NP)>(ep[nb]);
+                        wait_int<pu_clamp(pu_between(false, NB, NP, 2, KT) - 2 * NB + NP)>(ew[nb]);
+                    }
+                }
+                load_ops();
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        half<KT, 1, -1, false>();
+    }
+
+    template <bool FIRST>
+    __device__ __forceinline__ void tile(bool has_next) {
+        const int m0 = tm * GT_BM, m0n = (tm + Q) * GT_BM;
+        gate_for_each_ic([&](auto ktc) { this->template kstep<FIRST, decltype(ktc)::value>(m0, m0n, has_next); },
+                         std::make_integer_sequence<int, NK>{});
+        // the epilogue operands: requested at k-step xg_at <= 12 -- at least the three stages of k-steps 13 .. 15 are younger
+        wait_ops<3 * NP>();
+        const float ds = a.descale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int g = eok[nb] ? eg[nb] : -1;
+            f32x4 cn, hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
+                const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
+                cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
+                hn[e] = jlm_tanh(cn[e]) * go;
+            }
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hi4, lo4;
+            jlm_split4(hn, a.h_scale, hi4, lo4);
+            float *crow = g >= 0 ? a.c_out + (size_t)g * ld + u0 : dump;
+            *reinterpret_cast<f32x4 *>(crow) = cn;
+            _Float16 *blk = g >= 0 ? reinterpret_cast<_Float16 *>(a.h_out + (size_t)g * ld + (u0 & ~7)) + (u0 & 7) : reinterpret_cast<_Float16 *>(dump);
+            *reinterpret_cast<f16x4 *>(blk) = hi4;
+            *reinterpret_cast<f16x4 *>(g >= 0 ? blk + 8 : blk + 4) = lo4;
+            if constexpr (HF32) *reinterpret_cast<f32x4 *>(g >= 0 ? a.h_f32 + (size_t)g * ld + u0 : dump) = hn;
+        }
+    }
+
+    __device__ __forceinline__ void run(int wave_) {
+        lane = threadIdx.x & 63; wave = wave_;
+        gb = wave & 3; hb0 = (wave >> 2) ? 3 : 0;
+        li = lane & 31; hf = lane >> 5; lrow = lane >> 3; lslot = lane & 7;
+        H = a.H; ld = a.ld;
+        // XCD x keeps tiles_n / 8 gate-column tiles (their slices of the gate matrix stay in its L2: every tile stages them again)
+        const int b = blockIdx.x, cpx = a.tiles_n >> 3;
+        const int x = b & 7, jb = b >> 3;
+        const int tn = x * cpx + jb % cpx, q = jb / cpx;
+        Q = ((int)gridDim.x >> 3) / cpx;
+        M = a.ndev ? min(*a.ndev, a.nrows) : a.nrows;
+        tiles_m = (M + GT_BM - 1) / GT_BM;
+        if (q >= tiles_m) return;
+        n0 = tn * GT_BN;
+        u0 = (n0 >> 2) + 8 * gb + 4 * hf;
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)(H * 4), 0x40000000, 0x00020000);
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
+        dump = gate_pu_dump_page + 4 * (int)threadIdx.x;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) goff[st][p] = li * 32 + (((4 * st + 2 * hf + p) ^ ((li >> 1) & 7)) * 4);
+        w_off = gb * 32 * 32;
+        h_off = (GT_BN + hb0 * 32) * 32;
+        tm = q;
+        const int m0 = tm * GT_BM;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int r = m0 + 32 * (hb0 + nb) + li;
+            eok[nb] = r < M;
+            eg[nb] = a.rows[eok[nb] ? r : M - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int r = m0 + 8 * piece_index(i) + lrow;
+            nok[i] = r < M;
+            rn[i] = a.rows[nok[i] ? r : M - 1];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { ep[nb] = a.prev[eg[nb]]; ew[nb] = a.word[eg[nb]]; }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < 2) {
+                const int pr = 8 * (2 * wave + i), row = pr + lrow;
+                vidx[i] = n0 + row;
+                voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+                dst[i] = pr * 32;
+            } else {
+                const int prow = 8 * piece_index(i - 2), row = prow + lrow;
+                const int p = a.prev[rn[i - 2]];
+                vidx[i] = (nok[i - 2] && p >= 0) ? p : OOB_ROW;
+                voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+                dst[i] = (GT_BN + prow) * 32;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { asm volatile("" : "+v"(eg[nb])); asm volatile("" : "+v"(ep[nb])); asm volatile("" : "+v"(ew[nb])); }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(vidx[i]));
+        issue_at(0); issue_at(1); issue_at(2);
+        // the epilogue operands go out at k-step 5 + wave: the chip's table lines spread over eight k-steps instead of one burst
+        xg_at = 5 + wave;
+        tile<true>(tm + Q < tiles_m);
+        tm += Q;
+        for (; tm < tiles_m; tm += Q) tile<false>(tm + Q < tiles_m);
+    }
+};
+
+template <bool HF32>
+__global__ __launch_bounds__(512, 1) void gate_pu_kernel(GateXgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave < 4) { GatePu<3, 4, 1, HF32> k(a, smem); k.run(wave); }
+    else { GatePu<2, 5, 2, HF32> k(a, smem); k.run(wave); }
+}
+
 __device__ __forceinline__ bool gate_tile_of_block(const GateXgArgs &a, int &m0, int &n0, int &M) {
     const int b = blockIdx.x;
     int tm, tn;
@@ -722,14 +1066,26 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     a.tiles_m = (n_rows_max + GT_BM - 1) / GT_BM;
     a.tiles_n = 4 * H / GT_BN;
     a.cx = 0;
-    // JLM_GATE_V: 2 the W-stationary persistent kernel (csrc/jlm_gate_ws.hip: H = 512, a row list, gate-column tiles divisible over the 8
-    // XCDs); 1 one tile per workgroup, refill-in-place pipeline (round 3); 0 the round-2 loop (every H).  Default: 2 from 8 192 rows
-    // (two or more tiles per workgroup: 77.5 vs 82 us at 10 240 rows, 155 vs 167 at 20 480 -- tools/gpu_gate_ws.sh), else 1 (one tile
-    // per CU: 23.5 vs 27.5 us at 2 560 rows -- a single tile pays for loading its gate fragments and gets nothing back)
+    // JLM_GATE_V: 3 the persistent form of the one-tile kernel (gate_pu_kernel above); 2 the W-stationary persistent kernel
+    // (csrc/jlm_gate_ws.hip) -- both for H = 512, a row list, gate-column tiles divisible over the 8 XCDs; 1 one tile per workgroup,
+    // refill-in-place pipeline (round 3); 0 the round-2 loop (every H).  Default by the launch's row bound (tools/gpu_gate_pu.sh,
+    // tools/gpu_gate_ws.sh; us per launch for 1 / 3 / 2 on one box: 2 560 rows 23.2 / 24.1 / 26.4, 5 120: 42.1 / 40.5 / 43.1,
+    // 10 240: 82.7 / 75.0 / 80.2, 20 480: 174 / 160 / 156): one tile per CU -> 1; two to a few tiles per CU -> 3; more -> 2
     static const int variant_env = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : -1;
-    const int variant = variant_env >= 0 ? variant_env : (n_rows_max >= 8192 ? 2 : 1);
+    const int variant = variant_env >= 0 ? variant_env : (n_rows_max >= 16384 ? 2 : n_rows_max >= 4096 ? 3 : 1);
     static const int ws_l = getenv("JLM_GATE_WS_L") ? atoi(getenv("JLM_GATE_WS_L")) : 3;
-    if (variant == 2 && H == 512 && rows && (a.tiles_n & 7) == 0) {
+    if (variant == 3 && H == 512 && rows && (a.tiles_n & 7) == 0) {
+        // the persistent form of the one-tile kernel (gate_pu_kernel): tiles_n column tiles x Q row-tile sequences
+        const int per_col = 256 / a.tiles_n;
+        const int Q = a.tiles_m < per_col ? a.tiles_m : per_col;
+        const bool hf32 = h_f32_out != nullptr;
+        const void *fn = hf32 ? reinterpret_cast<const void *>(gate_pu_kernel<true>) : reinterpret_cast<const void *>(gate_pu_kernel<false>);
+        static JlmLdsGrant grant_pu[2];
+        if (int rc = jlm_grant_lds(grant_pu[hf32 ? 1 : 0], fn, GT_LDS_BYTES)) return rc;
+        void *params[] = {&a};
+        hipError_t e = hipLaunchKernel(fn, dim3(a.tiles_n * Q), dim3(512), params, GT_LDS_BYTES, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    } else if (variant == 2 && H == 512 && rows && (a.tiles_n & 7) == 0) {
         const int per_col = 256 / a.tiles_n;                       // row-tile sequences per gate-column tile: one resident workgroup per CU
         const int Q = a.tiles_m < per_col ? a.tiles_m : per_col;
         // gate-column tiles per XCD: fabric bytes ~ (16 / cx) x rows x 2 KB of state + (cx / 16) x 8 XCDs x 4 MB of gate matrix
