@@ -59,8 +59,13 @@ def main():
             best += o[0][1] == g[0][1]
             full += [w for _, w in o] == [w for _, w in g]
             md = max(md, max(abs(a[0] - b[0]) for a, b in zip(o, g)))
-        print("%-28s n=%3d  1-best %3d/%3d  n-best %3d/%3d  max score diff %.2e" % (name, len(sents), best, len(sents), full,
-                                                                                  len(sents), md))
+        m = dec.model.dev
+        form = "f32" if getattr(m, "split_array", None) is None else ("mixed" if len(getattr(m, "mixed_idx", [])) == m.n_segs else
+                                                                      "hybrid" if getattr(m, "mixed_idx", []) else "split")
+        cal = getattr(m, "mixed_calib", None)
+        print("%-28s n=%3d  1-best %3d/%3d  n-best %3d/%3d  max score diff %.2e  normaliser on %s rows%s" % (
+            name, len(sents), best, len(sents), full, len(sents), md, form,
+            "" if cal is None else " (load-time calibration: lse rms diff %.1e, limit %.0e)" % (cal["lse_rms_diff"], cal["limit"])))
 
 
 if __name__ == "__main__":
