@@ -200,7 +200,11 @@ class DecodeEngine:
         # step against 2.06 with three (jlm_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 when it still can)
         from . import hw_queues_ok as _hwq
         self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "4" if _hwq() else "3")))
-        self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "66")) if self.n_streams >= 2 else 0
+        # CU share of the vocabulary kernel beside other batches in flight.  Round 4: 100 (no cap).  With four batches in flight the
+        # step is flat in the share (1.85-1.93 ms device-resident for 50 ... 100 %, profiles/r04_b_share_sweep.txt), and a share
+        # below 100 makes the kernel's column cuts -- the grouping of its float32 partial sums, i.e. the last bits of a score --
+        # depend on whether the call had one chunk or several: one input, two answers.  JLM_LSE_SHARE=66 restores round 3's cut.
+        self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "100")) if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
         # `pipelined`: set by the caller around a pipelined sequence of submits (Decoder.decode_batch).  Per THREAD: two threads inside
@@ -357,7 +361,7 @@ class DecodeEngine:
         # The share is a property of the CALL (a pipelined sequence of batches: decode_batch with more than one chunk sets
         # `pipelined`), not of what happens to be in flight at this moment: the share moves the column cuts of the vocabulary
         # kernel, i.e. the grouping of its f32 partial sums, and a sentence's score must not depend on its chunk's position.
-        share = self.lse_share_pct if ((not timing or timing == "inflight") and self.pipelined) else 0
+        share = self.lse_share_pct if ((not timing or timing == "inflight") and self.pipelined and self.lse_share_pct < 100) else 0
         rc = ops.backend().decode_frames(self.m.decode_model(), p.obj, lat.n_frames, max_words["vs"], max_words["di"],
                                          max_words["dd"], bool(side), bool(timing), int(share))
         if rc != 0:

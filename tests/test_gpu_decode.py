@@ -214,7 +214,9 @@ def test_pipelined_chunks_equal_serial_decode(fixture, kind, kw, fx):
     share = eng.lse_share_pct
     try:
         dec.max_batch, dec.prefetch_workers = 48, 3
-        eng.lse_share_pct = 0        # the CU share moves the normaliser's column cuts (summation order) while another batch is in flight
+        # (the engine's default CU share is 100 %: the normaliser's column cuts -- the summation order -- do not depend on what else is
+        #  in flight or on how many chunks the call has; a share below 100 would make them)
+        assert eng.lse_share_pct in (0, 100)
         fast = dec.decode_batch(sents, beam_width=8, **kw)
         chunks = dec._chunks(sents, 8)                     # the same device batches (dealt by decreasing length), one at a time
         eng.n_streams, dec.perf_timing, dec.pipeline_depth, dec.prefetch_workers = 1, True, 0, 1

@@ -401,3 +401,39 @@ def test_packed_rows_take_32_blocks_at_most(tmp_path, fake):
     from jlm_amd.model import LSTM_Model
     m = LSTM_Model(1).dev
     assert m.split_array is not None and m.mixed_idx == [] and m.ld_tm == 0 and m.mixed_calib is None
+
+
+@pytest.mark.parametrize("mult,kept", [(1.0, True), (40.0, False)])
+def test_load_time_calibration_follows_the_logit_range(tmp_path, fake, monkeypatch, mult, kept):
+    """DeviceModel._calibrate_mixed over the numpy double: the same model keeps its mixed rows with its output embeddings as they are and
+    loses them with the embeddings x 40 (logits of +-40: the int8 cross terms would move path scores beyond the tolerance) -- and the
+    decode equals the oracle either way."""
+    for k in ("JLM_MIXED_MAX_LSE_RMS", "JLM_MIXED_MAX_SPREAD", "JLM_LSE_MIXED"):
+        monkeypatch.delenv(k, raising=False)
+    root = str(tmp_path)
+    cfg = synth.make_config(2000, 64, 200, "vtable", synth.wide_segs(2000))
+    _lex, _rd = synth.write_lexicon(root, 2000, alphabet=12)
+    w = synth.make_weights(cfg, scale=0.1)
+    for key in list(w):
+        if key.startswith("LM"):
+            w[key] = (w[key] * np.float32(mult)).astype(np.float32)
+    import json
+    import pickle
+    d = os.path.join(root, "train", "experiments", "1")
+    os.makedirs(os.path.join(d, "weights"), exist_ok=True)
+    with open(os.path.join(d, "config.json"), "wt") as f:
+        f.write(json.dumps(cfg))
+    with open(os.path.join(d, "weights", "lstm_weights.pkl"), "wb") as f:
+        pickle.dump(w, f)
+    jconfig.set_root(root)
+    from jlm_amd.decoder import Decoder
+    dec = Decoder(1)
+    dec.perf_timing = False
+    m = dec.model.dev
+    assert m.mixed_calib is not None and m.mixed_calib["kept"] == kept and bool(m.mixed_idx) == kept, m.mixed_calib
+    sents = synth.make_ragged_sentences(5, 2, 9, seed=5, alphabet=12)
+    o = orc.OracleDecoder(root, 1)
+    for s, g in zip(sents, dec.decode_batch(sents, beam_width=6)):
+        want = o.decode(s, beam_width=6)
+        assert [x for _, x in g] == [x for _, x in want]
+        np.testing.assert_allclose([x for x, _ in g], [x for x, _ in want], rtol=1e-6, atol=2e-5)
