@@ -32,3 +32,5 @@ pr.enable()
 dec.decode_batch(sents * chunks, beam_width=10, **kw)
 pr.disable()
 st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(22)
+print("---- by own time")
+st.sort_stats("tottime").print_stats(22)
