@@ -437,3 +437,10 @@ def test_load_time_calibration_follows_the_logit_range(tmp_path, fake, monkeypat
         want = o.decode(s, beam_width=6)
         assert [x for _, x in g] == [x for _, x in want]
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in want], rtol=1e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 5, 9])
+def test_random_models_on_the_double(seed, tmp_path, fake):
+    """A few of the GPU suite's random model draws (tests/random_models.py) through the host path on the numpy double."""
+    from tests import random_models as rm
+    rm.check(seed, str(tmp_path))
