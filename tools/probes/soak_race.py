@@ -18,8 +18,11 @@ for fixture, cls, kw in (("mid-vtable", Decoder, {}), ("mid-tied", Decoder, dict
     dec.perf_timing = False
     dec.max_batch = 192
     sents = synth.make_ragged_sentences(192 * chunks, 1, 30, seed=99, alphabet=al)
-    dec._engine.lse_share_pct = 0        # the CU share changes the vocabulary kernel's column cuts (a different summation order in the
-    t = time.perf_counter()              # last float32 bits) whenever another batch is in flight: off, so that both runs cut alike
+    # (rounds 2-3: a CU share below 100 % changed the vocabulary kernel's column cuts -- the summation order of the last float32 bits --
+    #  whenever another batch was in flight, and this probe switched the share off.  Round 4: the default share is 100, both runs cut alike)
+    if os.environ.get("SOAK_SHARE"):
+        dec._engine.lse_share_pct = int(os.environ["SOAK_SHARE"])
+    t = time.perf_counter()
     fast = dec.decode_batch(sents, beam_width=10, **kw)
     t_fast = time.perf_counter() - t
     eng = dec._engine
