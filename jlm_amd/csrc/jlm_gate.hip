@@ -641,6 +641,15 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
 // csrc/jlm_gate_ws.hip); stores are issued by every lane (rows past the edge: a dump page) so that the count is exact.
 constexpr int PU_ST = 3;                                  // stores per hypothesis block and lane that every launch issues (c, h hi, h lo)
 __device__ float gate_pu_dump_page[4 * 512 + 8];
+// -DJLM_PROFILE builds (tools/probes/gate_pu_profile.py): waves 0 and 4 stamp, for a workgroup's first eight tiles, the shader clock
+// at the top of the tile's k-steps, behind them, when the epilogue operands are in, and behind the cell update; [4] the wall clock
+#ifdef JLM_PROFILE
+__device__ unsigned long long jlm_gate_pu_time[256][2][8][5];
+#define JLM_PU_T(i) do { if ((threadIdx.x & 255) == 0 && tix < 8) { jlm_gate_pu_time[blockIdx.x & 255][threadIdx.x >> 8][tix][i] = clock64(); \
+    if ((i) == 0) jlm_gate_pu_time[blockIdx.x & 255][threadIdx.x >> 8][tix][4] = wall_clock64(); } } while (0)
+#else
+#define JLM_PU_T(i) (void)0
+#endif
 
 // issue order of a tile's vector-memory operations, per wave type (NB hypothesis blocks, NP pieces per stage).  k-step j issues
 //   D  the NP pieces of stage j + 3 (of the NEXT tile from j = 13 on);
@@ -689,6 +698,9 @@ struct GatePu {
     bool eok[NB];
     int vidx[NP], voff[NP], dst[NP];
     int rn[NS];
+#ifdef JLM_PROFILE
+    int tix = 0;
+#endif
     bool nok[NS];
     f32x16 acc[NB];
     f16x8 A[2][2], B[BS][NB][2];
@@ -866,10 +878,13 @@ struct GatePu {
     template <bool FIRST>
     __device__ __forceinline__ void tile(bool has_next) {
         const int m0 = tm * GT_BM, m0n = (tm + Q) * GT_BM;
+        JLM_PU_T(0);
         gate_for_each_ic([&](auto ktc) { this->template kstep<FIRST, decltype(ktc)::value>(m0, m0n, has_next); },
                          std::make_integer_sequence<int, NK>{});
+        JLM_PU_T(1);
         // the epilogue operands: requested at k-step xg_at <= 12 -- at least the three stages of k-steps 13 .. 15 are younger
         wait_ops<3 * NP>();
+        JLM_PU_T(2);
         const float ds = a.descale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -892,6 +907,10 @@ struct GatePu {
             *reinterpret_cast<f16x4 *>(g >= 0 ? blk + 8 : blk + 4) = lo4;
             if constexpr (HF32) *reinterpret_cast<f32x4 *>(g >= 0 ? a.h_f32 + (size_t)g * ld + u0 : dump) = hn;
         }
+        JLM_PU_T(3);
+#ifdef JLM_PROFILE
+        ++tix;
+#endif
     }
 
     __device__ __forceinline__ void run(int wave_) {
@@ -1024,6 +1043,12 @@ __global__ __launch_bounds__(512, 1) void gate_xg_kernel(GateXgArgs a) {
 }
 
 }  // namespace
+
+#ifdef JLM_PROFILE
+extern "C" int jlm_prof_read_gate_pu(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_gate_pu_time), sizeof(jlm_gate_pu_time)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // the kernel of the refill-in-place pipeline; measurement builds (-DJLM_GATE_ABLATE) carry ablated copies, picked by JLM_GATE_ABL
 static std::vector<const void *> gate_u16_variants() {
