@@ -54,6 +54,13 @@ extern "C" int jlm_prof_read_gate(unsigned long long *out) {
 #define JLM_GT_T(i) (void)0
 #endif
 
+// the NP LDS-DMA instructions of a k-step: 1 one behind each of the half step's first NP MFMAs, 0 all behind the first (rounds 2-3).
+// Interleaved A/B, tools/gpu_gate_spread.sh: the persistent kernels -2 ... -3.5 % (72.4 vs 73.5 us at 10 240 rows, 151 vs 157 at
+// 20 480), the one-tile kernel unchanged; a wider spacing (every second / third MFMA) measures the same as 1.
+#ifndef GT_DMA_SPREAD
+#define GT_DMA_SPREAD 1
+#endif
+
 namespace {
 
 constexpr int GT_STAGES = 4;
@@ -552,7 +559,7 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
 #pragma unroll
         for (int i = 0; i < 3 * NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i == 0 && DMA >= 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+            if (GT_DMA_SPREAD ? (i < NP && DMA >= 0) : (i == 0 && DMA >= 0)) __builtin_amdgcn_sched_group_barrier(0x020, GT_DMA_SPREAD ? 1 : NP, 0);
             if (i == NB - 1 && RA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i >= NB && RB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i == 3 * NB - 1 && RA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -790,7 +797,7 @@ struct GatePu {
 #pragma unroll
         for (int i = 0; i < 3 * NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i == 0 && DMA >= 0) __builtin_amdgcn_sched_group_barrier(0x020, NP, 0);
+            if (GT_DMA_SPREAD ? (i < NP && DMA >= 0) : (i == 0 && DMA >= 0)) __builtin_amdgcn_sched_group_barrier(0x020, GT_DMA_SPREAD ? 1 : NP, 0);
             if (i == NB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i >= NB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (i == 3 * NB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);

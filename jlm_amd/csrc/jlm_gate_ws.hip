@@ -195,7 +195,7 @@ struct GateWs {
 #pragma unroll
         for (int i = 0; i < 3 * WS_NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i == 0 && DMA >= 0 && !(WS_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, WS_NP, 0);
+            if (i < WS_NP && DMA >= 0 && !(WS_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // (one LDS-DMA instruction behind each of the first five MFMAs)
             if (i >= WS_NB && !(WS_ABL & 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
