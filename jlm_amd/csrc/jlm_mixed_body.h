@@ -13,6 +13,9 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define MX_MAX_PARTS 96
 #define MX_MAX_SUB (MX_MAX_PARTS + JLM_MAX_SEGMENTS)
 
+#ifndef MX_DMA_SPREAD
+#define MX_DMA_SPREAD 1
+#endif
 #ifndef MX_ABL
 #define MX_ABL 0      // measurement builds: 1 no in-stream fold, 2 no combine, 4 no DMA in the loop, 8 no barrier, 32 no LDS reads in the loop
 #endif
@@ -118,7 +121,7 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)p2);
         rs_bias = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p2u), 0, __builtin_amdgcn_readfirstlane(sg.n_vocab) * 4, 0x00020000);
     }
-    auto issue = [&](int t, int buf) {
+    auto issue_bias = [&](int t) {
         if (XBIAS && wave == 0) {                         // (words past the segment's end read 0: they are masked anyway)
 #pragma unroll
             for (int i = 0; i < (TW + 63) / 64; ++i)
@@ -126,6 +129,12 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, (__attribute__((address_space(3))) void *)(smem + BIAS_OFF + (t % 3) * (TW * 4) + i * 256),
                                                              4, (t * TW + i * 64 + lane) * 4, 0, 0, 0);
         }
+    };
+    constexpr int NDMA = NRG * NB;                       // LDS-DMA instructions per wave and tile
+    // (instruction q rides behind matrix instruction q % 4 of 32-k block q / 4 of the tile's first 32-word block; the last 32-k block has
+    //  three matrix instructions when NS16 is odd: shapes whose first block has no place for every q keep the burst)
+    constexpr bool SPREAD = MX_DMA_SPREAD && NDMA <= 4 * (NB - 1) + (NS16 == 2 * NB ? 4 : 3);
+    auto issue_rows = [&](int t, int buf) {
         // the row goes into the per-lane offset (the part the hardware range-checks: a row at or past n_vocab reads zeros), the
         // block into the scalar offset
         const int voff = dvoff + t * (TW * ROWB);
@@ -137,6 +146,13 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
                                                          voff + i * (64 * ROWB), j * 128, 0, 0);
         }
+    };
+    auto issue = [&](int t, int buf) { issue_bias(t); issue_rows(t, buf); };
+    auto issue_piece = [&](int t, int buf, int q) {       // instruction q = i NB + j of issue_rows
+        const int i = q / NB, j = q % NB;
+        unsigned char *dst = smem + buf * BUFB + ((wave + 8 * i) * NB) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
+                                                 dvoff + t * (TW * ROWB) + i * (64 * ROWB), j * 128, 0, 0);
     };
     // fragment addresses: block mt, row li: piece (4 mt + li / 8, j); inside it row li % 8, granule g ^ ((li >> 1) & 7)
     const int x = (li >> 1) & 7;
@@ -206,7 +222,12 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
         }
     };
     auto tile = [&](auto masked_c, int t) {
-        if (!(MX_ABL & 4) && t + 1 < vt1) issue(t + 1, buf ^ 1);
+        // The next tile's LDS-DMA instructions (~56 issue cycles each, 7-8 per wave) ride behind the first block's matrix instructions,
+        // one each, instead of standing in front of them (MX_DMA_SPREAD; interleaved A/B in tools/gpu_lse_spread.sh).  For that they
+        // are straight-line code: the tile behind a sub-range's last one is requested all the same (rows past the segment's end read
+        // zeros; the buffer it lands in is not read again and the tile's closing vmcnt(0) covers it).
+        if (!SPREAD) { if (!(MX_ABL & 4) && t + 1 < vt1) issue(t + 1, buf ^ 1); }
+        else if (!(MX_ABL & 4) && t + 1 < vt1) issue_bias(t + 1);
         const int lim = sg.n_vocab - t * TW;               // valid words of this tile
         // Fragments of 32-k block j: F[0..1] the f16 granules of steps 2 j, 2 j + 1; F[2] hi8, F[3] lo8; one register set, each
         // refilled in place with block j + 1's (or the next 32-word block's first) right behind the MFMA that read it.  f16 and
@@ -238,18 +259,25 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
 #pragma unroll
                     for (int pc = q * PP; pc < (q + 1) * PP && pc < NPIECE; ++pc) fold_piece(pc);
                 };
+                auto dma = [&](int i) {                           // the next tile's LDS-DMA instruction that rides behind matrix instruction i of the block
+                    if (SPREAD && !(MX_ABL & 4) && mt == 0 && 4 * J + i < NDMA) issue_piece(t + 1, buf ^ 1, 4 * J + i);
+                };
                 accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[0]), thi[2 * J], J == 0 ? zf : accf, 0, 0, 0);
+                dma(0);
                 rd(0, J + 1);
                 pieces(4 * J);
                 acci = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], tlo8[J], J == 0 ? zi : acci, 0, 0, 0);
+                dma(1);
                 rd(2, J + 1);
                 pieces(4 * J + 1);
                 if constexpr (second) {
                     accf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[1]), thi[second ? 2 * J + 1 : 0], accf, 0, 0, 0);
+                    dma(2);
                 }
                 rd(1, J + 1);
                 pieces(4 * J + 2);
                 acci = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[3], thi8[J], acci, 0, 0, 0);
+                dma(second ? 3 : 2);
                 rd(3, J + 1);
                 pieces(4 * J + 3);
                 // issue order of the block: matrix instruction, the read behind it, its share of the fold
@@ -257,6 +285,7 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
 #pragma unroll
                 for (int i = 0; i < NM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (SPREAD && !(MX_ABL & 4) && mt == 0 && 4 * J + i < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     if (rdm || mt + 1 < MTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (!(MX_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
                 }
