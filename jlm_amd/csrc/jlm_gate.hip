@@ -434,23 +434,25 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
     // return through either counter and, while one is outstanding -- here always --, turns EVERY wait for an LDS
     // read into s_waitcnt lgkmcnt(0); behind buffer_load ... lds it counts (lgkmcnt(n), in-order returns).
     constexpr int OOB_ROW = 0x7fffffff;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)(H * 4), 0x40000000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
-    int vidx[NP], voff[NP];
+    // Round 4: 16-byte records and ONE address register (idxen): index = row x (row bytes / 16) + the lane's swizzled 16-byte slot.  The
+    // two-register form (idxen + offen: row index, byte offset) costs 32.5 issue cycles per instruction against 25
+    // (tools/probes/lds_dma_issue.hip), and hipcc builds the register pair with moves in front of every instruction.
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)16, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)16, 0x7ffffff0, 0x00020000);
+    const int w16 = H >> 2, h16 = ld >> 2;               // 16-byte records per row
+    int vidx[NP];
     int dst[NP];                                         // float offset inside a stage (wave-uniform)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         if (i < 2) {
             const int pr = 8 * (2 * wave + i);
             const int row = pr + lrow;
-            vidx[i] = n0 + row;
-            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+            vidx[i] = (n0 + row) * w16 + (lslot ^ ((row >> 1) & 7));
             dst[i] = pr * 32;
         } else {
             const int row = prow[i - 2] + lrow;
             const int p = pok[i - 2] ? pp[i - 2] : -1;
-            vidx[i] = p >= 0 ? p : OOB_ROW;
-            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+            vidx[i] = p >= 0 ? p * h16 + (lslot ^ ((row >> 1) & 7)) : OOB_ROW;
             dst[i] = (GT_BN + prow[i - 2]) * 32;
         }
     }
@@ -460,7 +462,7 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             __builtin_amdgcn_struct_ptr_buffer_load_lds(i < 2 ? rs_w : rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]),
-                                                        16, vidx[i], voff[i], S * 128, 0, 0);
+                                                        16, vidx[i], 0, S * 128, 0, 0);
     };
 
     f32x4 xg[NB][4], cp[NB];
@@ -703,7 +705,8 @@ struct GatePu {
     int goff[2][2], w_off, h_off;
     int eg[NB], ep[NB], ew[NB];
     bool eok[NB];
-    int vidx[NP], voff[NP], dst[NP];
+    int vidx[NP], vslot[NP], dst[NP];                     // record index of the piece's lane (row x records per row + swizzled slot), the slot alone
+    int w16, h16;
     int rn[NS];
 #ifdef JLM_PROFILE
     int tix = 0;
@@ -722,10 +725,10 @@ struct GatePu {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (i < 2)
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], 0,
                                                             (SG & (NK - 1)) * 128, 0, 0);
             else
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], 0,
                                                             (SG & (NK - 1)) * 128, 0, 0);
         }
     }
@@ -734,10 +737,10 @@ struct GatePu {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (i < 2)
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], 0,
                                                             sg * 128, 0, 0);
             else
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], voff[i],
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + dst[i]), 16, vidx[i], 0,
                                                             sg * 128, 0, 0);
         }
     }
@@ -829,7 +832,7 @@ struct GatePu {
 #pragma unroll
             for (int i = 0; i < NS; ++i) wait_int<pu_clamp(9 * NP)>(rn[i]);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) vidx[2 + i] = (nok[i] && rn[i] >= 0) ? rn[i] : OOB_ROW;
+            for (int i = 0; i < NS; ++i) vidx[2 + i] = (nok[i] && rn[i] >= 0) ? rn[i] * h16 + vslot[2 + i] : OOB_ROW;
         }
         half<KT, 0, (KT + 3) & (NK - 1), KT == 0>();
         if constexpr (KT == 0 && !FIRST) {
@@ -935,8 +938,9 @@ struct GatePu {
         if (q >= tiles_m) return;
         n0 = tn * GT_BN;
         u0 = (n0 >> 2) + 8 * gb + 4 * hf;
-        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)(H * 4), 0x40000000, 0x00020000);
-        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
+        rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wt), (short)16, 0x7ffffff0, 0x00020000);     // (16-byte records, one address
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)16, 0x7ffffff0, 0x00020000);      //  register: see gate_xg_body_u)
+        w16 = H >> 2; h16 = ld >> 2;
         dump = gate_pu_dump_page + 4 * (int)threadIdx.x;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -964,14 +968,14 @@ struct GatePu {
         for (int i = 0; i < NP; ++i) {
             if (i < 2) {
                 const int pr = 8 * (2 * wave + i), row = pr + lrow;
-                vidx[i] = n0 + row;
-                voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+                vslot[i] = lslot ^ ((row >> 1) & 7);
+                vidx[i] = (n0 + row) * w16 + vslot[i];
                 dst[i] = pr * 32;
             } else {
                 const int prow = 8 * piece_index(i - 2), row = prow + lrow;
                 const int p = a.prev[rn[i - 2]];
-                vidx[i] = (nok[i - 2] && p >= 0) ? p : OOB_ROW;
-                voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+                vslot[i] = lslot ^ ((row >> 1) & 7);
+                vidx[i] = (nok[i - 2] && p >= 0) ? p * h16 + vslot[i] : OOB_ROW;
                 dst[i] = (GT_BN + prow) * 32;
             }
         }

@@ -107,7 +107,8 @@ struct GateWs {
     int goff[2][2];                                       // fragment offsets (floats) inside a stage
     int eg[WS_NB], ep[WS_NB], ew[WS_NB];                  // epilogue: global row, predecessor row, word of the lane's hypothesis in each block
     bool eok[WS_NB];
-    int vidx[WS_NP], voff[WS_NP];                         // LDS-DMA pieces of this wave: row index (or OOB) and swizzled byte offset
+    int vidx[WS_NP], vslot[WS_NP];                        // LDS-DMA pieces of this wave: 16-byte record index (row x records per row + swizzled slot, or OOB), the slot
+    int h16;
     int rn[WS_NP];                                        // next tile: piece row ids, then their predecessors
     bool nok[WS_NP];
     f32x16 acc[WS_NB];
@@ -133,7 +134,7 @@ struct GateWs {
 #pragma unroll
         for (int i = 0; i < WS_NP; ++i)
             __builtin_amdgcn_struct_ptr_buffer_load_lds(rs_h, (__attribute__((address_space(3))) void *)(base + 8 * (WS_NP * wave + i) * 32),
-                                                        16, vidx[i], voff[i], (SG & (WS_NK - 1)) * 128, 0, 0);
+                                                        16, vidx[i], 0, (SG & (WS_NK - 1)) * 128, 0, 0);
     }
     __device__ __forceinline__ void rdB(int stage, int st, int nb, int p) {
         if ((WS_ABL & 2) && !(stage == 0 && st == 0)) { asm volatile("" : "+v"(B[nb][p])); return; }
@@ -216,7 +217,7 @@ struct GateWs {
 #pragma unroll
             for (int i = 0; i < WS_NP; ++i) wait_int<ws_wait_ppn(FIRST, L)>(rn[i]);
 #pragma unroll
-            for (int i = 0; i < WS_NP; ++i) vidx[i] = (nok[i] && rn[i] >= 0) ? rn[i] : OOB_ROW;
+            for (int i = 0; i < WS_NP; ++i) vidx[i] = (nok[i] && rn[i] >= 0) ? rn[i] * h16 + vslot[i] : OOB_ROW;
         }
         half<KT, 0, (KT + L) & (WS_NK - 1), KT == 0>();
         // ---- the k-step's extra loads (X), then the first tile's gate-matrix loads (W)
@@ -346,7 +347,9 @@ struct GateWs {
         if (q >= tiles_m) return;
         n0 = tn * GT_BN;
         u0 = (n0 >> 2) + 8 * wave + 4 * hf;               // the lane's four hidden units
-        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)(ld * 4), 0x40000000, 0x00020000);
+        // (16-byte records and one address register per piece: csrc/jlm_gate.hip gate_xg_body_u says why)
+        rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.h), (short)16, 0x7ffffff0, 0x00020000);
+        h16 = ld >> 2;
         // stores are issued by EVERY lane, always (the number of vector-memory operations in flight is known at every wait): a
         // hypothesis row past the edge writes into the lane's own 16 bytes of a dump page instead
         dump = gate_dump_page + 4 * (int)threadIdx.x;
@@ -358,7 +361,7 @@ struct GateWs {
 #pragma unroll
         for (int i = 0; i < WS_NP; ++i) {
             const int row = 8 * (WS_NP * wave + i) + lrow;
-            voff[i] = (lslot ^ ((row >> 1) & 7)) * 16;
+            vslot[i] = lslot ^ ((row >> 1) & 7);
         }
         // ---- prologue (first tile): every index by ordinary loads, nothing asynchronous is in flight yet (a.rows != NULL: the
         //      launcher sends calls without a row list to gate_xg_u16_kernel).  (Requesting the first gate fragments in front of
@@ -386,7 +389,7 @@ struct GateWs {
 #pragma unroll
             for (int i = 0; i < WS_NP; ++i) {
                 const int p = a.prev[rn[i]];
-                vidx[i] = (nok[i] && p >= 0) ? p : OOB_ROW;
+                vidx[i] = (nok[i] && p >= 0) ? p * h16 + vslot[i] : OOB_ROW;
             }
             // "used" here: with LDS-DMA pieces in flight hipcc waits vmcnt(0) in front of the first use of an ordinary load's result
 #pragma unroll
