@@ -133,7 +133,9 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     constexpr int NDMA = NRG * NB;                       // LDS-DMA instructions per wave and tile
     // (instruction q rides behind matrix instruction q % 4 of 32-k block q / 4 of the tile's first 32-word block; the last 32-k block has
     //  three matrix instructions when NS16 is odd: shapes whose first block has no place for every q keep the burst)
-    constexpr bool SPREAD = MX_DMA_SPREAD && NDMA <= 4 * (NB - 1) + (NS16 == 2 * NB ? 4 : 3);
+    // Only the external-bias bodies (the tied k = 256 models: -1 ... -2 %): the D-softmax* launch measures the same either way and the tile
+    // requested behind each sub-range's last one is 1.8 MB of its HBM traffic per launch.
+    constexpr bool SPREAD = MX_DMA_SPREAD && XBIAS && NDMA <= 4 * (NB - 1) + (NS16 == 2 * NB ? 4 : 3);
     auto issue_rows = [&](int t, int buf) {
         // the row goes into the per-lane offset (the part the hardware range-checks: a row at or past n_vocab reads zeros), the
         // block into the scalar offset
