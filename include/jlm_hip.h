@@ -172,7 +172,8 @@ int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void 
  *                  (model.py:125-131 computes x.IM_g + h.HM_g + b_g; the table is the x.IM_g + b_g part);
  *   h_f32_out      optional (may be NULL): h' also as plain f32 rows, same stride (untied models: T is the state itself and
  *                  the edge-logit / word-list kernels read T as f32);
- *   c stays f32.   H % 32 == 0, ld_state % 16 == 0. */
+ *   c stays f32.   H % 32 == 0, ld_state % 16 == 0.  State rows are addressed as 16-byte records through a 31-bit index:
+ *   (highest row number + 1) x ld_state / 4 < 2^31 (16.7 M rows at H = 512). */
 int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
                      const int *rows, const int *prev, const int *word,
                      const void *wt8, const float *xgate8, int H, float descale, float h_scale, float *h_f32_out,

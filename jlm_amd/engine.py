@@ -76,6 +76,10 @@ class _Plan:
         self.B, self.beam, self.F = B, beam, F
         rmax, ncell = B * beam, F * B
         G = F * rmax
+        # the LSTM-step kernels address state rows as 16-byte records through a 31-bit index (csrc/jlm_gate.hip): H / 4 records per row
+        if G * max(m.H // 4, 1) >= 0x7ffffff0:
+            raise ValueError("a decode plan of %d state rows of %d units is beyond the LSTM-step kernels' addressing (rows x H / 4 < 2^31): "
+                             "decode fewer sentences per batch (Decoder.max_batch)" % (G, m.H))
         self.rmax, self.G, self.ncell = rmax, G, ncell
         sizes = dict(sent_len=B, end_off=ncell + 1, node_start=caps["nodes"], node_word=caps["nodes"], sg_off=ncell + 1,
                      sg_word=caps["nodes"], sg_node=caps["nodes"], g0=ncell, cidx=ncell, sidx=ncell, sidx2=ncell,
