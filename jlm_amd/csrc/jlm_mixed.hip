@@ -35,6 +35,10 @@
 #include "jlm_mixed_body.h"
 using namespace jlm_mx;
 
+#ifndef JLM_MX_WIDE_DEFAULT
+#define JLM_MX_WIDE_DEFAULT 0
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ packing (load time)
@@ -190,13 +194,15 @@ template <bool INLINE, bool XB, int NB, int NS16>
 struct MxCall {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                                float2 *prow, unsigned char *smem) {
-        mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        if constexpr (!XB && NB <= MX_ACC2_MAX_NB) mx_body_a2<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        else mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
     }
 };
 template <bool XB, int NB, int NS16>
 __device__ __noinline__ void mx_body_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                              float2 *prow, unsigned char *smem) {
-    mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    if constexpr (!XB && NB <= MX_ACC2_MAX_NB) mx_body_a2<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    else mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
 }
 template <bool XB, int NB, int NS16>
 struct MxCall<false, XB, NB, NS16> {
@@ -260,6 +266,9 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const
 
 #ifdef JLM_MX_RESOURCES
 // one kernel per instantiation: hipcc -S -DJLM_MX_RESOURCES shows each form's own register count (the shipped kernel hosts all)
+#define MX_RES2(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res2_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
+        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body_a2<NB_, NS_, mx_blocks_per_tile(NB_)>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
+MX_RES2(2, 4) MX_RES2(4, 7) MX_RES2(7, 13)
 #define MX_RES(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
         extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body<NB_, NS_, mx_blocks_per_tile(NB_), false>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
 MX_RES(2, 4) MX_RES(4, 7) MX_RES(7, 13) MX_RES(8, 16)
@@ -336,6 +345,10 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
     JLM_LAUNCH_CHECK();
     return 0;
 }
+
+// the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
+int jlm_mx_wide_launch(const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
+                       int lds, hipStream_t st);
 
 extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
                                    const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
@@ -469,6 +482,12 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     const dim3 grid(n_cols * n_ptiles), block(512);
     float2 *part2 = reinterpret_cast<float2 *>(part);
     hipStream_t st = (hipStream_t)stream;
+    static int wide = -1;
+    if (wide < 0) { const char *e = getenv("JLM_MX_WIDE"); wide = e ? atoi(e) : JLM_MX_WIDE_DEFAULT; }
+    if (which == 0 && wide) {
+        if (int rc = jlm_mx_wide_launch(a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+        return n_sub;
+    }
     switch (which) {
     case 0: hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
     case 1: hipLaunchKernelGGL(MX_KERNEL_GENERIC, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;

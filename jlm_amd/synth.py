@@ -286,6 +286,7 @@ def build_fixture(root, name, exp_id=1):
       wide128-tied                                 tied, E = 128: mixed rows without bias columns (the form of the tied k = 256 models)
       mid-tied / mid-vtable / mid-untied          V=50000 H=512 (configs 1 / 2; untied projection UM [H, V])
       big-tied                                    V=100000 H=512 E=256 (config 3)
+      bigpeaked-tied                              config 3's model with output embeddings x 10 and the unigram-like bias
       peaked-{vtable,tied} / peaked20-{vtable,tied} / heavy-{vtable,tied}
                                                   the mid-* models with trained-model-like output embeddings (shape_weights): logits
                                                   of +-10 / +-20 and a unigram-like bias; Student-t(3) blocks
@@ -296,6 +297,8 @@ def build_fixture(root, name, exp_id=1):
     alphabet, scale, shape = 80, 0.05, None
     if size in ("peaked", "peaked20", "heavy"):
         shape, size = size, "mid"
+    elif size == "bigpeaked":             # config 3's model (V = 100 k) with the peaked statistics
+        shape, size = "peaked", "big"
     if size == "small":
         scale = 0.25                      # keeps the tiny model's logits O(1)
         V, H, E, segs, alphabet = 2000, 64, 32, small_segs(2000), 12

@@ -64,7 +64,7 @@ DECODE_CASES = [
     ("mid-vtable/dynamic-quirk", "mid-vtable", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 8, 20, 94)),
     ("big-tied/static-b20", "big-tied", "static", dict(beam_width=20), ("fixed", 16, 20, 96)),
     # untied projection (model.py:189-191) at BASELINE size: V=50k, k = H = 512 (the tile-form normaliser inside the frame loop)
-    ("mid-untied/static", "mid-untied", "static", dict(beam_width=10), ("fixed", 8, 20, 95)),
+    ("mid-untied/static", "mid-untied", "static", dict(beam_width=10), ("fixed", 24, 20, 95)),
     # BASELINE-size models with trained-model-like statistics (round 4): what the int8 cross terms of the mixed-row normaliser
     # are sensitive to.  The default path must hold the same bars on them (DeviceModel._calibrate_mixed decides the form).
     ("peaked-vtable/static", "peaked-vtable", "static", dict(beam_width=10), ("fixed", 24, 20, 93)),
@@ -74,6 +74,17 @@ DECODE_CASES = [
     ("heavy-vtable/static", "heavy-vtable", "static", dict(beam_width=10), ("fixed", 24, 20, 89)),
     ("peaked20-vtable/static-vs", "peaked20-vtable", "static", dict(beam_width=10, vocab_select=True), ("fixed", 8, 20, 88)),
     ("peaked20-tied/dynamic", "peaked20-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 8, 20, 87)),
+    # round 5: the stated sentence lengths L = 10 and L = 40 -- a path score is a sum over the frames, so its error grows
+    # with L -- and trained-like weights for the selected-vocabulary decoders and for configs[2]'s shape
+    ("mid-vtable/static-L40", "mid-vtable", "static", dict(beam_width=10), ("fixed", 16, 40, 86)),
+    ("peaked-vtable/static-L40", "peaked-vtable", "static", dict(beam_width=10), ("fixed", 16, 40, 85)),
+    ("peaked20-tied/static-L40", "peaked20-tied", "static", dict(beam_width=10), ("fixed", 8, 40, 84)),
+    ("mid-tied/dynamic-L40", "mid-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 8, 40, 83)),
+    ("mid-vtable/static-L10", "mid-vtable", "static", dict(beam_width=10), ("fixed", 16, 10, 82)),
+    ("mid-tied/dynamic-L10", "mid-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 8, 10, 81)),
+    ("peaked-tied/dynamic", "peaked-tied", "dynamic", dict(beam_width=10, vocab_select=True), ("fixed", 16, 20, 80)),
+    ("peaked-vtable/static-vs", "peaked-vtable", "static", dict(beam_width=10, vocab_select=True), ("fixed", 16, 20, 79)),
+    ("bigpeaked-tied/static-b20", "bigpeaked-tied", "static", dict(beam_width=20), ("fixed", 8, 20, 78)),
 ]
 
 def is_quirk_case(name):

@@ -13,6 +13,8 @@ L = _lib.lib()
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+if os.environ.get("KBENCH_DUMP"):
+    torch.manual_seed(1234)
 PEAK = 157.3
 
 
@@ -37,6 +39,8 @@ def report(name, flops, ms):
 
 
 def rnd(*shape, scale=1.0):
+    if os.environ.get("KBENCH_ZERO"):        # all-zero operands: the same instruction stream at the lowest switching power (is a kernel power-bound?)
+        return torch.zeros(*shape, device=dev)
     return (torch.randn(*shape, device=dev) * scale).contiguous()
 
 
@@ -159,7 +163,11 @@ def bench_lse_mixed(V, widths, R, tag):
     g = lambda: L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
     f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
-    print("parts:", f())
+    np_ = f()
+    print("parts:", np_)
+    if os.environ.get("KBENCH_DUMP"):        # bit comparison of two builds: same seed, the partial (max, sum) pairs to a file
+        torch.cuda.synchronize()
+        np.save("%s.%s.k%s.npy" % (os.environ["KBENCH_DUMP"], tag, "_".join(map(str, widths))), part[:np_].cpu().numpy())
     report("vocab_lse_mixed      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
     report("pack_t_mixed         %s R=%d" % (tag, R), 1.0, timeit(g))
 
