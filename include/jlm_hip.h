@@ -346,11 +346,14 @@ int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
  * segment's int8 scale (a power of two >= max |f16(src scale)| / 127). */
 int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias, float scale, float bias_scale, float s8,
                    void *dst, int ld_dst, void *stream);
-/* The hypothesis side: T [G, ldt] f32 -> packed rows Tm [n_rows_max, ld_tm], COMPACT: packed row r = hypothesis row rows[r]
- * (a frame's live rows: one small buffer, rewritten every frame) (ld_tm = jlm_mixed_t_stride(segs, n_segs), 4-byte units): per
- * segment nb blocks of x = T 2^eT log2 e in the same block format, the bias constants 2^eT / 2^(eT-11) at columns k, k + 1 of the
- * f16 part, and at the end of the row JLM_MAX_SEGMENTS floats: the row's int8 scale per segment.  Once per row and frame (one
- * wave per row); the vocabulary kernel's workgroups only load the result.  t_scale[i] = 2^eT_i (a power of two). */
+/* The hypothesis side: T [G, ldt] f32 -> packed rows Tm, COMPACT: packed row r = hypothesis row rows[r] (a frame's live rows: one
+ * small buffer, rewritten every frame) (ld_tm = jlm_mixed_t_stride(segs, n_segs), 4-byte units per row): per segment nb blocks of
+ * x = T 2^eT log2 e in the same block format, the bias constants 2^eT / 2^(eT-11) at columns k, k + 1 of the f16 part, and
+ * JLM_MAX_SEGMENTS floats per row: the row's int8 scale per segment.  Once per row and frame (one wave per row); the vocabulary
+ * kernel's workgroups only load the result.  t_scale[i] = 2^eT_i (a power of two).
+ * ABI 9: the buffer is an opaque image of WHOLE 32-row blocks -- the caller allocates ceil(n_rows_max / 32) * 32 rows of ld_tm
+ * floats -- laid out granule-major inside a block (16-byte granule g of row r at block (r / 32) + g * 512 + (r % 32) * 16, the
+ * scales behind the granules), so that a wave of the vocabulary kernel reads one contiguous kilobyte per operand load. */
 int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs);
 int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
                      int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream);

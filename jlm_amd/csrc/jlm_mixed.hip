@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
     const int g = rows ? rows[r] : r;
     const int lane = threadIdx.x & 63;
     const float *trow = T + (size_t)g * ldt;
-    unsigned char *orow = Tm + (size_t)r * ld_tm * 4;          // COMPACT: packed row r = hypothesis row rows[r]
+    unsigned char *oblk = Tm + mx_tm_block(r, ld_tm);          // COMPACT: packed row r = hypothesis row rows[r]; granule-major (jlm_mixed_body.h)
     // (the launcher admits at most 64 groups -- 32 blocks -- per row: ONE pass, so every segment's maximum is reduced over all of
     //  the lanes that hold it before anything is quantised)
     int total = 0;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
             if (lane == 0 && grp0 == 0) {
                 const float w = x * (1.0f / 127.0f);
                 const int bt = (__float_as_int(w) + 0x007fffff) & 0x7f800000;
-                *reinterpret_cast<float *>(orow + ld_tm * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sj) = x > 0.0f ? __int_as_float(bt) : 1.0f;
+                *reinterpret_cast<float *>(oblk + mx_tm_scale(ld_tm, r, sj)) = x > 0.0f ? __int_as_float(bt) : 1.0f;
             }
         }
         if (!act) return;
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
             }
             ph[q] = wh; pl[q] = wl;
         }
-        unsigned char *blk = orow + sg.tm_off + j * 128;
-        *reinterpret_cast<f32x4 *>(blk + 32 * half) = *reinterpret_cast<const f32x4 *>(hi);
-        *reinterpret_cast<f32x4 *>(blk + 32 * half + 16) = *reinterpret_cast<const f32x4 *>(hi + 8);
-        *reinterpret_cast<i32x4 *>(blk + 64 + 16 * half) = i32x4{ph[0], ph[1], ph[2], ph[3]};
-        *reinterpret_cast<i32x4 *>(blk + 96 + 16 * half) = i32x4{pl[0], pl[1], pl[2], pl[3]};
+        // granules of the row's block j: 2 half, 2 half + 1 (f16 hi), 4 + half (hi8), 6 + half (lo8)
+        *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half, r)) = *reinterpret_cast<const f32x4 *>(hi);
+        *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half + 1, r)) = *reinterpret_cast<const f32x4 *>(hi + 8);
+        *reinterpret_cast<i32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 4 + half, r)) = i32x4{ph[0], ph[1], ph[2], ph[3]};
+        *reinterpret_cast<i32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 6 + half, r)) = i32x4{pl[0], pl[1], pl[2], pl[3]};
     }
 }
 
@@ -194,15 +194,13 @@ template <bool INLINE, bool XB, int NB, int NS16>
 struct MxCall {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                                float2 *prow, unsigned char *smem) {
-        if constexpr (!XB && NB <= MX_ACC2_MAX_NB) mx_body_a2<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
-        else mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+        mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
     }
 };
 template <bool XB, int NB, int NS16>
 __device__ __noinline__ void mx_body_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *T, int ldt, const int *rows,
                                              float2 *prow, unsigned char *smem) {
-    if constexpr (!XB && NB <= MX_ACC2_MAX_NB) mx_body_a2<NB, NS16, mx_blocks_per_tile(NB)>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
-    else mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+    mx_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
 }
 template <bool XB, int NB, int NS16>
 struct MxCall<false, XB, NB, NS16> {
@@ -266,9 +264,6 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const
 
 #ifdef JLM_MX_RESOURCES
 // one kernel per instantiation: hipcc -S -DJLM_MX_RESOURCES shows each form's own register count (the shipped kernel hosts all)
-#define MX_RES2(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res2_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
-        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body_a2<NB_, NS_, mx_blocks_per_tile(NB_)>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
-MX_RES2(2, 4) MX_RES2(4, 7) MX_RES2(7, 13)
 #define MX_RES(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
         extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; mx_body<NB_, NS_, mx_blocks_per_tile(NB_), false>(sg, 0, 100, blockIdx.x, 2560, T, ldt, rows, part, sm_); }
 MX_RES(2, 4) MX_RES(4, 7) MX_RES(7, 13) MX_RES(8, 16)

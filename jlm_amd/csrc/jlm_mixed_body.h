@@ -16,9 +16,6 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #ifndef MX_DMA_SPREAD
 #define MX_DMA_SPREAD 1
 #endif
-#ifndef MX_ACC2_MAX_NB
-#define MX_ACC2_MAX_NB 4   // contractions of up to this many 32-k blocks run the two-accumulator-pair body (mx_body_a2); 0: none
-#endif
 #ifndef MX_ABL
 #define MX_ABL 0      // measurement builds: 1 no in-stream fold, 2 no combine, 4 no DMA in the loop, 8 no barrier, 32 no LDS reads in the loop
 #endif
@@ -34,6 +31,19 @@ __host__ __device__ constexpr int mx_blocks_per_tile(int nb) { return nb >= 5 ? 
 template <int N> using IC = std::integral_constant<int, N>;
 template <class F, int... I>
 __device__ __forceinline__ void mx_for_each_ic(F &&f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+
+// ------------------------------------------------------------------------------------------------ packed hypothesis rows (Tm)
+// jlm_pack_t_mixed writes, the vocabulary kernels read.  Round 5: GRANULE-MAJOR inside blocks of 32 rows -- a row's 16-byte granule
+// g (8 per 128-byte mixed block, all segments concatenated) lives at
+//      block (r / 32) x 32 ld_tm 4   +   g x 512   +   (r % 32) x 16
+// so that the 64 lanes of a wave (32 rows x the two granules hf = 0 / 1 of an operand) read ONE contiguous kilobyte per load
+// instruction.  Row-major rows (rounds 3-4) made every operand load 64 separate cache lines: 54 loads x 64 lines x 4 waves = 14 k
+// cycles of the texture path per workgroup at k = 200, a quarter of a single-segment launch (profiles/r05_e_clock.txt).  The rows'
+// int8 scales (JLM_MAX_SEGMENTS floats per row) follow the granules of the block: 32 ld_tm 4 - 1024 + (r % 32) x 32.
+// The buffer holds ceil(rows / 32) x 32 rows of ld_tm floats.
+__device__ __forceinline__ size_t mx_tm_block(int r, int ld_tm) { return (size_t)(r >> 5) * 32 * ld_tm * 4; }
+__device__ __forceinline__ int mx_tm_granule(int tm_off, int g, int r) { return (tm_off / 16 + g) * 512 + (r & 31) * 16; }
+__device__ __forceinline__ int mx_tm_scale(int ld_tm, int r, int seg) { return 32 * (ld_tm * 4 - 4 * JLM_MAX_SEGMENTS) + (r & 31) * (4 * JLM_MAX_SEGMENTS) + 4 * seg; }
 
 // ------------------------------------------------------------------------------------------------ the kernel
 struct MxSeg {
@@ -78,21 +88,23 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     //         cost 21 us of a 52-us launch at k = 200 -- every one of a row tile's 24 column workgroups repeated it)
     const int prow = pt * 256 + wave * 32 + li;
     const bool row_ok = prow < n_paths;
-    const unsigned char *trow = reinterpret_cast<const unsigned char *>(T) + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt * 4;
+    // (granule-major packed rows: every load below is one contiguous kilobyte per wave; `rows` is not used -- the packed rows are compact)
+    // (a row past the end reads block 0's slot of its lane -- inside the buffer whatever its size -- and is zeroed below)
+    const unsigned char *tblk = reinterpret_cast<const unsigned char *>(T) + (row_ok ? mx_tm_block(prow, ldt) : 0);
     f16x8 thi[NS16];
     i32x4 thi8[NB], tlo8[NB];
     float s_t;
     {
-        const unsigned char *tb = trow + sg.tm_off;
+        const unsigned char *tb = tblk + mx_tm_granule(sg.tm_off, hf, prow);
         i32x4 raw[NS16 + 2 * NB];
 #pragma unroll
-        for (int q = 0; q < NS16; ++q) raw[q] = *reinterpret_cast<const i32x4 *>(tb + (q >> 1) * 128 + (2 * (q & 1) + hf) * 16);
+        for (int q = 0; q < NS16; ++q) raw[q] = *reinterpret_cast<const i32x4 *>(tb + ((q >> 1) * 8 + 2 * (q & 1)) * 512);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            raw[NS16 + 2 * j] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (4 + hf) * 16);
-            raw[NS16 + 2 * j + 1] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (6 + hf) * 16);
+            raw[NS16 + 2 * j] = *reinterpret_cast<const i32x4 *>(tb + (j * 8 + 4) * 512);
+            raw[NS16 + 2 * j + 1] = *reinterpret_cast<const i32x4 *>(tb + (j * 8 + 6) * 512);
         }
-        s_t = *reinterpret_cast<const float *>(trow + ldt * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sg.seg);
+        s_t = *reinterpret_cast<const float *>(tblk + mx_tm_scale(ldt, prow, sg.seg));
         const i32x4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < NS16; ++q) thi[q] = __builtin_bit_cast(f16x8, row_ok ? raw[q] : z);
@@ -334,209 +346,10 @@ __device__ __forceinline__ void mx_body(const MxSeg &sg, int vt0, int vt1, int p
     if (hf == 0 && row_ok) part_row[prow] = make_float2(m, s);
 }
 
-// ------------------------------------------------------------------------------------------------ round 5: two accumulator pairs
-// mx_body's block has two phases that do not overlap inside a wave: the COMBINE burst (32 VALU instructions that read the
-// accumulators the block's last matrix instruction is still writing -- the wave issues nothing to the matrix pipe from that
-// instruction until the burst is through) and the matrix stream with the fold of v[16] riding in it.  Where the row operands leave
-// room (k + 2 <= 128: 60 registers at k = 100, 32 at k = 50) the body below keeps TWO accumulator pairs and no v[]: even blocks
-// multiply into pair a, odd blocks into pair b, and the whole treatment of a finished pair -- combine IN PLACE (y into the f32
-// accumulator), max, scale / exp2 / add -- rides between the matrix instructions of the next block, which start at once.  Same
-// arithmetic in the same order per logit as mx_body: the partial (max, sum) pairs are bit-identical (tests/test_gpu_kernels.py).
-template <int NB, int NS16, int MTT>
-__device__ __forceinline__ void mx_body_a2(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const float *__restrict__ T, int ldt,
-                                           const int *__restrict__ rows, float2 *__restrict__ part_row, unsigned char *smem) {
-    static_assert(MTT % 2 == 0, "blocks alternate between the two accumulator pairs: a tile holds an even number");
-    constexpr float LN2 = 0.6931471805599453f;
-    constexpr int ROWB = NB * 128;
-    constexpr int TW = 32 * MTT;
-    constexpr int BUFB = TW * ROWB;
-    int tid_ = threadIdx.x;
-    asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hf = lane >> 5, li = lane & 31;
-    // ---- 1. row operands (as mx_body)
-    const int prow = pt * 256 + wave * 32 + li;
-    const bool row_ok = prow < n_paths;
-    const unsigned char *trow = reinterpret_cast<const unsigned char *>(T) + (size_t)(row_ok ? (rows ? rows[prow] : prow) : 0) * ldt * 4;
-    f16x8 thi[NS16];
-    i32x4 thi8[NB], tlo8[NB];
-    float s_t;
-    {
-        const unsigned char *tb = trow + sg.tm_off;
-        i32x4 raw[NS16 + 2 * NB];
-#pragma unroll
-        for (int q = 0; q < NS16; ++q) raw[q] = *reinterpret_cast<const i32x4 *>(tb + (q >> 1) * 128 + (2 * (q & 1) + hf) * 16);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            raw[NS16 + 2 * j] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (4 + hf) * 16);
-            raw[NS16 + 2 * j + 1] = *reinterpret_cast<const i32x4 *>(tb + j * 128 + (6 + hf) * 16);
-        }
-        s_t = *reinterpret_cast<const float *>(trow + ldt * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sg.seg);
-        const i32x4 z = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < NS16; ++q) thi[q] = __builtin_bit_cast(f16x8, row_ok ? raw[q] : z);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            thi8[j] = row_ok ? raw[NS16 + 2 * j] : z;
-            tlo8[j] = row_ok ? raw[NS16 + 2 * j + 1] : z;
-        }
-    }
-    const float csr = s_t * sg.cs;
-    const float descale = sg.descale;
-    // ---- 2. LDS-DMA of a tile (as mx_body)
-    const unsigned long long bptr = reinterpret_cast<unsigned long long>(sg.B);
-    const unsigned long long bptr_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bptr >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)bptr);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0,
-                                                                          __builtin_amdgcn_readfirstlane(sg.n_vocab) * ROWB, 0x00020000);
-    const int r8 = lane >> 3, dslot = lane & 7;
-    const int drow = 8 * wave + r8;
-    const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
-    constexpr int NRG = MTT / 2;
-    constexpr int NDMA = NRG * NB;                       // LDS-DMA instructions per wave and tile
-    auto issue_piece = [&](int t, int buf, int q) {       // instruction q = i NB + j
-        const int i = q / NB, j = q % NB;
-        unsigned char *dst = smem + buf * BUFB + ((wave + 8 * i) * NB) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
-                                                 dvoff + t * (TW * ROWB) + i * (64 * ROWB), j * 128, 0, 0);
-    };
-    auto issue = [&](int t, int buf) {
-#pragma unroll
-        for (int q = 0; q < NDMA; ++q) issue_piece(t, buf, q);
-    };
-    const int x = (li >> 1) & 7;
-    const int fbase = (li >> 3) * (NB * 1024) + (li & 7) * 128;
-    int goff[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) goff[g4] = fbase + ((2 * g4 + hf) ^ x) * 16;
-
-    float m = JLM_NEG_BIG, s = 0.0f;
-    // pair b starts as a finished block of sixteen -1e30 logits (as mx_body's v[]): its fold leaves (m, s) = (very negative, 16),
-    // which the first real fold scales to 0
-    f32x16 fa, fb;
-    i32x16 ia, ib;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { fb[r] = -1.0e30f; ib[r] = 0; fa[r] = 0.0f; ia[r] = 0; }
-    float tmax, nmn, sc_old, add0, add1;
-    constexpr int NSLOT = 4 * NB;                        // issue slots of a block (NS16 odd: the last block's third slot has no matrix instruction)
-    constexpr int NPIECE = 16 + 8 + 1 + 16 + 1;          // 16 x (cvt, fma), 8 x max3, 1, 16 x (fma, exp2, add), 1
-    // (slot 0 carries nothing: the pair's last matrix instruction was issued one slot earlier and its results are 16 passes away)
-    constexpr int PP = (NPIECE + NSLOT - 2) / (NSLOT - 1);
-    // one piece of the treatment of the finished pair (pf, pi), whose block was block mtp of a tile with lim valid words
-    auto fold_piece = [&](auto masked_c, f32x16 &pf, const i32x16 &pi, int mtp, int lim, int pc) {
-        constexpr bool MASKED = decltype(masked_c)::value != 0;
-        if (pc < 16) {
-            const int r = pc;
-            const float y = fmaf((float)pi[r], csr, pf[r]);
-            pf[r] = (MASKED && mtp * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim) ? JLM_NEG_BIG : y;
-        } else if (pc < 24) {
-            const int q = pc - 16;
-            const float t2 = fmaxf(pf[2 * q], pf[2 * q + 1]);
-            tmax = q == 0 ? t2 : fmaxf(tmax, t2);
-        } else if (pc == 24) {
-            const float mn = fmaxf(m, tmax * descale);
-            nmn = -mn;
-            sc_old = __builtin_amdgcn_exp2f(m - mn);
-            m = mn;
-            add0 = 0.0f; add1 = 0.0f;
-        } else if (pc < 41) {
-            const int r = pc - 25;
-            const float e = __builtin_amdgcn_exp2f(fmaf(pf[r], descale, nmn));
-            if (r & 1) add1 += e; else add0 += e;
-        } else if (pc == 41) {
-            s = s * sc_old + (add0 + add1);
-        }
-    };
-    issue(vt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    // one 32-word block: its matrix instructions into (wf, wi); the finished pair (pf, pi) treated between them
-    auto block = [&](auto masked_c, auto mtc, int t, int lim_p, f32x16 &wf, i32x16 &wi, f32x16 &pf, i32x16 &pi, i32x4 (&F)[4]) {
-        constexpr int mt = decltype(mtc)::value;
-        constexpr int mtp = (mt + MTT - 1) % MTT;                 // the finished pair's block number inside its tile
-        const unsigned char *bs = smem + buf * BUFB + mt * (4 * NB * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const i32x16 zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto rd = [&](int g4, int j) {
-            if (j < NB) F[g4] = *reinterpret_cast<const i32x4 *>(bs + j * 1024 + goff[g4]);
-            else if (mt + 1 < MTT) F[g4] = *reinterpret_cast<const i32x4 *>(bs + (4 * NB * 1024) + goff[g4]);
-        };
-        auto pieces = [&](int q) {                                // the pieces that ride in issue slot q of the block
-            if (q == 0) return;
-#pragma unroll
-            for (int pc = (q - 1) * PP; pc < q * PP && pc < NPIECE; ++pc) fold_piece(masked_c, pf, pi, mtp, lim_p, pc);
-        };
-        mx_for_each_ic([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            constexpr bool second = 2 * J + 1 < NS16;
-            constexpr bool rdm = (J + 1 < NB);
-            wf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[0]), thi[2 * J], J == 0 ? zf : wf, 0, 0, 0);
-            rd(0, J + 1);
-            pieces(4 * J);
-            wi = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[2], tlo8[J], J == 0 ? zi : wi, 0, 0, 0);
-            rd(2, J + 1);
-            pieces(4 * J + 1);
-            if constexpr (second) wf = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[1]), thi[second ? 2 * J + 1 : 0], wf, 0, 0, 0);
-            rd(1, J + 1);
-            pieces(4 * J + 2);
-            wi = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[3], thi8[J], wi, 0, 0, 0);
-            rd(3, J + 1);
-            pieces(4 * J + 3);
-            constexpr int NM = second ? 4 : 3;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (rdm || mt + 1 < MTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (4 * J + i > 0) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
-            }
-            if constexpr (!second) {
-                if (rdm || mt + 1 < MTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
-            }
-        }, std::make_integer_sequence<int, NB>{});
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto tile = [&](auto masked_c, int t) {
-        if (t + 1 < vt1) issue(t + 1, buf ^ 1);
-        const int lim = sg.n_vocab - t * TW;               // valid words of this tile
-        i32x4 F[4];
-        {
-            const unsigned char *bs0 = smem + buf * BUFB;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) F[g4] = *reinterpret_cast<const i32x4 *>(bs0 + goff[g4]);
-        }
-        mx_for_each_ic([&](auto hc) {
-            constexpr int mt0 = 2 * decltype(hc)::value;
-            // the pair treated in a tile's first block belongs to the tile before (whole: a segment has one partial tile, its last) or
-            // is the dummy: never masked
-            if constexpr (mt0 == 0) block(IC<0>{}, IC<mt0>{}, t, lim, fa, ia, fb, ib, F);
-            else block(masked_c, IC<mt0>{}, t, lim, fa, ia, fb, ib, F);
-            block(masked_c, IC<mt0 + 1>{}, t, lim, fb, ib, fa, ia, F);
-        }, std::make_integer_sequence<int, MTT / 2>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        buf ^= 1;
-    };
-    const int t_full = min(vt1, sg.n_vocab / TW);
-    for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, t);
-    for (int t = max(vt0, t_full); t < vt1; ++t) tile(IC<1>{}, t);
-    // the last block (pair b: a tile's last block is odd)
-    {
-        const int lim_last = sg.n_vocab - (vt1 - 1) * TW;
-#pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) fold_piece(IC<1>{}, fb, ib, MTT - 1, lim_last, pc);
-    }
-    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
-    {
-        const float mm = fmaxf(m, m2);
-        s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
-        m = mm * LN2;
-    }
-    if (hf == 0 && row_ok) part_row[prow] = make_float2(m, s);
-}
+// (Round 5 tried TWO accumulator pairs at 32 rows per wave -- the finished pair combined, max-ed and exponentiated in place between the
+//  next block's matrix instructions, no combine burst, no v[] -- for every contraction length: 28.2-28.9 vs 28.6-29.6 us at k = 100,
+//  nothing at k = 200 / 50 and on the three-segment launch (profiles/r05_a_acc2.txt).  The two-pair scheme lives on in the wide
+//  kernel, jlm_mixed_w.hip.)
 
 // (Round 3 also tried FOUR waves of 64 rows -- two 32-row sets per wave, every fragment feeding two matrix instructions, one wave per
 //  SIMD owning the 512-register file with two accumulator sets: half the LDS reads, and no faster: 38.1 / 32.8 / 30.8 us against

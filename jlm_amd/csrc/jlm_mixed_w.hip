@@ -174,25 +174,28 @@ struct MxWide {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         hf = lane >> 5;
         const int li = lane & 31;
-        // ---- 1. row operands of both sets, straight into accumulation registers.  A row past the end takes row 0's operands
-        //         (finite numbers; its result is not stored): selecting zeros would cost a VALU move per register.
+        // ---- 1. row operands of both sets, straight into accumulation registers.  A row past the end reads its lane's slot of
+        //         block 0 (inside the buffer whatever its size; its result is not stored and no other row sees it): selecting zeros would cost
+        //         a VALU move per register.
         bool row_ok[2];
         int prow[2];
 #pragma unroll
         for (int S = 0; S < 2; ++S) {
             prow[S] = pt * 256 + wave * 64 + S * 32 + li;
             row_ok[S] = prow[S] < n_paths;
-            const unsigned char *trow = Tm + (size_t)(row_ok[S] ? prow[S] : 0) * ld_tm * 4;
-            const unsigned char *tb = trow + sg.tm_off + hf * 16;
+            // (granule-major packed rows, jlm_mixed_body.h: one contiguous kilobyte per load instruction; the instruction offset has
+            //  12 bits, hence a base per 32-k block)
+            const unsigned char *tblk = Tm + (row_ok[S] ? mx_tm_block(prow[S], ld_tm) : 0);
+            const unsigned char *tb = tblk + mx_tm_granule(sg.tm_off, hf, prow[S]);
 #pragma unroll
             for (int q = 0; q < NS16; ++q)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(thi[S][q]) : "v"(tb), "n"((q >> 1) * 128 + 2 * (q & 1) * 16) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(thi[S][q]) : "v"(tb + (q >> 1) * 4096), "n"(2 * (q & 1) * 512) : "memory");
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(thi8[S][j]) : "v"(tb), "n"(j * 128 + 64) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(tlo8[S][j]) : "v"(tb), "n"(j * 128 + 96) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(thi8[S][j]) : "v"(tb + j * 4096), "n"(4 * 512) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&a"(tlo8[S][j]) : "v"(tb + j * 4096), "n"(6 * 512) : "memory");
             }
-            const float s_t = *reinterpret_cast<const float *>(trow + ld_tm * 4 - 4 * JLM_MAX_SEGMENTS + 4 * sg.seg);
+            const float s_t = *reinterpret_cast<const float *>(tblk + mx_tm_scale(ld_tm, prow[S], sg.seg));
             csr[S] = s_t * sg.cs;
         }
         descale = sg.descale;

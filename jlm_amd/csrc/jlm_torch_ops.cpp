@@ -215,8 +215,8 @@ struct JlmPlan : torch::CustomClassHolder {
         p.run_max = tptr<float>(tensors, "run_max"); p.run_sum = tptr<double>(tensors, "run_sum");
         p.part = tptr<float>(tensors, "part"); p.max_parts = (int)geti(i, "max_parts");
         p.Tm = tptr<void>(tensors, "Tm"); p.ld_tm = (int)geti(i, "ld_tm");
-        TORCH_CHECK(!p.Tm || (p.ld_tm > 0 && find(tensors, "Tm")->numel() >= (int64_t)lat.n_sent * lat.beam * p.ld_tm),
-                    "jlm.Plan: Tm must hold n_sent * beam rows of ld_tm");
+        TORCH_CHECK(!p.Tm || (p.ld_tm > 0 && find(tensors, "Tm")->numel() >= (((int64_t)lat.n_sent * lat.beam + 31) / 32 * 32) * p.ld_tm),
+                    "jlm.Plan: Tm must hold n_sent * beam rows (rounded up to whole 32-row blocks) of ld_tm");
         p.out_nodes = tptr<int>(tensors, "out_nodes"); p.out_len = tptr<int>(tensors, "out_len");
         p.out_score = tptr<double>(tensors, "out_score"); p.stride = (int)geti(i, "stride");
         TORCH_CHECK(st.score && st.lse && st.bp && st.node && st.word && st.cnt && st.live && st.n_live && st.live_base && p.h && p.c &&
@@ -408,7 +408,7 @@ int64_t lse_probe(const c10::intrusive_ptr<JlmModel> &model, const Tensor &rowli
     TORCH_CHECK(rowlist.scalar_type() == at::kInt && prev.scalar_type() == at::kInt && word.scalar_type() == at::kInt, "jlm.lse_probe: int32 indices");
     TORCH_CHECK(h.numel() >= G * model->m.H && c.numel() >= G * model->m.H && T.numel() >= G * model->m.ldt, "jlm.lse_probe: state buffers");
     TORCH_CHECK(part.numel() >= max_parts * rows * 2 && max_parts >= 1, "jlm.lse_probe: slice buffer");
-    TORCH_CHECK(!Tm.has_value() || !Tm->defined() || Tm->numel() >= rows * ld_tm, "jlm.lse_probe: packed-row buffer");
+    TORCH_CHECK(!Tm.has_value() || !Tm->defined() || Tm->numel() >= ((rows + 31) / 32 * 32) * ld_tm, "jlm.lse_probe: packed-row buffer (whole 32-row blocks)");
     const c10::hip::HIPGuard device_guard(h.device().index());
     const std::lock_guard<std::mutex> lock(g_enqueue_mutex);
     const int rc = jlm_lse_probe(&model->m, ptr<const int>(rowlist, "rowlist"), ptr<const int>(prev, "prev"), ptr<const int>(word, "word"),

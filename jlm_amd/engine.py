@@ -133,7 +133,7 @@ class _Plan:
         # packed rows of the frame being stepped, for the segments of the normaliser on mixed rows (jlm_pack_t_mixed)
         self.Tm = None
         if self.part is not None and getattr(m, "ld_tm", 0):
-            self.Tm = torch.zeros((rmax, m.ld_tm), device=dev, dtype=f32)
+            self.Tm = torch.zeros(((rmax + 31) // 32 * 32, m.ld_tm), device=dev, dtype=f32)      # whole 32-row blocks (granule-major, jlm_hip.h)
         self.stride = F + 1
         self.out_nodes = e((rmax, self.stride), i32)
         self.out_len = e(rmax, i32)

@@ -419,7 +419,7 @@ class DeviceModel:
                 h = torch.zeros((G, H), dtype=torch.float32, device=dev)
                 c = torch.zeros((G, H), dtype=torch.float32, device=dev)
                 T = torch.zeros((G, self.ldt), dtype=torch.float32, device=dev)
-                Tm = torch.zeros((R, self.ld_tm), dtype=torch.float32, device=dev)
+                Tm = torch.zeros(((R + 31) // 32 * 32, self.ld_tm), dtype=torch.float32, device=dev)
                 part = torch.zeros((max_parts, R, 2), dtype=torch.float32, device=dev)
                 n = int(O.lse_probe(dm, rowlist, prev, word, S, R, h, c, T, Tm, self.ld_tm, form, part, max_parts))
                 if n < 1:

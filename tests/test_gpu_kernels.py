@@ -845,7 +845,7 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     nd = torch.as_tensor(np.array([R - 2], dtype=np.int32)).cuda()
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
     ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
-    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
     assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
     n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
     assert n >= len(widths), n
@@ -869,7 +869,7 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
             one = (_lib.Segment * 1)(_lib.Segment(w, w + 1, widths[i], segs[i].t_off, segs[i].B + 128 * nb * (w - bounds[i]), segs[i].ldb))
             import ctypes
             ld1 = L.jlm_mixed_t_stride(one, 1)
-            Tm1 = torch.zeros((R, ld1), dtype=torch.float32, device="cuda")
+            Tm1 = torch.zeros(((R + 31) // 32 * 32, ld1), dtype=torch.float32, device="cuda")
             assert L.jlm_pack_t_mixed(one, (ctypes.c_float * 1)(ts[i]), 1, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
                                       Tm1.data_ptr(), ld1, _st()) == 0
             n1 = L.jlm_vocab_lse_mixed(one, (ctypes.c_float * 1)(ds[i]), (ctypes.c_float * 1)(s8[i]), bias2, 1,
@@ -909,7 +909,7 @@ def test_vocab_lse_mixed_spread(L, tails):
     T_np = (np.tanh(rng.standard_normal((R, k))) * rng.uniform(0.05, 1.0, size=(R, 1))).astype(np.float32)
     T = torch.as_tensor(T_np).cuda()
     ld_tm = L.jlm_mixed_t_stride(seg, 1)
-    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
     eT = 10
     assert L.jlm_pack_t_mixed(seg, (ctypes.c_float * 1)(2.0 ** eT), 1, T.data_ptr(), k, None, R, None, Tm.data_ptr(), ld_tm, _st()) == 0
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
@@ -964,7 +964,7 @@ def test_vocab_lse_hybrid(L, V, bounds, R):
     rows = torch.as_tensor(rows_np).cuda()
     nd = torch.as_tensor(np.array([R - 2], dtype=np.int32)).cuda()
     ld_tm = L.jlm_mixed_t_stride(only, 2)
-    Tm = torch.zeros((R, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
     assert L.jlm_pack_t_mixed(only, (ctypes.c_float * 2)(ts[0], ts[1]), 2, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
                               Tm.data_ptr(), ld_tm, _st()) == 0
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")

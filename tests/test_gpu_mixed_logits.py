@@ -76,7 +76,7 @@ def _mixed_lse(m, L, segs, ts, ds, s8, bias2, T, last, rows, part):
     arr = (_lib.Segment * n)(*segs)
     ld_tm = L.jlm_mixed_t_stride(arr, n)
     assert ld_tm > 0
-    Tm = torch.zeros((rows, ld_tm), dtype=torch.float32, device=m.device)
+    Tm = torch.zeros(((rows + 31) // 32 * 32, ld_tm), dtype=torch.float32, device=m.device)
     assert L.jlm_pack_t_mixed(arr, (ctypes.c_float * n)(*ts), n, T.data_ptr(), m.ldt, last.data_ptr(), rows, None, Tm.data_ptr(), ld_tm,
                               _st()) == 0
     r = L.jlm_vocab_lse_mixed(arr, (ctypes.c_float * n)(*ds), (ctypes.c_float * n)(*s8), bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(),

@@ -159,7 +159,7 @@ def bench_lse_mixed(V, widths, R, tag):
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     rows = torch.arange(R, device=dev, dtype=torch.int32)
     ld_tm = L.jlm_mixed_t_stride(segs, n)
-    Tm = torch.zeros((R, ld_tm), device=dev)
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
     g = lambda: L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
     f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
@@ -215,7 +215,7 @@ def bench_lse_hybrid(V, widths, R, tag, n_mixed=2):
     rows = torch.arange(R, device=dev, dtype=torch.int32)
     only = (_lib.Segment * n_mixed)(*[mx[i] for i in range(n_mixed)])
     ld_tm = L.jlm_mixed_t_stride(only, n_mixed)
-    Tm = torch.zeros((R, ld_tm), device=dev)
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
     g = lambda: L.jlm_pack_t_mixed(only, mts, n_mixed, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
     f = lambda: L.jlm_vocab_lse_hybrid(sp, ts, ds, bcol, mx, mds, ms8, n, b2.data_ptr(), T.data_ptr(), off, Tm.data_ptr(), ld_tm,

@@ -25,7 +25,7 @@ for k in ks:
     ts, ds, s8 = (ctypes.c_float * 1)(2.0 ** 10), (ctypes.c_float * 1)(2.0 ** -25), (ctypes.c_float * 1)(2.0 ** 7)
     T = torch.randn(R, kp, device=dev) * (0.0 if ZERO else 0.3)
     ld_tm = L.jlm_mixed_t_stride(seg, 1)
-    Tm = torch.zeros((R, ld_tm), device=dev)
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
     assert L.jlm_pack_t_mixed(seg, ts, 1, T.data_ptr(), kp, None, R, None, Tm.data_ptr(), ld_tm, None) == 0
     part = torch.empty((96, R, 2), device=dev)
     for _ in range(int(os.environ.get("CLOCK_ITERS", "20"))):

@@ -26,7 +26,7 @@ for i, k in enumerate(widths):
     off += k
 T = torch.randn(R, off, device=dev) * 0.3
 ld_tm = L.jlm_mixed_t_stride(segs, n)
-Tm = torch.zeros((R, ld_tm), device=dev)
+Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
 assert L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, None, R, None, Tm.data_ptr(), ld_tm, None) == 0
 part = torch.empty((96, R, 2), device=dev)
 for _ in range(20):
