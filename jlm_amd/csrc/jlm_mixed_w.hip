@@ -29,6 +29,18 @@ using namespace jlm_mx;
 #define MXW_ABL 0      // measurement builds (wrong numbers): 1 no fold, 2 no exp2 in the fold, 4 no LDS-DMA in the loop, 8 no barrier, 16 combine only, 32 no fragment reads in the loop, 64 row set 1 multiplies with set 0's operands
 #endif
 
+#ifdef MXW_TRACE
+// -DMXW_TRACE: wave 0 of the first 256 workgroups stamps the shader clock at kernel-body start [0], when the row operands and the
+// first tile have landed [1], and at the end of every tile [2 + i] (tools/probes/mixed_w_trace.py)
+static __device__ unsigned long long jlm_mxw_trace[256][64];
+extern "C" int jlm_prof_read_mxw_trace(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jlm_mxw_trace), sizeof(jlm_mxw_trace)) == hipSuccess ? 0 : -1;
+}
+#define MXW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256 && (i) < 64) jlm_mxw_trace[blockIdx.x][i] = clock64(); } while (0)
+#else
+#define MXW_STAMP(i) (void)0
+#endif
+
 namespace {
 
 template <int NB, int NS16, int MTT>
@@ -168,6 +180,7 @@ struct MxWide {
                                         float2 *__restrict__ part_row, unsigned char *smem_) {
         constexpr float LN2 = 0.6931471805599453f;
         smem = smem_;
+        MXW_STAMP(0);
         int tid_ = threadIdx.x;
         asm volatile("" : "+v"(tid_));
         const int tid = tid_, lane = tid & 63;
@@ -240,6 +253,7 @@ struct MxWide {
             for (int j = 0; j < NB; ++j) { asm volatile("" : "+a"(thi8[S][j])); asm volatile("" : "+a"(tlo8[S][j])); }
         }
         __builtin_amdgcn_s_barrier();
+        MXW_STAMP(1);
         int buf = 0;
         auto tile = [&](auto masked_c, int t) {
             constexpr bool MASKED = decltype(masked_c)::value != 0;
@@ -263,6 +277,7 @@ struct MxWide {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(MXW_ABL & 8)) __builtin_amdgcn_s_barrier();
             buf ^= 1;
+            MXW_STAMP(2 + t - vt0);
         };
         const int t_full = min(vt1, sg.n_vocab / TW);
         for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, t);
@@ -279,6 +294,7 @@ struct MxWide {
             const float ss = s[S] * __builtin_amdgcn_exp2f(m[S] - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
             if (hf == 0 && row_ok[S]) part_row[prow[S]] = make_float2(mm * LN2, ss);
         }
+        MXW_STAMP(63);
     }
 };
 
