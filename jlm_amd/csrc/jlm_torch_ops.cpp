@@ -11,6 +11,8 @@
 //                             plus the timing events of a timed decode
 //   torch.ops.jlm.decode_frames(Model, Plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct)
 //                             the whole frame loop of a batch: ONE op (jlm_decode_frames)
+//   torch.ops.jlm.decode_batch(Model, Plan, staging block, lattice block, read-back buffers, ...)
+//                             round 5: upload + frame loop + read-back of one batch, ONE op (what DecodeEngine submits)
 //   torch.ops.jlm.frame_times(Plan) -> Tensor [n_frames, 5] milliseconds of the last timed decode (after it finished)
 //   torch.ops.jlm.lstm_step / gemm_nt / softmax_rows      LSTM_Model.predict / project (numpy-facing API)
 //   torch.ops.jlm.pack_split_f16 / pack_split_f16_col / dequant_u8     weight preparation at load
@@ -175,9 +177,6 @@ struct JlmPlan : torch::CustomClassHolder {
     jlm_decode_plan p{};
     int frames_cap = 0;
     std::vector<hipEvent_t> events;         // JLM_EVENTS_PER_FRAME per frame, created on first timed decode
-    // JLM_GRAPH=1: the launch sequence of a decode shape, captured on its second use and replayed (decode_frames)
-    std::map<std::array<long, 8>, hipGraphExec_t> graphs;
-    std::set<std::array<long, 8>> seen, no_graph;
     int timed_frames = 0;                   // frames of the last timed decode (0: the last decode was not timed)
     int device = -1;
 
@@ -225,7 +224,6 @@ struct JlmPlan : torch::CustomClassHolder {
     }
     ~JlmPlan() override {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
     }
 };
 
@@ -267,44 +265,66 @@ int64_t decode_frames(const c10::intrusive_ptr<JlmModel> &model, const c10::intr
         ev = reinterpret_cast<void *const *>(pl.events.data());
         pl.timed_frames = (int)n_frames;
     }
-    // JLM_GRAPH=1: the ~130 launches and events of a batch cost the calling thread ~0.75 ms; a decode shape (frames, list
-    // maxima, CU share, side stream, launch stream) seen for the second time on this plan is captured into a hipGraph and
-    // replayed from then on -- every pointer in it belongs to the plan or the model, nothing in the sequence depends on host
-    // data of the batch.  The first use runs eagerly (one-time kernel attributes, shape checks).
-    // Measured (ROCm 7.2, MI355X, tools/probes/host_threads_cpu.py): correct (the GPU decode suite passes with it) and SLOWER --
-    // 3.52-3.58 vs 2.58-2.71 ms per 256-sentence chunk, the calling thread 3.4 instead of 2.4 ms busy: hipGraphLaunch of this
-    // 130-node, two-branch graph costs more than the launches it replaces, and the two batches in flight no longer overlap.
-    // Left off.
-    static const bool use_graph = [] { const char *e = getenv("JLM_GRAPH"); return e && atoi(e) == 1; }();
-    if (use_graph && !timed) {
-        const std::array<long, 8> key = {(long)n_frames, (long)vs_max, (long)di_max, (long)dd_max, (long)lse_cu_share_pct,
-                                         (long)(side_s != nullptr), (long)(intptr_t)main.stream(), (long)(intptr_t)&model->m};
-        auto it = pl.graphs.find(key);
-        if (it == pl.graphs.end() && pl.seen.count(key) && !pl.no_graph.count(key)) {
-            // a capture that cannot start or does not end cleanly (seen with four batches in flight: hipStreamBeginCapture refuses
-            // while the thread's other streams are busy) leaves this shape on the eager path for good -- nothing was launched
-            hipGraph_t graph = nullptr;
-            bool ok = hipStreamBeginCapture(main.stream(), hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, nullptr);
-                const hipError_t e = hipStreamEndCapture(main.stream(), &graph);
-                ok = rc == 0 && e == hipSuccess && graph;
-            }
-            hipGraphExec_t exec = nullptr;
-            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void)hipGraphDestroy(graph);
-            if (ok) it = pl.graphs.emplace(key, exec).first;
-            else { (void)hipGetLastError(); pl.no_graph.insert(key); }
-        }
-        if (it != pl.graphs.end()) {
-            jlm_check((int)hipGraphLaunch(it->second, main.stream()), "hipGraphLaunch");
-            return 0;
-        }
-        pl.seen.insert(key);
-    }
+    // (Rounds 2-4 could replay the launch sequence as a captured hipGraph, JLM_GRAPH=1: correct and slower -- 3.52-3.58 vs 2.58-2.71 ms
+    //  per 256-sentence chunk, hipGraphLaunch of the 130-node two-branch graph cost more than the launches -- removed in round 5.)
     const int rc = jlm_decode_frames(&model->m, &pl.p, &pl.lat, &pl.st, main.stream(), side_s, ev);
     if (rc == -2) return -2;
     jlm_check(rc, "jlm_decode_frames");
+    return 0;
+}
+
+// Round 5: one batch, one op -- everything DecodeEngine._enqueue did between the staging block and the `done` event as a
+// dozen torch calls (0.3-0.6 ms of interpreter time per 256-sentence chunk, tools/probes/host_profile2.py): the upload of the
+// batch's lattice (head of the plan's page-locked staging block; the four node arrays straight from the lattice's own
+// page-locked block), the counters' reset, the frame loop, and the read-back of the n-best traces into page-locked host
+// buffers.  All asynchronous on the current stream; torch has released the interpreter lock around the whole call, so a
+// second Python thread (the collector building the previous batch's strings) runs beside it.
+//   host_ints [>= head_end] int32, page-locked: the staging block; blk (optional) int32, page-locked: the lattice's block, of
+//   which blk_n[i] ints at blk_src[i] go to dev_ints + blk_dst[i]; without blk the whole staging block is copied.
+//   h_nodes / h_len / h_score (/ h_nlive with a timed decode): page-locked destinations of out_nodes / out_len / out_score / n_live.
+int64_t decode_batch(const c10::intrusive_ptr<JlmModel> &model, const c10::intrusive_ptr<JlmPlan> &plan, const Tensor &host_ints,
+                     int64_t head_end, const OptTensor &blk, std::vector<int64_t> blk_src, std::vector<int64_t> blk_dst,
+                     std::vector<int64_t> blk_n, const Tensor &h_nodes, const Tensor &h_len, const Tensor &h_score, const OptTensor &h_nlive,
+                     int64_t n_frames, int64_t vs_max, int64_t di_max, int64_t dd_max, bool use_side, bool timed, int64_t lse_cu_share_pct) {
+    JlmPlan &pl = *plan;
+    const Tensor *dev_ints = find(pl.tensors, "ints");
+    const Tensor *cnt = find(pl.tensors, "cnt"), *n_live = find(pl.tensors, "n_live");
+    const Tensor *o_nodes = find(pl.tensors, "out_nodes"), *o_len = find(pl.tensors, "out_len"), *o_score = find(pl.tensors, "out_score");
+    auto host_ok = [](const Tensor &t, at::ScalarType ty) { return t.defined() && !t.is_cuda() && t.is_contiguous() && t.scalar_type() == ty; };
+    TORCH_CHECK(host_ok(host_ints, at::kInt) && host_ints.numel() <= dev_ints->numel() && head_end >= 0 && head_end <= host_ints.numel(),
+                "jlm.decode_batch: the staging block must be a contiguous int32 host tensor no larger than the plan's");
+    TORCH_CHECK(host_ok(h_nodes, at::kInt) && h_nodes.numel() >= o_nodes->numel() && host_ok(h_len, at::kInt) && h_len.numel() >= o_len->numel() &&
+                    host_ok(h_score, at::kDouble) && h_score.numel() >= o_score->numel(),
+                "jlm.decode_batch: read-back buffers");
+    const bool has_blk = blk.has_value() && blk->defined();
+    TORCH_CHECK(!has_blk || (host_ok(*blk, at::kInt) && blk_src.size() == blk_dst.size() && blk_src.size() == blk_n.size()), "jlm.decode_batch: lattice block");
+    const c10::hip::HIPGuard device_guard(pl.device);
+    hipStream_t st = c10::hip::getCurrentHIPStream(pl.device).stream();
+    int *d = reinterpret_cast<int *>(dev_ints->data_ptr());
+    const int *h = reinterpret_cast<const int *>(host_ints.data_ptr());
+    if (!has_blk) {
+        jlm_check((int)hipMemcpyAsync(d, h, (size_t)host_ints.numel() * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync (staging block)");
+    } else {
+        if (head_end) jlm_check((int)hipMemcpyAsync(d, h, (size_t)head_end * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync (staging head)");
+        const int *b = reinterpret_cast<const int *>(blk->data_ptr());
+        for (size_t i = 0; i < blk_n.size(); ++i) {
+            if (blk_n[i] <= 0) continue;
+            TORCH_CHECK(blk_src[i] >= 0 && blk_src[i] + blk_n[i] <= blk->numel() && blk_dst[i] >= 0 && blk_dst[i] + blk_n[i] <= dev_ints->numel(),
+                        "jlm.decode_batch: a lattice array outside its block or the plan");
+            jlm_check((int)hipMemcpyAsync(d + blk_dst[i], b + blk_src[i], (size_t)blk_n[i] * 4, hipMemcpyHostToDevice, st), "hipMemcpyAsync (lattice array)");
+        }
+    }
+    jlm_check((int)hipMemsetAsync(cnt->data_ptr(), 0, (size_t)cnt->numel() * 4, st), "hipMemsetAsync (cnt)");
+    jlm_check((int)hipMemsetAsync(n_live->data_ptr(), 0, (size_t)n_live->numel() * 4, st), "hipMemsetAsync (n_live)");
+    const int64_t rc = decode_frames(model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct);
+    if (rc != 0) return rc;
+    jlm_check((int)hipMemcpyAsync(h_nodes.data_ptr(), o_nodes->data_ptr(), (size_t)o_nodes->numel() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (traces)");
+    jlm_check((int)hipMemcpyAsync(h_len.data_ptr(), o_len->data_ptr(), (size_t)o_len->numel() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (trace lengths)");
+    jlm_check((int)hipMemcpyAsync(h_score.data_ptr(), o_score->data_ptr(), (size_t)o_score->numel() * 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (scores)");
+    if (h_nlive.has_value() && h_nlive->defined()) {
+        TORCH_CHECK(host_ok(*h_nlive, at::kInt) && h_nlive->numel() >= n_live->numel(), "jlm.decode_batch: live-row read-back buffer");
+        jlm_check((int)hipMemcpyAsync(h_nlive->data_ptr(), n_live->data_ptr(), (size_t)n_live->numel() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (live rows)");
+    }
     return 0;
 }
 
@@ -432,6 +452,9 @@ TORCH_LIBRARY(jlm, m) {
     m.class_<JlmPlan>("Plan").def(torch::init<TDict, IDict>());
     m.def("decode_frames(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, int n_frames, int vs_max, "
           "int di_max, int dd_max, bool use_side, bool timed, int lse_cu_share_pct) -> int", decode_frames);
+    m.def("decode_batch(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, Tensor host_ints, int head_end, "
+          "Tensor? blk, int[] blk_src, int[] blk_dst, int[] blk_n, Tensor(a!) h_nodes, Tensor(b!) h_len, Tensor(c!) h_score, Tensor? h_nlive, "
+          "int n_frames, int vs_max, int di_max, int dd_max, bool use_side, bool timed, int lse_cu_share_pct) -> int", decode_batch);
     m.def("frame_times(__torch__.torch.classes.jlm.Plan plan) -> Tensor", frame_times);
     m.def("lstm_step(Tensor h_in, Tensor c_in, int ld_state, Tensor(a!) h_out, Tensor(b!) c_out, Tensor? rows, Tensor prev, Tensor word, "
           "Tensor emb, int ld_emb, Tensor wt, Tensor bias, int kpad, int H, int E, int n_rows_max, Tensor? n_dev) -> ()", lstm_step);

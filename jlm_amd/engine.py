@@ -342,6 +342,30 @@ class DecodeEngine:
             if perm:
                 p._set("di_wwords", dyn_lists[4])
                 p._set("sg_wword", dyn_lists[5])
+        be = ops.backend()
+        from . import hw_queues_ok
+        side = self.use_side and self.device.type == "cuda" and (
+            self.n_streams < 2 or (self.n_streams == 2 and hw_queues_ok()) or os.environ.get("JLM_SIDE") == "1")
+        share = self.lse_share_pct if ((not timing or timing == "inflight") and self.pipelined and self.lse_share_pct < 100) else 0
+        if self.device.type == "cuda" and hasattr(be, "decode_batch"):
+            # Round 5: upload, counters, frame loop and read-back of the batch as ONE op (csrc/jlm_torch_ops.cpp decode_batch) -- the
+            # dozen torch calls below cost the calling thread 0.3-0.6 ms of interpreter time per 256-sentence chunk
+            # (profiles/r05_i_host_profile.txt), the op runs without the interpreter lock
+            src, dst, cnt = [], [], []
+            if blk is not None:
+                for name in p.BIG_ARRAYS:
+                    n = int(getattr(lat, name).shape[0])
+                    assert n <= p.isize[name], (name, n, p.isize[name])
+                    src.append(int(lat.block_off[name])); dst.append(int(p.ioff[name])); cnt.append(n)
+            rc = be.decode_batch(self.m.decode_model(), p.obj, p.host_ints, int(p.head_end) if blk is not None else 0,
+                                 blk.tensor if blk is not None else None, src, dst, cnt, p.h_nodes, p.h_len, p.h_score,
+                                 p.h_nlive if (timing and self.keep_n_live) else None, lat.n_frames, max_words["vs"], max_words["di"],
+                                 max_words["dd"], bool(side), bool(timing), int(share))
+            if rc != 0:
+                raise _lib.JlmHipError("jlm.decode_batch: the model is outside the shapes the frame loop covers (code %d)" % rc)
+            done = torch.cuda.Event(blocking=self.blocking_sync)
+            done.record()
+            return done
         if blk is None:
             p.dev_ints.copy_(p.host_ints, non_blocking=True)
         else:
@@ -354,19 +378,15 @@ class DecodeEngine:
                     p.dev_ints[d:d + n].copy_(blk.tensor[o:o + n], non_blocking=True)
         p.cnt.zero_()
         p.n_live.zero_()
-        # side stream for the edge logits: with one stream, and with two when the hardware queues are there (ROCm's default of
-        # four is not enough: jlm_amd/__init__.py); with three or more streams (the default is four) they run on the batch's own stream
-        from . import hw_queues_ok
-        side = self.use_side and self.device.type == "cuda" and (
-            self.n_streams < 2 or (self.n_streams == 2 and hw_queues_ok()) or os.environ.get("JLM_SIDE") == "1")
+        # (side stream for the edge logits -- `side` above: with one stream, and with two when the hardware queues are there (ROCm's default
+        #  of four is not enough: jlm_amd/__init__.py); with three or more streams (the default is four) they run on the batch's own stream)
         # the whole launch sequence of the batch: ONE op, no host synchronisation inside (csrc/jlm_decode.hip)
         # another batch in flight: this batch's vocabulary kernel takes LSE_SHARE_PCT of the CUs and the other batch's
         # latency-bound kernels the rest, side by side (include/jlm_hip.h, jlm_decode_plan.lse_cu_share_pct)
         # The share is a property of the CALL (a pipelined sequence of batches: decode_batch with more than one chunk sets
         # `pipelined`), not of what happens to be in flight at this moment: the share moves the column cuts of the vocabulary
         # kernel, i.e. the grouping of its f32 partial sums, and a sentence's score must not depend on its chunk's position.
-        share = self.lse_share_pct if ((not timing or timing == "inflight") and self.pipelined and self.lse_share_pct < 100) else 0
-        rc = ops.backend().decode_frames(self.m.decode_model(), p.obj, lat.n_frames, max_words["vs"], max_words["di"],
+        rc = be.decode_frames(self.m.decode_model(), p.obj, lat.n_frames, max_words["vs"], max_words["di"],
                                          max_words["dd"], bool(side), bool(timing), int(share))
         if rc != 0:
             raise _lib.JlmHipError("jlm.decode_frames: the model is outside the shapes the frame loop covers (code %d)" % rc)

@@ -54,6 +54,13 @@ class Ops:
         return r
 
 
+    def decode_batch(self, *a):
+        t = time.perf_counter()
+        r = be.decode_batch(*a)
+        acc["submit/decode_batch op"] = acc.get("submit/decode_batch op", 0.0) + time.perf_counter() - t
+        return r
+
+
 ops._backend = Ops()
 import jlm_amd.lattice as LT
 for nm in ("static_vocab", "dynamic_vocab"):
