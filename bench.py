@@ -359,27 +359,30 @@ def main():
         elif args.decoder == "dynamic":
             ekind, ekw = "dynamic", dict(dyn_lists=lat.dynamic_vocab()[:4])
 
-        def run_device_steps(n, timing=False, sink=None):
+        def run_device_steps(n, timing=False, sink=None, on=None):
             """n steps with the lattice resident; the host read-out of step i overlaps the GPU work of step i+1.
-            timing="inflight": HIP events around the kernel groups on each batch's own stream (sink collects them)."""
+            timing="inflight": HIP events around the kernel groups on each batch's own stream (sink collects them).
+            on = (decoder, lattice, engine kind, engine kwargs, batch, beam): another decoder's loop (the legs)."""
+            dec_, lat_, ekind_, ekw_, batch_, beam_ = on or (dec, lat, ekind, ekw, args.batch, args.beam)
+            eng_ = dec_._engine
             inflight = deque()                 # pipeline_depth steps in flight, as Decoder.decode_batch keeps its chunks
-            eng.pipelined = True
+            eng_.pipelined = True
 
             def fin(t):
-                eng.collect(t)
+                eng_.collect(t)
                 if sink is not None:
-                    sink["n_live"].append(eng.last_n_live)
+                    sink["n_live"].append(eng_.last_n_live)
                     for k in ("gate_gemm", "vocab_lse"):
-                        sink[k].extend(eng.last_kernel_ms[k])
+                        sink[k].extend(eng_.last_kernel_ms[k])
             try:
                 for _ in range(n):
-                    inflight.append(eng.submit(lat, ekind, topN=10, timing=timing, **ekw))
-                    if len(inflight) > dec.depth_for(args.batch, args.beam):
+                    inflight.append(eng_.submit(lat_, ekind_, topN=10, timing=timing, **ekw_))
+                    if len(inflight) > dec_.depth_for(batch_, beam_):
                         fin(inflight.popleft())
                 while inflight:
                     fin(inflight.popleft())
             finally:
-                eng.pipelined = False
+                eng_.pipelined = False
 
         # untimed: the requested warm-up steps (plans for every stream and pipeline slot exist afterwards), then two settle calls
         # of the timed call's own size: a fresh process runs its first K-batch call 20-25 % slower than the third
@@ -408,13 +411,25 @@ def main():
                                             "12 - warmup, 4) = %d steps each, repeated until two successive calls agree within 3 %% "
                                             "(first-touch of the heap, the page-locked blocks and the plans a call of that size needs)"
                                             % (n_settle, settle))
-        barrier()
-        c0 = time.process_time()
-        t0 = time.perf_counter()
-        out = dec.decode_batch(sents * args.steps, beam_width=args.beam, **dkw)      # K steps = K pipelined 256-sentence batches
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        cpu_s = time.process_time() - c0
+        # The timed region: EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks -- taken three times in a
+        # row, the MEDIAN reported (`ms_per_step_repeats` lists all three): a 20-step region is 40 ms, and single regions on one
+        # box spread by 8 %, more than most changes the line is meant to show.
+        dts, cpus = [], []
+        for _rep in range(3):
+            barrier()
+            c0 = time.process_time()
+            t0 = time.perf_counter()
+            out = dec.decode_batch(sents * args.steps, beam_width=args.beam, **dkw)      # K steps = K pipelined 256-sentence batches
+            barrier()
+            dts.append(max_over_ranks(time.perf_counter() - t0))
+            cpus.append(time.process_time() - c0)
+            assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
+            if _rep < 2:
+                del out
+        _mid = sorted(range(3), key=lambda i_: dts[i_])[1]
+        dt, cpu_s = dts[_mid], cpus[_mid]
+        line_extra["ms_per_step_repeats"] = [round(x / args.steps * 1e3, 3) for x in dts]
+        line_extra["ms_per_step_note"] = "three consecutive timed regions of `steps` steps each; `value` / `ms_per_step` are the median one"
         line_extra["host_cpu_ms_per_step"] = round(cpu_s / args.steps * 1e3, 3)
         line_extra["host_cpu_note"] = ("process CPU time (all threads of this rank: calling thread, lattice workers, HIP runtime) per "
                                        "step of the timed region; %.2f CPUs busy on average, %d usable" % (cpu_s / dt, jlm_amd.usable_cpus()))
@@ -445,9 +460,8 @@ def main():
             # consistency of the two clocks: the dominant kernel's solo launches of one step cannot take longer than the step
             per_step = roofline["launches"] / float(min(args.steps, 20))
             roofline["solo_launch_ms_per_step"] = round(roofline["avg_launch_ms"] * per_step, 4)
-            assert roofline["solo_launch_ms_per_step"] <= line_extra["device_resident_ms_per_step"], (
-                "dominant kernel: %.3f ms of solo launches per step against a %.3f ms step" % (
-                    roofline["solo_launch_ms_per_step"], line_extra["device_resident_ms_per_step"]))
+            # (two different runs -- serialised event timing vs the pipelined loop: recorded, never raised)
+            roofline["clock_consistency_ok"] = bool(roofline["solo_launch_ms_per_step"] <= line_extra["device_resident_ms_per_step"])
         if roofline and args.decoder == "static" and roofline.get("lse_form") in ("mixed", "hybrid"):
             # the same launches on SPLIT rows (three f16 passes; what a model the load-time gates keep off the int8 planes runs)
             os.environ["JLM_LSE_MIXED"] = "0"
@@ -532,9 +546,16 @@ def main():
 
         # ---------------------------------------------- short legs: BASELINE configs[2] and configs[3] (one GPU, this process)
         if not args.no_legs and args.decoder == "static" and world == 1:
-            def run_leg(fixture, kind, batch, beam, steps, kw, what):
-                root_, _cfg, alphabet_, dec_ = make_decoder(fixture, kind)
-                sents_ = synth.make_sentences(batch, args.length, seed=3131, alphabet=alphabet_)
+            def run_leg(fixture, kind, batch, beam, steps, kw, what, length=None, use=None, kernels=True):
+                """one more workload, strings -> strings, settled like the headline; `use` = (root, alphabet, decoder): a decoder that
+                exists already (the length legs run on the headline's)"""
+                length = length or args.length
+                if use is None:
+                    root_, _cfg, alphabet_, dec_ = make_decoder(fixture, kind)
+                else:
+                    root_, alphabet_, dec_ = use
+                    jconfig.set_root(root_)
+                sents_ = synth.make_sentences(batch, length, seed=3131, alphabet=alphabet_)
                 dec_.max_batch = batch
                 n_settle_, prev_ = 0, None                       # untimed: calls of the timed size until two agree within 3 % (2-5)
                 while n_settle_ < 5:
@@ -555,13 +576,24 @@ def main():
                 del out_
                 lat_ = BatchLattice(dec_._builder, sents_, beam)
                 ekind_, ekw_ = ("dynamic", dict(dyn_lists=lat_.dynamic_vocab()[:4])) if kind == "dynamic" else ("static", {})
-                rf, gt = measure_kernels(dec_, lat_, ekind_, ekw_, 2, full_vocab=(kind == "static"), fixture=fixture, decoder_name=kind)
+                # the same steps with the lattice resident (as the headline's device_resident_*)
+                on_ = (dec_, lat_, ekind_, ekw_, batch, beam)
+                run_device_steps(min(steps, 4), on=on_)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                run_device_steps(steps, on=on_)
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - tb
+                rf, gt = measure_kernels(dec_, lat_, ekind_, ekw_, 2, full_vocab=(kind == "static"), fixture=fixture, decoder_name=kind) if kernels else (None, None)
                 leg = {"workload": what, "value": round(sum(len(x) for x in sents_) * steps / dta, 1), "unit": "chars/s", "n_gpus": 1,
                        "steps": steps, "untimed_steps": n_settle_ * steps, "ms_per_step": round(dta / steps * 1e3, 3),
+                       "device_resident_ms_per_step": round(dtb / steps * 1e3, 3),
                        "timed": "strings -> strings, one decode_batch call of `steps` pipelined batches"}
                 if rf:
                     leg["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "frac", "achieved", "peak", "unit", "frac_of_dense_f16",
                                                                      "avg_launch_ms", "note") if rf.get(k) is not None}
+                    if rf.get("lse_form"):
+                        leg["dominant_kernel"]["lse_form"] = rf["lse_form"]
                 if gt:
                     leg["gate_gemm"] = {k: gt[k] for k in ("mfma_util_pct", "avg_launch_ms")}
                 del dec_, lat_
@@ -570,10 +602,41 @@ def main():
             line_extra["config3"] = run_leg(
                 "big-tied", "static", 1024, 20, 3, {},
                 "BASELINE configs[2]: tied softmax V=100k (h=512, e=256), beam=20, batch=1024 sentences x %d kana" % args.length)
-            line_extra["config4"] = run_leg(
-                "mid-tied", "dynamic", 256, args.beam, 10, dict(vocab_select=True),
-                "BASELINE configs[3]: DynamicDecoder (decoder_dynamic.py incremental vocabulary selection), tied softmax V=50k, "
-                "beam=%d, batch=256 sentences x %d kana" % (args.beam, args.length))
+            # BASELINE configs[3] in a process of its own (this very script with --decoder dynamic): as the fourth decoder of this
+            # process the incremental decoder -- the one whose host side is heaviest -- measured 1.71 ms per step where its own
+            # process measures 1.33-1.36 (profiles/r05_l_switch_interval.txt); the leg reports what a service running it gets
+            import subprocess
+            what4 = ("BASELINE configs[3]: DynamicDecoder (decoder_dynamic.py incremental vocabulary selection), tied softmax V=50k, "
+                     "beam=%d, batch=256 sentences x %d kana" % (args.beam, args.length))
+            cmd4 = [sys.executable, os.path.abspath(__file__), "--fixture", "mid-tied", "--decoder", "dynamic", "--steps", "40", "--warmup", "3",
+                    "--beam", str(args.beam), "--length", str(args.length), "--no-cpu-baseline", "--no-config5", "--no-legs"]
+            try:
+                pr = subprocess.run(cmd4, capture_output=True, text=True, timeout=600)
+                d4 = json.loads(pr.stdout.strip().splitlines()[-1])
+                line_extra["config4"] = {
+                    "workload": what4, "value": d4["value"], "unit": "chars/s", "n_gpus": 1, "steps": d4["steps"],
+                    "untimed_steps": d4.get("untimed_steps"), "ms_per_step": d4["ms_per_step"], "ms_per_step_repeats": d4.get("ms_per_step_repeats"),
+                    "device_resident_ms_per_step": d4.get("device_resident_ms_per_step"),
+                    "timed": "strings -> strings; `python bench.py --fixture mid-tied --decoder dynamic --steps 40 --warmup 3 --no-legs` in a process of its own",
+                    "dominant_kernel": {k: (d4.get("roofline") or {}).get(k) for k in ("kernel", "avg_launch_ms", "note")},
+                    "gate_gemm": {k: (d4.get("gate_gemm") or {}).get(k) for k in ("mfma_util_pct", "avg_launch_ms")}}
+            except Exception as e:          # (a leg must not take the line with it)
+                line_extra["config4"] = {"workload": what4, "error": "%s: %s" % (type(e).__name__, e)}
+
+            # the stated sentence lengths ("also report L = 10, 40") on the headline's own model and decoder
+            if args.fixture == "mid-vtable" and args.length == 20:
+                for L_ in (10, 40):
+                    line_extra["length%d" % L_] = run_leg(
+                        args.fixture, "static", args.batch, args.beam, 20, {},
+                        "BASELINE configs[1] at %d kana per sentence (batch=%d, beam=%d, D-softmax* V=50k)" % (L_, args.batch, args.beam),
+                        length=L_, use=(root, alphabet, dec), kernels=False)
+                # ... and what a TRAINED model gets: the same architecture with output embeddings x 20 (logits of +-20) and a unigram-like
+                # bias (synth.shape_weights): its normaliser runs on split rows (DeviceModel._calibrate_mixed: the int8 cross terms
+                # would cost 3e-6 rms per frame there), three f16 passes instead of one f16 + two int8
+                line_extra["peaked20"] = run_leg(
+                    "peaked20-vtable", "static", args.batch, args.beam, 20, {},
+                    "BASELINE configs[1] on trained-model-like weights (fixture peaked20-vtable: logits of +-20, unigram-like bias), "
+                    "batch=%d x %d kana, beam=%d" % (args.batch, args.length, args.beam))
 
     if rank != 0:
         if dist is not None:
@@ -616,7 +679,8 @@ def main():
         "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate%s: f32-grade error, tests/test_gpu_kernels.py; "
-                  "scores f64)" % ("; the vocabulary projection as f16 hi.hi + two int8 cross-term passes" if getattr(m, "mixed_idx", None) else "")
+                  "scores f64; parity bars: step logits <= 1e-4 relative, 1-best identical, path scores within 1e-6 per frame + 2e-6 of the "
+                  "reference's -- tests/test_gpu_decode.py score_atol)" % ("; the vocabulary projection as f16 hi.hi + two int8 cross-term passes" if getattr(m, "mixed_idx", None) else "")
                   if getattr(m, "split_lstm", False) else "f32"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "fixture": args.fixture,
