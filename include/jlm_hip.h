@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 8
+#define JLM_ABI_VERSION 9
 #define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
@@ -141,25 +141,6 @@ int jlm_pack_split_f16(const float *src, int rows, int k, int ld, float scale,
  * expanded from them where the kernels need it. */
 int jlm_dequant_u8(const uint8_t *code, int rows, int k, int ld_code, const float *codebook, int n_codes,
                    float *dst, int ld_dst, void *stream);
-
-/* jlm_lstm_step on split rows (K1+K2+K3+K9): h_in / h_out are split rows of the
- * state scaled by h_scale (a power of two <= 2^14; |h| < 1), emb the split rows
- * of the input embedding, wt the split rows of the packed gate matrix whose
- * first H columns are scaled by S / h_scale and the rest by S / (embedding
- * scale), descale = 1 / S.  c stays f32.  H % 32 == 0, E % 16 == 0, all strides
- * multiples of 16.  Same row semantics as jlm_lstm_step (decoder/model.py:105-131).
- *
- * xgate != NULL: the input side is a table lookup instead of a contraction.
- * xgate[w][n] = sum_e emb[w][e] * W_x[n][e] + bias[n]  (f32 [V, 4H], packed column
- * order) is added in the epilogue for w = word[g]; the GEMM then runs over the
- * state only (emb / bias / E are ignored, wt needs its first H columns only).
- * model.py:125-131 computes x.IM_g + h.HM_g + b_g; the table is x.IM_g + b_g for
- * every vocabulary word, formed once at load time. */
-int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
-                        const int *rows, const int *prev, const int *word,
-                        const void *emb, int ld_emb, const void *wt, const float *bias,
-                        int kpad, int H, int E, float descale, float h_scale, const float *xgate,
-                        int n_rows_max, const int *n_dev, void *stream);
 
 /* ABI 4: the decode's LSTM step (K1+K2+K3+K9; decoder/model.py:125-139 with the state gather / scatter of
  * Decoder._batch_predict, decoder/decoder.py:206-218), table form, one 160-row x 128-gate-column tile per CU.
@@ -421,9 +402,9 @@ typedef struct {
     int split_lstm;                 /* state rows and gate matrix are split rows */
     /* jlm_lstm_step operands (split_lstm == 0) */
     const float *emb; int ld_emb; const float *wt; const float *gate_bias; int kpad, E;
-    /* jlm_lstm_step_split operands (split_lstm == 1; input side = xgate table) */
-    const void *wt_split; int kpad_split; float gate_descale, h_scale; const float *xgate;
-    /* jlm_lstm_step_xg operands (ABI 4; used instead of the line above when wt8 != NULL) */
+    /* jlm_lstm_step_xg operands (split_lstm == 1; the input side is the per-word table xgate8).  ABI 9: the round-1 split step
+     * (jlm_lstm_step_split: wt_split / kpad_split / xgate) is gone */
+    float gate_descale, h_scale;
     const void *wt8; const float *xgate8;
     /* untied model on split rows (ABI 4; untied_split != NULL): the vocabulary matrix UM^T [V, H] as split rows scaled by
      * 2^eB, untied_descale = 2^-(14 + eB); the state rows plan.h are split rows then, plan.T their plain f32 copy */

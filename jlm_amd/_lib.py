@@ -40,8 +40,8 @@ class DecodeModel(Structure):
     _fields_ = [("segs", POINTER(Segment)), ("n_segs", c_int), ("b2", c_void_p), ("H", c_int), ("ldt", c_int),
                 ("untied", c_int), ("self_norm", c_int), ("split_lstm", c_int),
                 ("emb", c_void_p), ("ld_emb", c_int), ("wt", c_void_p), ("gate_bias", c_void_p), ("kpad", c_int), ("E", c_int),
-                ("wt_split", c_void_p), ("kpad_split", c_int), ("gate_descale", c_float), ("h_scale", c_float),
-                ("xgate", c_void_p), ("wt8", c_void_p), ("xgate8", c_void_p), ("untied_split", c_void_p), ("untied_descale", c_float),
+                ("gate_descale", c_float), ("h_scale", c_float),
+                ("wt8", c_void_p), ("xgate8", c_void_p), ("untied_split", c_void_p), ("untied_descale", c_float),
                 ("pmt", c_void_p), ("pmt_split", c_void_p), ("n_t", c_int), ("t_descale", c_float),
                 ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
                 ("split_bias_col", POINTER(c_int)),
@@ -72,8 +72,6 @@ _SIGS = {
     "jlm_lse_combine": ([P, c_int, c_int, P, P, c_int, P, P], c_int),
     "jlm_vocab_lse_stationary": ([POINTER(Segment), c_int, P, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_pack_split_f16": ([P, c_int, c_int, c_int, c_float, P, c_int, P], c_int),
-    "jlm_lstm_step_split": ([P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_float, c_float, P, c_int, P,
-                             P], c_int),
     "jlm_lstm_step_xg": ([P, P, c_int, P, P, P, P, P, P, P, c_int, c_float, c_float, P, c_int, P, P], c_int),
     "jlm_vocab_lse_partials_split": ([P, c_int, c_int, c_int, P, c_int, P, P, c_float, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_gemm_nt_split": ([P, c_int, P, P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, P, P], c_int),
@@ -131,7 +129,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 8:
+        if l.jlm_abi_version() != 9:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

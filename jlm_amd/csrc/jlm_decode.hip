@@ -121,8 +121,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
             JLM_TRY(jlm_lstm_step_xg(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, m->wt8, m->xgate8, m->H,
                                      m->gate_descale, m->h_scale, m->untied ? p->T : nullptr, rmax, ndev, stream));
         else if (m->split_lstm)
-            JLM_TRY(jlm_lstm_step_split(p->h, p->c, m->H, p->h, p->c, rows, st.bp, st.word, nullptr, 0, m->wt_split, nullptr,
-                                        m->kpad_split, m->H, 0, m->gate_descale, m->h_scale, m->xgate, rmax, ndev, stream));
+            return -2;              // (a split-row model always carries wt8 / xgate8: DeviceModel builds them together)
         else
             JLM_TRY(jlm_lstm_step((const float *)p->h, p->c, m->H, (float *)p->h, p->c, rows, st.bp, st.word, m->emb,
                                   m->ld_emb, m->wt, m->gate_bias, m->kpad, m->H, m->E, rmax, ndev, stream));

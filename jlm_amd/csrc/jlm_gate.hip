@@ -1107,8 +1107,10 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     // refill-in-place pipeline (round 3); 0 the round-2 loop (every H).  Default by the launch's row bound (tools/gpu_gate_pu.sh,
     // tools/gpu_gate_ws.sh; us per launch for 1 / 3 / 2 on one box: 2 560 rows 23.2 / 24.1 / 26.4, 5 120: 42.1 / 40.5 / 43.1,
     // 10 240: 82.7 / 75.0 / 80.2, 20 480: 174 / 160 / 156): one tile per CU -> 1; two to a few tiles per CU -> 3; more -> 2
+    // (JLM_GATE_V = 1 / 2 / 3 forces one of the three H = 512 forms for A/B; the round-2 loop serves the other H only -- forcing it
+    //  at H = 512, JLM_GATE_V=0, left with ABI 9)
     static const int variant_env = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : -1;
-    const int variant = variant_env >= 0 ? variant_env : (n_rows_max >= 16384 ? 2 : n_rows_max >= 4096 ? 3 : 1);
+    const int variant = variant_env >= 1 ? variant_env : (n_rows_max >= 16384 ? 2 : n_rows_max >= 4096 ? 3 : 1);
     static const int ws_l = getenv("JLM_GATE_WS_L") ? atoi(getenv("JLM_GATE_WS_L")) : 3;
     if (variant == 3 && H == 512 && rows && (a.tiles_n & 7) == 0) {
         // the persistent form of the one-tile kernel (gate_pu_kernel): tiles_n column tiles x Q row-tile sequences

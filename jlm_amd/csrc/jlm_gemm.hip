@@ -789,38 +789,8 @@ extern "C" int jlm_gemm_nt(const float *Ap, int lda, const int *a_rows, const fl
     return launch_gemm2<Cfg128>(A, B, K, epi, 0, (hipStream_t)stream);
 }
 
-// Split-f16 forms of the two entry points above (operands = split rows, strides in 4-byte units).
-extern "C" int jlm_lstm_step_split(const void *h_in, const float *c_in, int ld_state, void *h_out, float *c_out,
-                                   const int *rows, const int *prev, const int *word, const void *emb, int ld_emb,
-                                   const void *wt, const float *bias, int kpad, int H, int E, float descale,
-                                   float h_scale, const float *xgate, int n_rows_max, const int *n_dev, void *stream) {
-    if (H % 32 != 0 || E % 16 != 0 || kpad % BK != 0 || kpad < H + E || ld_state % 16 || ld_emb % 16) return -1;
-    GateRows A;
-    A.h = reinterpret_cast<const float *>(h_in); A.ldh = ld_state; A.rows = rows; A.prev = prev; A.word = word;
-    A.emb = reinterpret_cast<const float *>(emb); A.lde = ld_emb; A.H = H; A.nrows = n_rows_max; A.ndev = n_dev;
-    PlainRows B;
-    B.base = reinterpret_cast<const float *>(wt); B.map = nullptr; B.ld = kpad; B.nrows = 4 * H; B.ndev = nullptr;
-    EpiGate epi;
-    epi.c_in = c_in; epi.h_out = nullptr; epi.c_out = c_out; epi.ld = ld_state;
-    epi.rows = rows; epi.prev = prev; epi.bias = bias;
-    epi.scale = descale; epi.h_split = reinterpret_cast<float *>(h_out); epi.h_scale = h_scale;
-    if (xgate) { epi.xgate = xgate; epi.word = word; epi.ld_gate = H; }
-    const int Kc = xgate ? H : H + E;      // with the table the contraction is over the state only
-    static int tile = -1;
-    if (tile < 0) { const char *e = getenv("JLM_GATE_TILE"); tile = e ? atoi(e) : 128; }
-    const int tiles_n = 4 * H / (tile == 256 ? 128 : 64);
-    const int xcd = (tiles_n % 8 == 0) ? 2 : 0;
-    // 160: one 160 x 128 tile per CU (16 x 16 = 256 workgroups at 2 560 rows, H = 512), four waves each owning a
-    // 32-column strip, a 4-stage LDS ring -- every operand byte crosses L2 -> LDS 16 times instead of 20 / 32
-    if (tile == 160 && (4 * H) % 128 == 0) {
-        const int xc = ((4 * H / 128) % 8 == 0) ? 2 : 0;
-        return launch_gemm_split3<TileCfg<1, 4, 5, 1>, GateRows, PlainRows, EpiGate, 4>(A, B, Kc, epi, xc, (hipStream_t)stream);
-    }
-    if (tile == 256 && (4 * H) % 128 == 0) return launch_gemm_split<Cfg128>(A, B, Kc, epi, xcd, (hipStream_t)stream);
-    if (tile == 128) return launch_gemm_split<TileCfg<2, 2, 2, 1>>(A, B, Kc, epi, xcd, (hipStream_t)stream);
-    return launch_gemm_split<Cfg64>(A, B, Kc, epi, xcd, (hipStream_t)stream);
-}
-
+// Split-f16 form of jlm_gemm_nt (operands = split rows, strides in 4-byte units).  (The round-1 split LSTM step that lived here,
+// jlm_lstm_step_split, left with ABI 9: the decode has used jlm_lstm_step_xg since round 2 -- HISTORY.md.)
 extern "C" int jlm_gemm_nt_split(const void *Ap, int lda, const int *a_rows, const void *Bp, int ldb, const int *b_rows,
                                  float *C, int ldc, const int *c_rows, const float *bias, float descale, int M, int N,
                                  int K, const int *m_dev, void *stream) {

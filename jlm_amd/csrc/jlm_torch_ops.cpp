@@ -132,8 +132,7 @@ struct JlmModel : torch::CustomClassHolder {
         m.emb = tptr<const float>(tensors, "emb"); m.ld_emb = (int)geti(i, "ld_emb");
         m.wt = tptr<const float>(tensors, "wt"); m.gate_bias = tptr<const float>(tensors, "gate_bias");
         m.kpad = (int)geti(i, "kpad"); m.E = (int)geti(i, "E");
-        m.wt_split = nullptr; m.kpad_split = (int)geti(i, "kpad_split");
-        m.gate_descale = (float)getf(f, "gate_descale"); m.h_scale = (float)getf(f, "h_scale"); m.xgate = nullptr;
+        m.gate_descale = (float)getf(f, "gate_descale"); m.h_scale = (float)getf(f, "h_scale");
         m.wt8 = tptr<const void>(tensors, "wt8"); m.xgate8 = tptr<const float>(tensors, "xgate8");
         m.untied_split = tptr<const void>(tensors, "untied_split"); m.untied_descale = (float)getf(f, "untied_descale");
         m.pmt = tptr<const float>(tensors, "pmt"); m.pmt_split = tptr<const void>(tensors, "pmt_split");
@@ -231,7 +230,7 @@ struct JlmPlan : torch::CustomClassHolder {
 // maps streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise (jlm_amd/__init__.py)
 std::map<std::pair<int, hipStream_t>, c10::hip::HIPStream> g_side;
 // torch releases the interpreter lock around custom ops: two Python threads may be inside decode_frames at once (two
-// decoders, or JLM_COLLECTOR=1).  The side-stream table, a plan's event / graph tables and the launchers' one-time kernel
+// decoders).  The side-stream table, a plan's event table and the launchers' one-time kernel
 // attributes (function-local statics in libjlm_hip.so) are all touched in here: one lock around the enqueue.  It is held
 // for the ~0.5 ms the launches take; the GPU work itself is asynchronous.
 std::mutex g_enqueue_mutex;

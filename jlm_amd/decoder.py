@@ -101,11 +101,9 @@ class Decoder():
         self.max_batch = 1024            # sentences per device batch; longer inputs are pipelined in chunks
         self.plan_budget_bytes = 6 << 30  # state rows of one batch (frames x sentences x beam x (2 H + ldt) x 4 B): see _chunks
         self.last_lattice = None
-        self.collector_thread = os.environ.get("JLM_COLLECTOR", "0") == "1"      # _run_pipeline: finish chunks on their own thread
-        # _run_pipeline: enqueue chunks on their own thread.  Measured (profiles/r04_a_submit_thread_ab.txt, interleaved runs on one box):
-        # 1.97-2.01 vs 1.99-2.07 ms per step at configs[1], no gain for vocab_select, a loss for the incremental decoder (1.47-1.82
-        # vs 1.44-1.45): the two threads meet at the interpreter lock and the process burns 20 % more CPU.  Off unless asked for.
-        self.submit_thread = os.environ.get("JLM_SUBMIT_THREAD", "0") == "1"
+        # (rounds 2-4 could finish or enqueue chunks on a thread of their own -- JLM_COLLECTOR / JLM_SUBMIT_THREAD; measured in
+        #  rounds 2, 4 and 5, never a gain -- profiles/r04_a_submit_thread_ab.txt, r05_k_host_bench.txt -- and removed in round 5: the
+        #  enqueue is ONE op without the interpreter lock now, engine._enqueue)
         self._pool = None                # worker threads that build the lattices of upcoming chunks
         from . import usable_cpus
         # lattice builds (single-threaded, 1.4 ms per 256-sentence chunk) running ahead of the GPU: two workers keep it fed
@@ -248,12 +246,7 @@ class Decoder():
         """The device pipeline of decode_batch: ``submit`` every prepared chunk (enqueue upload + frame loop + read-back: no
         waiting), ``finish`` them in order (wait for the batch, build its n-best lists).  ``pipeline_depth`` + 1 chunks are in
         flight at most (the engine alternates streams; a chunk owns its plan's buffers until finished).
-
-        ``collector_thread`` (JLM_COLLECTOR=1, off by default): the finishing runs on its own thread -- the submitting thread
-        spends most of a chunk inside the frame-loop op and the finishing thread inside the event wait, both without the GIL.
-        It takes the calling thread from 92-97 % to 47 % busy (tools/probes/host_threads_cpu.py) but the decode is GPU bound
-        once the collector pause below is in: 2.87 vs 2.80 ms per chunk (tools/probes/e2e_collector.py) -- kept for hosts
-        slower than the ones measured."""
+"""
         # The n-best lists are ~8 k acyclic containers per 256-sentence chunk: left on, the cyclic collector runs a dozen
         # young collections per chunk and, as the result list grows, full collections over everything decoded so far (4.0 vs
         # 2.9 ms per chunk at 200 vs 40 chunks per call).  Nothing allocated in here can form a cycle: collection is paused.
@@ -270,113 +263,21 @@ class Decoder():
                 gc.enable()
 
     def _run_pipeline_nogc(self, prepared, n_chunks, submit, finish, depth):
-        if n_chunks > 2 and self.submit_thread and not self.collector_thread:
-            return self._run_pipeline_submitter(prepared, n_chunks, submit, finish, depth)
-        if n_chunks <= 2 or not self.collector_thread:
-            inflight = deque()
-            try:
-                for item in prepared:
-                    inflight.append(submit(item))
-                    if len(inflight) > depth:
-                        finish(*inflight.popleft())
-                while inflight:
-                    finish(*inflight.popleft())
-            except BaseException:
-                while inflight:                      # chunks already on the device: wait for them, their plans are released
-                    try:
-                        self._engine.collect(inflight.popleft()[1])
-                    except Exception:
-                        pass
-                raise
-            return
-        import queue
-        import threading
-        q, slots, failed = queue.Queue(), threading.Semaphore(depth + 1), []
-
-        def collector():
-            while True:
-                item = q.get()
-                if item is None:
-                    return
-                try:
-                    if not failed:
-                        finish(*item)
-                except BaseException as e:          # re-raised on the calling thread; keep draining so it never blocks
-                    failed.append(e)
-                finally:
-                    slots.release()
-
-        th = threading.Thread(target=collector, name="jlm-collect", daemon=True)
-        th.start()
+        inflight = deque()
         try:
             for item in prepared:
-                slots.acquire()
-                if failed:
-                    slots.release()
-                    break
+                inflight.append(submit(item))
+                if len(inflight) > depth:
+                    finish(*inflight.popleft())
+            while inflight:
+                finish(*inflight.popleft())
+        except BaseException:
+            while inflight:                      # chunks already on the device: wait for them, their plans are released
                 try:
-                    q.put(submit(item))
-                except BaseException:
-                    slots.release()
-                    raise
-        finally:
-            q.put(None)
-            th.join()
-        if failed:
-            raise failed[0]
-
-    def _run_pipeline_submitter(self, prepared, n_chunks, submit, finish, depth):
-        """Round 4: the ENQUEUE of every chunk (staging, one H2D copy, the frame-loop op: 0.5-0.7 ms of host work per chunk, most of
-        it without the interpreter lock) runs on its own thread, in chunk order, as soon as the chunk's lattice is built; the
-        calling thread only waits for finished batches and builds their n-best lists (~1 ms per chunk).  On one thread the two add
-        up to about the 1.9 ms the GPU needs for a 256-sentence batch -- any jitter and the device idles -- and the decoders whose
-        batches take the GPU 1.2-1.4 ms (``vocab_select``, the incremental decoder) were host bound.  ``depth`` + 1 batches are
-        submitted but not yet collected at most, as on one thread.  Built, measured, and NOT the default (see ``submit_thread`` in
-        ``__init__``): JLM_SUBMIT_THREAD=1 selects it."""
-        import queue
-        import threading
-        q, slots, stop = queue.Queue(), threading.Semaphore(depth + 1), threading.Event()
-        pipelined = n_chunks > 1
-
-        def submitter():
-            self._engine.pipelined = pipelined          # per thread (DecodeEngine.pipelined): this thread does the submitting
-            try:
-                for item in prepared:
-                    slots.acquire()
-                    if stop.is_set():
-                        slots.release()
-                        break
-                    q.put(("ok", submit(item)))
-            except BaseException as e:                  # re-raised on the calling thread
-                q.put(("err", e))
-            finally:
-                self._engine.pipelined = False
-                q.put(None)
-
-        th = threading.Thread(target=submitter, name="jlm-submit", daemon=True)
-        th.start()
-        err = None
-        while True:
-            msg = q.get()
-            if msg is None:
-                break
-            kind, payload = msg
-            if kind == "err":
-                err = err or payload
-                continue
-            try:
-                if err is None:
-                    finish(*payload)
-                else:                                   # after a failure: only wait for what is already on the device
-                    self._engine.collect(payload[1])
-            except BaseException as e:
-                err = err or e
-                stop.set()
-            finally:
-                slots.release()
-        th.join()
-        if err is not None:
-            raise err
+                    self._engine.collect(inflight.popleft()[1])
+                except Exception:
+                    pass
+            raise
 
     def _chunks(self, inputs, beam_width, reorder=True):
         """Index lists of the device batches of one decode_batch call.  A batch's frame loop and buffers run to its LONGEST
@@ -485,7 +386,8 @@ class Decoder():
         if getattr(self, "_numa", None) is None:
             dev = getattr(self.model, "device", None)
             idx = dev.index if (dev is not None and dev.type == "cuda" and dev.index is not None) else 0
-            self._numa = numa.worker_cpus(idx) if (dev is not None and dev.type == "cuda") else (-1, set())
+            self._numa = (numa.worker_cpus(idx, min_cpus=max(numa.MIN_PIN_CPUS, self.prefetch_workers + 1))
+                          if (dev is not None and dev.type == "cuda") else (-1, set()))
         pin = (lambda cpus=self._numa[1]: numa.pin_current_thread(cpus))
         if workers == 1:
             if self._pool1 is None:          # a pool of ONE thread runs its tasks in submission order

@@ -26,9 +26,8 @@ re-upload of constants per batch).  submit()/collect() split a decode into the
 asynchronous device part and the host read-out, so the strings of batch i are
 built while the GPU decodes batch i+1 (two plans of the same shape alternate).
 
-The whole launch sequence of a batch is ONE custom op (torch.ops.jlm.decode_frames -> jlm_decode_frames,
-csrc/jlm_decode.hip): no host work between the frames.  Replaying a captured hipGraph instead was measured
-slower everywhere once the loop was native and is gone.
+Upload, the whole launch sequence and the read-back of a batch are ONE custom op (torch.ops.jlm.decode_batch ->
+jlm_decode_frames, csrc/jlm_decode.hip): no host work between the frames, none of it under the interpreter lock.
 """
 import os
 import threading
@@ -186,7 +185,7 @@ class DecodeEngine:
         self.last_n_live = None
         self.keep_n_live = False        # bench.py: read back every frame's live-row count with a timed decode
         self.use_side = os.environ.get("JLM_SIDE", "1") != "0"       # edge logits beside the normaliser
-        self.blocking_sync = os.environ.get("JLM_BLOCKING_SYNC", "0") == "1"
+        self.blocking_sync = False       # (JLM_BLOCKING_SYNC, rounds 2-4: the collecting thread asleep instead of spinning -- no less CPU, 1-3 % slower; removed)
         from .lattice import StagingPool
         self.staging_pool = None if os.environ.get("JLM_PINNED_LATTICE", "1") == "0" else StagingPool(self.torch, self.device.type == "cuda")
         self.plans = []
@@ -204,11 +203,10 @@ class DecodeEngine:
         # step against 2.06 with three (jlm_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 when it still can)
         from . import hw_queues_ok as _hwq
         self.n_streams = max(1, int(os.environ.get("JLM_STREAMS", "4" if _hwq() else "3")))
-        # CU share of the vocabulary kernel beside other batches in flight.  Round 4: 100 (no cap).  With four batches in flight the
-        # step is flat in the share (1.85-1.93 ms device-resident for 50 ... 100 %, profiles/r04_b_share_sweep.txt), and a share
-        # below 100 makes the kernel's column cuts -- the grouping of its float32 partial sums, i.e. the last bits of a score --
-        # depend on whether the call had one chunk or several: one input, two answers.  JLM_LSE_SHARE=66 restores round 3's cut.
-        self.lse_share_pct = int(os.environ.get("JLM_LSE_SHARE", "100")) if self.n_streams >= 2 else 0
+        # CU share of the vocabulary kernel beside other batches in flight: none since round 4 (the step is flat in it with four batches
+        # in flight, profiles/r04_b_share_sweep.txt, and a share below 100 made a score's last bits depend on how many chunks the call
+        # had); the JLM_LSE_SHARE knob left in round 5, the frame-loop op keeps its (unused) argument.
+        self.lse_share_pct = 100 if self.n_streams >= 2 else 0
         self._streams = []
         self._rr = 0
         # `pipelined`: set by the caller around a pipelined sequence of submits (Decoder.decode_batch).  Per THREAD: two threads inside

@@ -364,7 +364,6 @@ class DeviceModel:
                 xg *= 2.0 ** S
                 self.xgate8 = torch.from_numpy(xg.astype(np.float32)).to(self.device)
                 del xg, wx
-                self.kpad_split = H
                 wt8 = torch.from_numpy(np.ascontiguousarray(wt_host[perm8, :H])).to(self.device)
                 self.wt8 = torch.zeros((4 * H, H), dtype=torch.float32, device=self.device)
                 O.pack_split_f16(wt8, 0, 4 * H, H, H, float(2.0 ** (S - 14)), self.wt8, 0, H)
@@ -397,11 +396,24 @@ class DeviceModel:
         rows.  Measured on the trained-model-like fixtures (numpy emulation and GPU): the worst path score of 20-kana sentences moves
         by ~10 x this rms, so the default 1.0e-6 keeps scores inside 1e-5, half the test suite's tolerance.  ``mixed_calib`` records the measurement either way (bench.py prints it)."""
         self.mixed_calib = None
-        if not getattr(self, "mixed_idx", None) or not self.split_lstm or self.pmt_split is None or self.mode == "untied":
+        if not getattr(self, "mixed_idx", None):
             return
         limit = float(os.environ.get("JLM_MIXED_MAX_LSE_RMS", "1.0e-6"))
         if not (limit > 0.0):
             return
+
+        def drop(reason, **kw):
+            """the model stays on split rows; mixed_calib says why (bench.py prints it)"""
+            self.mixed_calib = dict(kept=False, limit=limit, reason=reason, **kw)
+            self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []
+            self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [], [], []
+            self.ld_tm, self.b2_log2 = 0, None
+            self._decode_model = None
+
+        # (round 5, ADVICE) a model the probe cannot run on -- no split LSTM step, no projection panel -- must not keep the int8
+        # planes on the spread gate alone (that gate misses peaked logits): it stays on split rows
+        if not self.split_lstm or self.pmt_split is None or self.mode == "untied":
+            return drop("the load-time probe does not cover this model (no split LSTM step / projection panel): split rows")
         torch, O = self.torch, _ops.backend()
         R, S, H = self.CALIB_ROWS, self.CALIB_STEPS, self.H
         G = (S + 1) * R
@@ -421,9 +433,12 @@ class DeviceModel:
                 T = torch.zeros((G, self.ldt), dtype=torch.float32, device=dev)
                 Tm = torch.zeros(((R + 31) // 32 * 32, self.ld_tm), dtype=torch.float32, device=dev)
                 part = torch.zeros((max_parts, R, 2), dtype=torch.float32, device=dev)
-                n = int(O.lse_probe(dm, rowlist, prev, word, S, R, h, c, T, Tm, self.ld_tm, form, part, max_parts))
+                try:
+                    n = int(O.lse_probe(dm, rowlist, prev, word, S, R, h, c, T, Tm, self.ld_tm, form, part, max_parts))
+                except (RuntimeError, _lib.JlmHipError) as e:        # a launcher refused (stride check, LDS grant, ...): not a load failure
+                    return drop("the load-time probe failed (%s): split rows" % str(e).splitlines()[0][:160])
                 if n < 1:
-                    return                               # a model the probe does not cover: the spread gate alone decides
+                    return drop("the load-time probe does not cover this model (code %d): split rows" % n)
                 if dev.type == "cuda":
                     torch.cuda.synchronize(dev)
                 p = part[:n].double().cpu().numpy()
@@ -437,10 +452,8 @@ class DeviceModel:
         self.mixed_calib = dict(rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst, limit=limit, kept=keep,
                                 lse_mean=float(np.mean(lse[0])))
         if not keep:
-            self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []
-            self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [], [], []
-            self.ld_tm, self.b2_log2 = 0, None
-            self._decode_model = None
+            drop("log-normaliser rms difference above the limit", rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst,
+                 lse_mean=float(np.mean(lse[0])))
 
     # (k + 2 -> 32-k blocks, 16-k f16 steps) with inlined mixed-row bodies: k = 200, 100, 50 (csrc/jlm_mixed.hip MX_KERNEL_DSOFTMAX; the
     # first two also in csrc/jlm_split.hip vocab_lse_hybrid_kernel, beside split-row bodies for other short segments)
@@ -549,7 +562,6 @@ class DeviceModel:
                 if self.um_split is not None:
                     t["untied_split"] = self.um_split
                     f["untied_descale"] = self.um_descale
-                i["kpad_split"] = self.kpad_split
                 f.update(gate_descale=self.gate_descale, h_scale=self.h_scale, t_descale=self.t_descale)
             meta = lambda segs: [int(sg[k]) for sg in segs for k in ("v_start", "v_end", "k", "t_off", "ldb")]
             if self.split_array is not None:

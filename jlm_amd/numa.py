@@ -57,8 +57,13 @@ def device_pci_bus_id(device_index):
         return None
 
 
-def worker_cpus(device_index, sysfs=SYSFS, pci_bus_id=None, allowed=None):
-    """(numa node, CPUs of that node this process may use) for the GPU; (-1, set()) when there is nothing to pin to"""
+MIN_PIN_CPUS = 4          # fewer CPUs of the GPU's node than this in the process mask: pinning would crowd the workers, leave them alone
+
+
+def worker_cpus(device_index, sysfs=SYSFS, pci_bus_id=None, allowed=None, min_cpus=None):
+    """(numa node, CPUs of that node this process may use) for the GPU; (-1, set()) when there is nothing to pin to.
+    A process mask that only grazes the node (fewer than ``min_cpus`` of its CPUs, default MIN_PIN_CPUS or the worker count the
+    caller passes) gives (node, set()): the workers then run unpinned rather than all on one or two CPUs."""
     if os.environ.get("JLM_NUMA_PIN", "1") == "0":
         return -1, set()
     bus = pci_bus_id or device_pci_bus_id(device_index)
@@ -73,6 +78,9 @@ def worker_cpus(device_index, sysfs=SYSFS, pci_bus_id=None, allowed=None):
         except AttributeError:
             return node, set()
     cpus = node_cpus(node, sysfs) & set(allowed)
+    need = MIN_PIN_CPUS if min_cpus is None else max(int(min_cpus), 1)
+    if len(cpus) < need:
+        return node, set()
     return node, cpus
 
 

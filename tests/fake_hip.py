@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 8
+        return 9
 
     def jlm_lse_probe(self, m, rowlist, prev, word, steps, rows, h, c, T, Tm, ld_tm, form, part, max_parts, stream):
         """ABI 8 (csrc/jlm_decode.hip): `steps` LSTM steps from the zero state, T of the last block, its normaliser slices"""
@@ -138,8 +138,7 @@ class FakeLib:
                 r = self.jlm_lstm_step_xg(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, m.wt8, m.xgate8, m.H,
                                           m.gate_descale, m.h_scale, p.T if m.untied else None, rmax, ndev, stream)
             elif m.split_lstm:
-                r = self.jlm_lstm_step_split(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, None, 0, m.wt_split, None,
-                                             m.kpad_split, m.H, 0, m.gate_descale, m.h_scale, m.xgate, rmax, ndev, stream)
+                return -2
             else:
                 r = self.jlm_lstm_step(p.h, p.c, m.H, p.h, p.c, rows, st.bp, st.word, m.emb, m.ld_emb, m.wt, m.gate_bias,
                                        m.kpad, m.H, m.E, rmax, ndev, stream)
@@ -281,46 +280,6 @@ class FakeLib:
         nb = x.shape[1] // 8
         out[row_ids, :nb, 0, :] = hi.reshape(len(row_ids), nb, 8)
         out[row_ids, :nb, 1, :] = lo.reshape(len(row_ids), nb, 8)
-
-    def jlm_lstm_step_split(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, emb, ld_emb, wt, bias, kpad, H, E,
-                            descale, h_scale, xgate, n_rows_max, n_dev, stream):
-        table = _p(xgate) != 0
-        if H % 32 or kpad % 32 or ld % 16 or (not table and (E % 16 or kpad < H + E or ld_emb % 16)):
-            return -1
-        n = _n(n_rows_max, n_dev)
-        if n == 0:
-            return 0
-        g = _rows(rows, n)
-        gmax = int(g.max()) + 1
-        p = view(prev, gmax, np.int32)[g].astype(np.int64)
-        w = view(word, gmax, np.int32)[g].astype(np.int64)
-        hmax = max(gmax, int(p.max()) + 1)
-        hin = self._split_read(h_in, hmax, ld)
-        cin = view(c_in, hmax * ld, np.float32).reshape(hmax, ld)
-        x = np.zeros((n, kpad), dtype=np.float64)
-        ok = p >= 0
-        x[ok, :H] = hin[p[ok], :H]
-        if not table:
-            x[:, H:H + E] = self._split_read(emb, int(w.max()) + 1, ld_emb)[w, :E]
-        cp = np.zeros((n, H), dtype=np.float32)
-        cp[ok] = cin[p[ok], :H]
-        W = self._split_read(wt, 4 * H, kpad)
-        if table:
-            W = W.copy()
-            W[:, H:] = 0.0
-            add = view(xgate, (int(w.max()) + 1) * 4 * H, np.float32).reshape(-1, 4 * H)[w]
-        else:
-            add = view(bias, 4 * H, np.float32)
-        z = ((x @ W.T) * float(descale)).astype(np.float32) + add
-        u = np.arange(H)
-        zi, zf, zo, zg = (z[:, (u // 16) * 64 + k * 16 + (u % 16)] for k in range(4))
-        sig = lambda t: (1.0 / (np.exp(-t.astype(np.float64)) + 1.0)).astype(np.float32)
-        cn = cp * sig(zf) + np.tanh(zg) * sig(zi)
-        hn = (np.tanh(cn) * sig(zo)).astype(np.float32)
-        self._split_write(h_out, gmax, ld, g, hn * np.float32(h_scale))
-        cout = view(c_out, gmax * ld, np.float32).reshape(gmax, ld)
-        cout[g, :H] = cn
-        return 0
 
     def jlm_lstm_step_xg(self, h_in, c_in, ld, h_out, c_out, rows, prev, word, wt8, xgate8, H, descale, h_scale, h_f32_out,
                          n_rows_max, n_dev, stream):
@@ -997,7 +956,7 @@ class _FakeModel:
         m.H, m.ldt = i["H"], i["ldt"]
         m.untied, m.self_norm, m.split_lstm = i.get("untied", 0), i.get("self_norm", 0), i.get("split_lstm", 0)
         m.emb, m.ld_emb, m.wt, m.gate_bias = ptr("emb"), i.get("ld_emb", 0), ptr("wt"), ptr("gate_bias")
-        m.kpad, m.E, m.kpad_split = i.get("kpad", 0), i.get("E", 0), i.get("kpad_split", 0)
+        m.kpad, m.E = i.get("kpad", 0), i.get("E", 0)
         m.gate_descale, m.h_scale, m.t_descale = f.get("gate_descale", 0.0), f.get("h_scale", 0.0), f.get("t_descale", 0.0)
         m.wt8, m.xgate8, m.pmt, m.pmt_split, m.n_t = ptr("wt8"), ptr("xgate8"), ptr("pmt"), ptr("pmt_split"), i.get("n_t", 0)
         m.untied_split, m.untied_descale = ptr("untied_split"), f.get("untied_descale", 0.0)

@@ -126,82 +126,6 @@ def _pack(L, src_g, k, scale, ld_dst=None, dst=None, col0=0, src_col0=0):
     return dst
 
 
-@pytest.mark.parametrize("H,E,R,use_rows", [(64, 32, 10, False), (64, 32, 200, True), (512, 256, 700, True),
-                                            (512, 200, 2560, True), (128, 352, 33, True)])
-def test_lstm_step_split(L, H, E, R, use_rows):
-    """split-f16 LSTM step against the f64 restatement on the ORIGINAL f32 operands (same bar as the
-    f32 kernel) and against the numpy double fed the same split rows"""
-    rng = np.random.default_rng(H + E + R)
-    V, G = 500, R * 3 + 7
-    kpad = (H + E + 31) // 32 * 32
-    E16 = (E + 15) // 16 * 16
-    kps = (H + E16 + 31) // 32 * 32
-    h, hg = _pair(np.tanh(rng.standard_normal((G, H))).astype(np.float32))
-    c, cg = _pair(rng.standard_normal((G, H)).astype(np.float32) * 0.5)
-    emb, embg = _pair(rng.standard_normal((V, E)).astype(np.float32) * 0.3)
-    wt_np = np.zeros((4 * H, kpad), dtype=np.float32)
-    wt_np[:, :H + E] = rng.standard_normal((4 * H, H + E)).astype(np.float32) * 0.08
-    wt, wtg = _pair(wt_np)
-    bias, biasg = _pair(rng.standard_normal(4 * H).astype(np.float32) * 0.1)
-    word, wordg = _pair(rng.integers(0, V, size=G).astype(np.int32))
-    if use_rows:
-        rows_np = (G - 1 - rng.permutation(R)).astype(np.int32)
-        prev_np = rng.integers(-1, G - R, size=G).astype(np.int32)
-        rows, rowsg = _pair(rows_np)
-        nd, ndg = _pair(np.array([R - 1], dtype=np.int32))
-        rp, rpg, ndp, ndpg = rows.data_ptr(), rowsg.data_ptr(), nd.data_ptr(), ndg.data_ptr()
-        ho, co, cog = h, c, cg
-    else:
-        prev_np = np.arange(G, dtype=np.int32)
-        rp = rpg = ndp = ndpg = None
-        ho, _ = _pair(np.zeros((G, H), dtype=np.float32))
-        co, cog = _pair(np.zeros((G, H), dtype=np.float32))
-    prev, prevg = _pair(prev_np)
-    assert FK.jlm_lstm_step(h.data_ptr(), c.data_ptr(), H, ho.data_ptr(), co.data_ptr(), rp, prev.data_ptr(),
-                            word.data_ptr(), emb.data_ptr(), E, wt.data_ptr(), bias.data_ptr(), kpad, H, E, R, ndp, 0) == 0
-    # split operands: h * 2^14, emb * 2^8, W_h * 2^(S-14), W_x * 2^(S-8), S = 20
-    hs = _pack(L, hg, H, 2.0 ** 14)
-    es = _pack(L, embg, E, 2.0 ** 8)
-    ws = torch.zeros((4 * H, kps), dtype=torch.float32, device="cuda")
-    _pack(L, wtg, H, 2.0 ** 6, dst=ws)
-    _pack(L, wtg, E, 2.0 ** 12, dst=ws, col0=H, src_col0=H)
-    hos = hs if use_rows else torch.zeros_like(hs)
-    torch.cuda.synchronize()
-    hs_c, es_c, ws_c = hs.cpu(), es.cpu(), ws.cpu()
-    hos_c = hs_c if use_rows else torch.zeros_like(hs_c)
-    c_orig = cg.cpu().numpy().copy()
-    cc, _ = _pair(c_orig.copy())
-    args = (kps, H, E16, 2.0 ** -20, 2.0 ** 14, None, R)
-    cog_in = cg
-    assert L.jlm_lstm_step_split(hs.data_ptr(), cog_in.data_ptr(), H, hos.data_ptr(), cog.data_ptr(), rpg, prevg.data_ptr(),
-                                 wordg.data_ptr(), es.data_ptr(), E16, ws.data_ptr(), biasg.data_ptr(), *args, ndpg,
-                                 _st()) == 0
-    torch.cuda.synchronize()
-    h_gpu = _unsplit(hos) / 2.0 ** 14
-    sel = rows_np[:R - 1] if use_rows else np.arange(R)
-    np.testing.assert_allclose(h_gpu[sel], ho.numpy()[sel], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(cog.cpu().numpy()[sel], co.numpy()[sel], rtol=2e-5, atol=2e-6)
-    # the numpy double on the same split rows
-    co2 = cc if use_rows else torch.zeros((G, H), dtype=torch.float32)
-    assert FK.jlm_lstm_step_split(hs_c.data_ptr(), cc.data_ptr(), H, hos_c.data_ptr(), co2.data_ptr(), rp, prev.data_ptr(),
-                                  word.data_ptr(), es_c.data_ptr(), E16, ws_c.data_ptr(), bias.data_ptr(), *args, ndp, 0) == 0
-    np.testing.assert_allclose(h_gpu[sel], (_unsplit(hos_c) / 2.0 ** 14)[sel], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(cog.cpu().numpy()[sel], co2.numpy()[sel], rtol=2e-5, atol=2e-6)
-    # input side as a table lookup: xgate[w] = emb[w] . W_x^T + bias, contraction over the state only
-    xg = (emb.numpy().astype(np.float64) @ wt_np[:, H:H + E].astype(np.float64).T + bias.numpy()).astype(np.float32)
-    xgg = torch.as_tensor(xg).cuda()
-    hs2 = _pack(L, hg, H, 2.0 ** 14)
-    hos2 = hs2 if use_rows else torch.zeros_like(hs2)
-    cg2 = torch.as_tensor(c_orig.copy()).cuda()
-    cog2 = cg2 if use_rows else torch.zeros_like(cg2)
-    assert L.jlm_lstm_step_split(hs2.data_ptr(), cg2.data_ptr(), H, hos2.data_ptr(), cog2.data_ptr(), rpg, prevg.data_ptr(),
-                                 wordg.data_ptr(), None, 0, ws.data_ptr(), None, kps, H, 0, 2.0 ** -20, 2.0 ** 14,
-                                 xgg.data_ptr(), R, ndpg, _st()) == 0
-    torch.cuda.synchronize()
-    np.testing.assert_allclose((_unsplit(hos2) / 2.0 ** 14)[sel], ho.numpy()[sel], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(cog2.cpu().numpy()[sel], co.numpy()[sel], rtol=2e-5, atol=2e-6)
-
-
 @pytest.mark.parametrize("H,R,use_rows", [(64, 10, False), (64, 200, True), (512, 700, True), (512, 2560, True), (128, 161, True),
                                          (512, 159, False),
                                          # the W-stationary persistent kernel (H = 512 with a row list): one tile per workgroup at 2 560 rows; two

@@ -246,38 +246,6 @@ def bench_gate(H, E, R):
     report("lstm_step H=%d E=%d R=%d" % (H, E, R), 2.0 * (H + E) * 4 * H * R, timeit(f))
 
 
-def bench_gate_split(H, E, R):
-    if flt and flt not in "gate":
-        return
-    V, G = 50000, 3 * R
-    E16 = (E + 15) // 16 * 16
-    kps = (H + E16 + 31) // 32 * 32
-    pk = lambda src, k, sc, dst, col0=0: L.jlm_pack_split_f16(src.data_ptr() + 4 * col0, src.shape[0], k, src.shape[1], sc,
-                                                              dst.data_ptr() + 4 * col0, dst.shape[1], st)
-    hf, c = torch.tanh(rnd(G, H)), rnd(G, H)
-    embf, wtf = rnd(V, E16, scale=0.3), rnd(4 * H, kps, scale=0.05)
-    h, emb, wt = torch.zeros_like(hf), torch.zeros_like(embf), torch.zeros_like(wtf)
-    assert pk(hf, H, 2.0 ** 14, h) == 0 and pk(embf, E16, 2.0 ** 8, emb) == 0
-    assert pk(wtf, H, 2.0 ** 6, wt) == 0 and pk(wtf, E16, 2.0 ** 12, wt, H) == 0
-    bias = rnd(4 * H)
-    rows = (torch.arange(R, device=dev, dtype=torch.int32) + 2 * R).contiguous()
-    prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
-    word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
-    nd = torch.tensor([R], device=dev, dtype=torch.int32)
-    f = lambda: L.jlm_lstm_step_split(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(),
-                                      prev.data_ptr(), word.data_ptr(), emb.data_ptr(), E16, wt.data_ptr(), bias.data_ptr(),
-                                      kps, H, E16, 2.0 ** -20, 2.0 ** 14, None, R, nd.data_ptr(), st)
-    assert f() == 0
-    report("lstm_step_split H=%d E=%d R=%d tile=%s" % (H, E, R, os.environ.get("JLM_GATE_TILE", "128")),
-           2.0 * (H + E) * 4 * H * R, timeit(f))
-    xg = rnd(V, 4 * H)
-    f2 = lambda: L.jlm_lstm_step_split(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(),
-                                       prev.data_ptr(), word.data_ptr(), None, 0, wt.data_ptr(), None,
-                                       kps, H, 0, 2.0 ** -20, 2.0 ** 14, xg.data_ptr(), R, nd.data_ptr(), st)
-    assert f2() == 0
-    report("lstm_step_split+xgate-table H=%d E=%d R=%d" % (H, E, R), 2.0 * (H + E) * 4 * H * R, timeit(f2))
-
-
 def bench_gate_xg(H, R):
     if flt and flt not in "gate":
         return
@@ -327,10 +295,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     for R in (2560,):
         bench_gate(512, 200, R)
-        bench_gate_split(512, 200, R)
         bench_gate_xg(512, R)
         bench_gate(512, 256, R)
-        bench_gate_split(512, 256, R)
         bench_lse_stat(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*", bias_col=True)
