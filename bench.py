@@ -228,7 +228,9 @@ def main():
         v = kernel_stats(durs, rows, "vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
         roofline = None
         if v:
-            kname = ("gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
+            kname = ("vocab_lse_mixedw_kernel<1, true, 16, 32> (jlm_vocab_lse_mixed: the wide one-row-set form for k = 512, csrc/jlm_mixed_w.hip; rows "
+                     "packed by pack_t_mixed_kernel from the state's f32 copy)" if (mixed and getattr(m, "um_split", None) is not None) else
+                     "gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
                      "vocab_lse_mixed_kernel (jlm_vocab_lse_mixed; its rows packed by pack_t_mixed_kernel behind the T projection)" if mixed else
                      "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok

@@ -135,8 +135,11 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                                     m->n_t, m->H, ndev, stream));
         }
         // segments of the full-vocabulary normaliser on mixed rows: this frame's live rows are packed once, here, behind T
+        // (round 5: an untied model at H = 512 -- T is the state's f32 copy, one segment of k = 512 -- runs jlm_vocab_lse_mixed's wide
+        //  one-row-set form instead of the tile GEMM below when its vocabulary matrix exists as mixed rows)
         bool hybrid = false, all_mixed = false;
-        if (full && !m->self_norm && !tile_form && m->mixed_segs && m->split_segs && p->Tm) {
+        const bool untied_mixed = tile_form && m->untied && m->n_segs == 1 && m->mixed_segs && m->mixed_segs[0].B && p->Tm;
+        if (full && !m->self_norm && ((!tile_form && m->mixed_segs && m->split_segs && p->Tm) || untied_mixed)) {
             jlm_segment only[JLM_MAX_SEGMENTS];
             float only_ts[JLM_MAX_SEGMENTS];
             int n_only = 0;
@@ -174,7 +177,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->di_words, p->di_off, p->di_idx, 2 * cell, 0, B, p->di_max));
             else if (select)
                 JLM_TRY(wl_lse(p->g0 + cell, p->cidx + cell, p->vs_words, p->vs_off, p->sidx, 0, 0, B, p->vs_max));
-            else if (tile_form) {
+            else if (tile_form && !all_mixed) {
                 int n_parts = 0;
                 for (int i = 0; i < m->n_segs; ++i) {
                     const jlm_segment &sg = m->segs[i];
@@ -236,7 +239,28 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
 // steps; rowlist[g] = g, prev[g] = g - rows (< 0 for block 1: zero state), word[g] = the word consumed by step t.
 extern "C" int jlm_lse_probe(const jlm_decode_model *m, const int *rowlist, const int *prev, const int *word, int steps, int rows,
                              void *h, float *c, float *T, void *Tm, int ld_tm, int form, float *part, int max_parts, void *stream) {
-    if (steps < 1 || rows < 1 || !m->split_lstm || !m->wt8 || m->untied || m->self_norm || !m->split_segs || !m->pmt_split) return -2;
+    if (steps < 1 || rows < 1 || !m->split_lstm || !m->wt8 || m->self_norm) return -2;
+    if (m->untied) {
+        // an untied model (round 5): T is the f32 copy of the state the step writes beside its split rows; form 0 = the tile GEMM on
+        // split rows (jlm_vocab_lse_partials_split), form 1 = the mixed rows of the vocabulary matrix (k = 512: the wide kernel)
+        if (!m->untied_split || m->n_segs != 1) return -2;
+        for (int t = 1; t <= steps; ++t)
+            JLM_TRY(jlm_lstm_step_xg(h, c, m->H, h, c, rowlist + (size_t)t * rows, prev, word, m->wt8, m->xgate8, m->H, m->gate_descale,
+                                     m->h_scale, T, rows, nullptr, stream));
+        const int *rl = rowlist + (size_t)steps * rows;
+        const jlm_segment &sg = m->segs[0];
+        if (form == 0) {
+            if ((sg.v_end - sg.v_start + 127) / 128 > max_parts) return -1;
+            return jlm_vocab_lse_partials_split(m->untied_split, m->H, sg.v_end - sg.v_start, m->H, h, m->H, rl, m->b2 + sg.v_start,
+                                                m->untied_descale, part, rows, 0, rows, nullptr, stream);
+        }
+        if (!m->mixed_segs || !m->mixed_segs[0].B || !Tm) return -2;
+        if (jlm_mixed_t_stride(m->mixed_segs, 1) != ld_tm) return -1;
+        JLM_TRY(jlm_pack_t_mixed(m->mixed_segs, m->mixed_t_scale, 1, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
+        return jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, 1, Tm, ld_tm, part, rows, max_parts, rows,
+                                   nullptr, stream);
+    }
+    if (!m->split_segs || !m->pmt_split) return -2;
     for (int t = 1; t <= steps; ++t)
         JLM_TRY(jlm_lstm_step_xg(h, c, m->H, h, c, rowlist + (size_t)t * rows, prev, word, m->wt8, m->xgate8, m->H, m->gate_descale,
                                  m->h_scale, nullptr, rows, nullptr, stream));

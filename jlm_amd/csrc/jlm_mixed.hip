@@ -331,7 +331,7 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
         const int nb = mx_seg_blocks(sg);
-        if (nb < 1 || nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
+        if (nb < 1 || nb > MXW_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
         a.seg[i] = MxTSeg{sg.k, sg.t_off, nb, off, t_scale[i] * 1.4426950408889634f, sg.k + 2 <= 32 * nb ? t_scale[i] : 0.0f};
         off += nb * 128;
     }
@@ -342,8 +342,8 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
 }
 
 // the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
-int jlm_mx_wide_launch(const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
-                       int lds, hipStream_t st);
+int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
+                       int n_ptiles, int lds, hipStream_t st);
 
 extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
                                    const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
@@ -362,6 +362,7 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     // 68.9 us, the decode 2.04 vs 2.06 ms per step); pipelined launches are capped by the CU share below that anyway.  1: multiples of 8
     if (np8 < 0) { const char *e = getenv("JLM_MX_NP8"); np8 = e ? atoi(e) : 0; }
     int ntiles[JLM_MAX_SEGMENTS];
+    int rows_wg = 256;                                   // hypothesis rows per workgroup (128: the wide kernel's k = 512 form)
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
     long n_tiles_all = 0;
     int lds_max = 0, tm_off = 0;
@@ -369,9 +370,13 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
         const int nb = mx_seg_blocks(sg);
-        if (nb < 1 || nb > MX_MAX_NB || sg.k % 4 || sg.t_off % 4) return -2;
+        // (a single segment of sixteen blocks in the external-bias form -- k = 512: an untied model's vocabulary matrix -- runs on the
+        //  wide kernel's one-row-set form, jlm_mixed_w.hip; every other shape has at most eight blocks)
+        const bool k512 = n_segs == 1 && nb == 16 && sg.k == 512;
+        if (nb < 1 || (nb > MX_MAX_NB && !k512) || sg.k % 4 || sg.t_off % 4) return -2;
         if ((long)(sg.v_end - sg.v_start) * nb * 128 >= (1l << 31)) return -2;        // 32-bit buffer offsets
         const bool xb = sg.k + 2 > 32 * nb;                  // no bias columns: the biases come from bias2 (base-2 units)
+        if (k512) rows_wg = 128;
         if (i == 0) xbias = xb;
         if (xb != xbias || (xb && (!bias2 || nb % 2))) return -2;      // one form per launch; external-bias bodies exist for even nb
         MxSeg &m = a.seg[i];
@@ -399,7 +404,7 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         total += ctile[i] * ntiles[i];
         n_tiles_all += ntiles[i];
     }
-    const int n_ptiles = (n_rows_max + 255) / 256;
+    const int n_ptiles = (n_rows_max + rows_wg - 1) / rows_wg;
     int cap = max_parts < MX_MAX_SUB ? max_parts : MX_MAX_SUB;
     cap -= n_segs - 1;
     if (cap > MX_MAX_PARTS) cap = MX_MAX_PARTS;
@@ -470,19 +475,23 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         if (xbias) { if (nb != 8) which = 3; }
         else if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4))) which = 1;
     }
+    float2 *part2 = reinterpret_cast<float2 *>(part);
+    hipStream_t st = (hipStream_t)stream;
+    static int wide = -1;
+    if (wide < 0) { const char *e = getenv("JLM_MX_WIDE"); wide = e ? atoi(e) : JLM_MX_WIDE_DEFAULT; }
+    if (rows_wg == 128) {
+        if (int rc = jlm_mx_wide_launch(1, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+        return n_sub;
+    }
+    if (which == 0 && wide) {
+        if (int rc = jlm_mx_wide_launch(0, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+        return n_sub;
+    }
     static JlmLdsGrant grant[4];
     const void *fns[4] = {reinterpret_cast<const void *>(MX_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MX_KERNEL_GENERIC),
                           reinterpret_cast<const void *>(MX_KERNEL_TIED), reinterpret_cast<const void *>(MX_KERNEL_GENERIC_XB)};
     if (int rc = jlm_grant_lds(grant[which], fns[which], lds)) return rc;
     const dim3 grid(n_cols * n_ptiles), block(512);
-    float2 *part2 = reinterpret_cast<float2 *>(part);
-    hipStream_t st = (hipStream_t)stream;
-    static int wide = -1;
-    if (wide < 0) { const char *e = getenv("JLM_MX_WIDE"); wide = e ? atoi(e) : JLM_MX_WIDE_DEFAULT; }
-    if (which == 0 && wide) {
-        if (int rc = jlm_mx_wide_launch(a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
-        return n_sub;
-    }
     switch (which) {
     case 0: hipLaunchKernelGGL(MX_KERNEL_DSOFTMAX, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;
     case 1: hipLaunchKernelGGL(MX_KERNEL_GENERIC, grid, block, lds, st, a, T, ldt, rows, part2, ld_part, n_rows_max, n_dev, n_ptiles); break;

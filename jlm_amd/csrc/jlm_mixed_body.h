@@ -10,6 +10,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 #define MX_MAX_NB 8                // 32-k blocks per row: k + 2 <= 256 (the nine-block form does not fit the register file)
+#define MXW_MAX_NB 16              // ... of the wide kernel's one-row-set form (jlm_mixed_w.hip): k = 512, the row operands in 256 accumulation registers
 #define MX_MAX_PARTS 96
 #define MX_MAX_SUB (MX_MAX_PARTS + JLM_MAX_SEGMENTS)
 
@@ -26,7 +27,7 @@ namespace jlm_mx {
 #ifndef MX_MTT_MID
 #define MX_MTT_MID 4
 #endif
-__host__ __device__ constexpr int mx_blocks_per_tile(int nb) { return nb >= 5 ? 2 : nb >= 3 ? MX_MTT_MID : 8; }
+__host__ __device__ constexpr int mx_blocks_per_tile(int nb) { return nb >= 9 ? 1 : nb >= 5 ? 2 : nb >= 3 ? MX_MTT_MID : 8; }
 
 template <int N> using IC = std::integral_constant<int, N>;
 template <class F, int... I>

@@ -43,76 +43,98 @@ extern "C" int jlm_prof_read_mxw_trace(unsigned long long *out) {
 
 namespace {
 
-template <int NB, int NS16, int MTT>
+// NB 32-k blocks per row, NS16 f16 steps, MTT 32-word blocks per tile, RS row sets of 32 per wave (2: every fragment feeds two matrix
+// instructions; 1: contractions whose operands fill the accumulation registers by themselves -- k = 512: 256 of them), XB: the rows
+// carry no bias columns (k a multiple of 32): the tile's biases (base-2 units) come into LDS beside it, three slots, and join the
+// logits in the combine (as mx_body's XBIAS form).
+template <int NB, int NS16, int MTT, int RS, bool XB>
 struct MxWide {
-    static_assert(MTT % 2 == 0, "blocks alternate between two accumulator pairs");
+    static_assert(RS == 1 || RS == 2, "one or two row sets per wave");
     static constexpr int ROWB = NB * 128;
     static constexpr int TW = 32 * MTT;
     static constexpr int BUFB = TW * ROWB;
+    static constexpr int BIAS_OFF = 2 * BUFB;             // XB: three slots of TW floats behind the two buffers
+    static constexpr int RW = 128 * RS;                   // hypothesis rows per workgroup
     static constexpr int NMF = NS16 + 2 * NB;             // matrix instructions of a block and row set
-    static constexpr int NSLOT = 8 * NB;                  // issue slots of a block (two per fragment; NS16 odd: two of the last 32-k block's are empty)
-    static constexpr int NPIECE = 2 * 42;                 // per row set: 16 x (cvt, fma), 8 x max3, 1, 16 x (fma, exp2, add), 1
-    static constexpr int PP = (NPIECE + NSLOT - 3) / (NSLOT - 2);        // (slots 0, 1 carry nothing: the pairs' last instructions are still in the pipe)
+    static constexpr int NSLOT = 4 * RS * NB;             // issue slots of a block (RS per fragment; NS16 odd: RS of the last 32-k block's are empty)
+    static constexpr int NP1 = 42;                        // per row set: 16 x combine, 8 x max3, 1, 16 x (scale, exp2, add), 1
+    static constexpr int NPIECE = RS * NP1;
+    static constexpr int SKIP = 2;                        // (the first slots carry nothing: the finished pairs' last instructions are still in the pipe)
+    static constexpr int PP = (NPIECE + NSLOT - SKIP - 1) / (NSLOT - SKIP);
 
     // row operands: MFMA B operands, in accumulation registers for the whole sub-range
-    f16x8 thi[2][NS16];
-    i32x4 thi8[2][NB], tlo8[2][NB];
-    float csr[2], descale;
-    float m[2], s[2];
-    float tmax[2], nmn[2], sc_old[2], add0[2], add1[2];
-    f32x16 fa[2], fb[2];                                  // pair a (even blocks) / b (odd blocks) of each row set
-    i32x16 ia[2], ib[2];
-    i32x4 F[8];                                           // fragment ring: 32-k block J lives in F[4 (J & 1) ..]
+    f16x8 thi[RS][NS16];
+    i32x4 thi8[RS][NB], tlo8[RS][NB];
+    float csr[RS], descale;
+    float m[RS], s[RS];
+    float tmax[RS], nmn[RS], sc_old[RS], add0[RS], add1[RS];
+    f32x16 accf[2][RS];                                   // two accumulator pairs per row set: blocks alternate
+    i32x16 acci[2][RS];
+    f32x4 bq[4];                                          // XB: the finished block's biases of this lane's 16 words
+    i32x4 F[8];                                           // fragment ring: 32-k block number n lives in F[4 (n & 1) ..]
     int goff[4];
     int hf;
     unsigned char *smem;
 
     // one piece of the treatment of the finished pair (pf, pi) of row set S
-    template <bool MASKED>
-    __device__ __forceinline__ void fold_piece(int S, f32x16 &pf, const i32x16 &pi, int mtp, int lim, int pc) {
+    __device__ __forceinline__ void fold_piece(const bool MASKED, int S, f32x16 &pf, const i32x16 &pi, int mtp, int lim, int pc) {
         if (pc < 16) {
             const int r = pc;
-            const float y = fmaf((float)pi[r], csr[S], pf[r]);
+            float y = fmaf((float)pi[r], csr[S], pf[r]);
+            if (XB) y = fmaf(y, descale, bq[r >> 2][r & 3]);            // (base-2 logit units from here on)
             pf[r] = (MASKED && mtp * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim) ? JLM_NEG_BIG : y;
         } else if (pc < 24) {
             const int q = pc - 16;
             const float t2 = fmaxf(pf[2 * q], pf[2 * q + 1]);
             tmax[S] = q == 0 ? t2 : fmaxf(tmax[S], t2);
         } else if (pc == 24) {
-            const float mn = fmaxf(m[S], tmax[S] * descale);
+            const float mn = fmaxf(m[S], XB ? tmax[S] : tmax[S] * descale);
             nmn[S] = -mn;
             sc_old[S] = __builtin_amdgcn_exp2f(m[S] - mn);
             m[S] = mn;
             add0[S] = 0.0f; add1[S] = 0.0f;
         } else if (pc < 41) {
             const int r = pc - 25;
-            const float e = (MXW_ABL & 2) ? fmaf(pf[r], descale, nmn[S]) : __builtin_amdgcn_exp2f(fmaf(pf[r], descale, nmn[S]));
+            const float x = XB ? pf[r] + nmn[S] : fmaf(pf[r], descale, nmn[S]);
+            const float e = (MXW_ABL & 2) ? x : __builtin_amdgcn_exp2f(x);
             if (r & 1) add1[S] += e; else add0[S] += e;
         } else if (pc == 41) {
             s[S] = s[S] * sc_old[S] + (add0[S] + add1[S]);
         }
     }
-    // pieces alternate between the two row sets: piece 2 q -> set 0 piece q, 2 q + 1 -> set 1 piece q
-    template <bool MASKED>
-    __device__ __forceinline__ void fold2(f32x16 (&pf)[2], const i32x16 (&pi)[2], int mtp, int lim, int pc2) {
+    // pieces alternate between the row sets: piece RS q + S -> set S piece q
+    // (masked / pw are literals at every call site and this is force-inlined: plain arguments, not template parameters -- hipcc's HOST
+    //  pass rejects the template forms inside the nested generic lambdas of block() with "substitution failure")
+    __device__ __forceinline__ void fold2(const bool masked, const int pw, int mtp, int lim, int pc2) {
+        f32x16 (&pf)[RS] = accf[pw];
+        i32x16 (&pi)[RS] = acci[pw];
         if (MXW_ABL & 1) {           // (the finished accumulators stay "used": without this the compiler drops every matrix instruction)
-            if (pc2 == 0) asm volatile("" :: "v"(pf[0]), "v"(pi[0]), "v"(pf[1]), "v"(pi[1]));
+            if (pc2 == 0) { asm volatile("" :: "v"(pf[0]), "v"(pi[0])); if (RS == 2) asm volatile("" :: "v"(pf[RS - 1]), "v"(pi[RS - 1])); }
             return;
         }
-        if ((MXW_ABL & 16) && (pc2 >> 1) >= 16) {      // combine only
-            if (pc2 == 32) asm volatile("" :: "v"(pf[0]), "v"(pf[1]));
+        if ((MXW_ABL & 16) && (pc2 / RS) >= 16) {      // combine only
+            if (pc2 == 16 * RS) { asm volatile("" :: "v"(pf[0])); if (RS == 2) asm volatile("" :: "v"(pf[RS - 1])); }
             return;
         }
-        fold_piece<MASKED>(pc2 & 1, pf[pc2 & 1], pi[pc2 & 1], mtp, lim, pc2 >> 1);
+        fold_piece(masked, pc2 % RS, pf[pc2 % RS], pi[pc2 % RS], mtp, lim, pc2 / RS);
+    }
+    // XB: the finished block's biases (its 32 words start at LDS byte `boff`) for this lane's 16 logits
+    __device__ __forceinline__ void load_bias(int boff) {
+        if (!XB) return;
+        const unsigned char *bp = smem + boff + (4 * hf) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(bp + q * 32);
     }
 
-    // one 32-word block: its matrix instructions into (wf, wi); the finished pairs (pf, pi) treated between them; tile t + 1's
-    // LDS-DMA instruction (mt NB + J) behind the first matrix instruction of 32-k block J
-    template <bool MASKED, int mt>
-    __device__ __forceinline__ void block(int buf, int lim_p, f32x16 (&wf)[2], i32x16 (&wi)[2], f32x16 (&pf)[2], i32x16 (&pi)[2],
-                                          const __amdgpu_buffer_rsrc_t rs_next, int voff_next, int wave) {
+    // one 32-word block: its matrix instructions into pair W; pair 1 - W (finished) treated between them; tile t + 1's LDS-DMA
+    // instruction (mt NB + J) behind the first matrix instruction of 32-k block J
+    template <bool MASKED, int mt, int W>
+    __device__ __forceinline__ void block(int buf, int lim_p, int boff_p, const __amdgpu_buffer_rsrc_t rs_next, int voff_next, int wave) {
         constexpr int mtp = (mt + MTT - 1) % MTT;
+        f32x16 (&wf)[RS] = accf[W];
+        i32x16 (&wi)[RS] = acci[W];
         const unsigned char *bs = smem + buf * BUFB + mt * (4 * NB * 1024);
+        load_bias(boff_p);
         __builtin_amdgcn_sched_barrier(0);
         const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const i32x16 zi = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -127,9 +149,9 @@ struct MxWide {
                 else if (mt + 1 < MTT) F[Rn + g4] = *reinterpret_cast<const i32x4 *>(bs + (4 * NB * 1024) + goff[g4]);
             };
             auto pieces = [&](int q) {
-                if (q < 2) return;
+                if (q < SKIP) return;
 #pragma unroll
-                for (int pc = (q - 2) * PP; pc < (q - 1) * PP && pc < NPIECE; ++pc) fold2<MASKED>(pf, pi, mtp, lim_p, pc);
+                for (int pc = (q - SKIP) * PP; pc < (q - SKIP + 1) * PP && pc < NPIECE; ++pc) fold2(MASKED, 1 - W, mtp, lim_p, pc);
             };
             // DMA piece (mt NB + J) of the next tile: row group wave + 4 i, 32-k block j
             if (!(MXW_ABL & 4)) {
@@ -138,39 +160,41 @@ struct MxWide {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_next, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
                                                          voff_next + i * (32 * ROWB), j * 128, 0, 0);
             }
-            wf[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 0]), thi[0][2 * J], J == 0 ? zf : wf[0], 0, 0, 0);
-            pieces(8 * J);
-            wf[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 0]), thi[(MXW_ABL & 64) ? 0 : 1][2 * J], J == 0 ? zf : wf[1], 0, 0, 0);
-            rd(0);
-            pieces(8 * J + 1);
-            wi[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 2], tlo8[0][J], J == 0 ? zi : wi[0], 0, 0, 0);
-            pieces(8 * J + 2);
-            wi[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 2], tlo8[(MXW_ABL & 64) ? 0 : 1][J], J == 0 ? zi : wi[1], 0, 0, 0);
-            rd(2);
-            pieces(8 * J + 3);
-            if constexpr (second) {
-                wf[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 1]), thi[0][second ? 2 * J + 1 : 0], wf[0], 0, 0, 0);
-                pieces(8 * J + 4);
-                wf[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 1]), thi[(MXW_ABL & 64) ? 0 : 1][second ? 2 * J + 1 : 0], wf[1], 0, 0, 0);
-            } else {
-                pieces(8 * J + 4);
-            }
-            rd(1);
-            pieces(8 * J + 5);
-            wi[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 3], thi8[0][J], wi[0], 0, 0, 0);
-            pieces(8 * J + 6);
-            wi[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 3], thi8[(MXW_ABL & 64) ? 0 : 1][J], wi[1], 0, 0, 0);
-            rd(3);
-            pieces(8 * J + 7);
+            constexpr int Q0 = 4 * RS * J;
+            // fragment order: f16 step 2 J (F[R + 0]), int8 hi8 x the rows' lo8 (F[R + 2]), f16 step 2 J + 1 (F[R + 1]), int8 lo8 x the rows' hi8 (F[R + 3])
+            mx_for_each_ic([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                wf[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 0]), thi[S][2 * J], J == 0 ? zf : wf[S], 0, 0, 0);
+                if (S == RS - 1) rd(0);
+                pieces(Q0 + S);
+            }, std::make_integer_sequence<int, RS>{});
+            mx_for_each_ic([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                wi[S] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 2], tlo8[S][J], J == 0 ? zi : wi[S], 0, 0, 0);
+                if (S == RS - 1) rd(2);
+                pieces(Q0 + RS + S);
+            }, std::make_integer_sequence<int, RS>{});
+            mx_for_each_ic([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                if constexpr (second) wf[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F[R + 1]), thi[S][second ? 2 * J + 1 : 0], wf[S], 0, 0, 0);
+                if (S == RS - 1) rd(1);
+                pieces(Q0 + 2 * RS + S);
+            }, std::make_integer_sequence<int, RS>{});
+            mx_for_each_ic([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                wi[S] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F[R + 3], thi8[S][J], wi[S], 0, 0, 0);
+                if (S == RS - 1) rd(3);
+                pieces(Q0 + 3 * RS + S);
+            }, std::make_integer_sequence<int, RS>{});
             // issue order: matrix instruction, [the LDS-DMA instruction], [a fragment read], its share of the fold
             constexpr bool reads = (J + 1 < NB) || (mt + 1 < MTT);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool has_m = second || (i != 4 && i != 5);
+            for (int i = 0; i < 4 * RS; ++i) {
+                const bool has_m = second || (i / RS != 2);
                 if (has_m) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (i == 0 && !(MXW_ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if ((i & 1) && reads && !(MXW_ABL & 32)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (8 * J + i >= 2 && !(MXW_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
+                if ((i % RS) == RS - 1 && reads && !(MXW_ABL & 32)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (Q0 + i >= SKIP && !(MXW_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
             }
         }, std::make_integer_sequence<int, NB>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -187,14 +211,14 @@ struct MxWide {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         hf = lane >> 5;
         const int li = lane & 31;
-        // ---- 1. row operands of both sets, straight into accumulation registers.  A row past the end reads its lane's slot of
-        //         block 0 (inside the buffer whatever its size; its result is not stored and no other row sees it): selecting zeros would cost
-        //         a VALU move per register.
-        bool row_ok[2];
-        int prow[2];
+        // ---- 1. row operands of every set, straight into accumulation registers.  A row past the end reads its lane's slot of
+        //         block 0 (inside the buffer whatever its size; its result is not stored and no other row sees it): selecting zeros
+        //         would cost a VALU move per register.
+        bool row_ok[RS];
+        int prow[RS];
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
-            prow[S] = pt * 256 + wave * 64 + S * 32 + li;
+        for (int S = 0; S < RS; ++S) {
+            prow[S] = pt * RW + wave * (32 * RS) + S * 32 + li;
             row_ok[S] = prow[S] < n_paths;
             // (granule-major packed rows, jlm_mixed_body.h: one contiguous kilobyte per load instruction; the instruction offset has
             //  12 bits, hence a base per 32-k block)
@@ -219,6 +243,23 @@ struct MxWide {
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)bptr);
         const int nrec = __builtin_amdgcn_readfirstlane(sg.n_vocab) * ROWB;
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0, nrec, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_bias = rs_b;
+        if (XB) {
+            const unsigned long long p2 = reinterpret_cast<unsigned long long>(sg.bias2);
+            const unsigned long long p2u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(p2 >> 32)) << 32) |
+                                           (unsigned)__builtin_amdgcn_readfirstlane((int)p2);
+            rs_bias = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p2u), 0, __builtin_amdgcn_readfirstlane(sg.n_vocab) * 4, 0x00020000);
+        }
+        // XB: tile t's biases into slot `slot` (every wave writes the same words: no branch on the wave number; words past the
+        // segment's end read 0 and are masked anyway)
+        auto issue_bias = [&](int t, int slot) {
+            if (!XB) return;
+#pragma unroll
+            for (int i = 0; i < (TW + 63) / 64; ++i)
+                if (i * 64 + 64 <= TW || lane < TW - i * 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, (__attribute__((address_space(3))) void *)(smem + BIAS_OFF + slot * (TW * 4) + i * 256),
+                                                             4, (t * TW + i * 64 + lane) * 4, 0, 0, 0);
+        };
         const int r8 = lane >> 3, dslot = lane & 7;
         const int drow = 8 * wave + r8;
         const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
@@ -227,13 +268,15 @@ struct MxWide {
         const int fbase = (li >> 3) * (NB * 1024) + (li & 7) * 128;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) goff[g4] = fbase + ((2 * g4 + hf) ^ x) * 16;
+        // pair 1 starts as a finished block of sixteen -1e30 logits: its fold leaves (m, s) = (very negative, 16), which the first
+        // real fold scales to 0 (as mx_body's v[])
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
+        for (int S = 0; S < RS; ++S) {
             m[S] = JLM_NEG_BIG; s[S] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { fb[S][r] = -1.0e30f; ib[S][r] = 0; fa[S][r] = 0.0f; ia[S][r] = 0; }
+            for (int r = 0; r < 16; ++r) { accf[1][S][r] = -1.0e30f; acci[1][S][r] = 0; accf[0][S][r] = 0.0f; acci[0][S][r] = 0; }
         }
-        // the first tile
+        // the first tile (and its biases: slot 0)
         {
             const int voff = dvoff + vt0 * (TW * ROWB);
 #pragma unroll
@@ -243,52 +286,82 @@ struct MxWide {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, voff + i * (32 * ROWB),
                                                          j * 128, 0, 0);
             }
+            issue_bias(vt0, 0);
+            // (XB: the dummy pair's "biases" -- slot 2 is read by the first block's combine before anything was written there)
+            if (XB && tid < TW) *reinterpret_cast<float *>(smem + BIAS_OFF + 2 * (TW * 4) + tid * 4) = 0.0f;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
+        for (int S = 0; S < RS; ++S) {
 #pragma unroll
             for (int q = 0; q < NS16; ++q) asm volatile("" : "+a"(thi[S][q]));
 #pragma unroll
             for (int j = 0; j < NB; ++j) { asm volatile("" : "+a"(thi8[S][j])); asm volatile("" : "+a"(tlo8[S][j])); }
         }
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         MXW_STAMP(1);
         int buf = 0;
-        auto tile = [&](auto masked_c, int t) {
+        int bs_prev = 2, bs_cur = 0, bs_next = 1;           // bias slots of the tile before, this tile, the next one
+        // P: the accumulator pair the tile's first block writes (an even number of blocks per tile: always 0)
+        auto tile = [&](auto masked_c, auto p_c, int t) {
             constexpr bool MASKED = decltype(masked_c)::value != 0;
+            constexpr int P = decltype(p_c)::value;
             const bool more = t + 1 < vt1;
             // (behind a sub-range's last tile: a descriptor of zero records -- the instructions stay in the stream, nothing is fetched)
             const __amdgpu_buffer_rsrc_t rs_next = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0, more ? nrec : 0, 0x00020000);
             const int voff_next = dvoff + (t + 1) * (TW * ROWB);
             const int lim = sg.n_vocab - t * TW;
+            if (more) issue_bias(t + 1, bs_next);
             {
                 const unsigned char *bs0 = smem + buf * BUFB;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) F[g4] = *reinterpret_cast<const i32x4 *>(bs0 + goff[g4]);
             }
-            mx_for_each_ic([&](auto hc) {
-                constexpr int mt0 = 2 * decltype(hc)::value;
-                // (the pairs treated in a tile's first block belong to the tile before -- whole -- or are the dummy: never masked)
-                if constexpr (mt0 == 0) block<false, mt0>(buf, lim, fa, ia, fb, ib, rs_next, voff_next, wave);
-                else block<MASKED, mt0>(buf, lim, fa, ia, fb, ib, rs_next, voff_next, wave);
-                block<MASKED, mt0 + 1>(buf, lim, fb, ib, fa, ia, rs_next, voff_next, wave);
-            }, std::make_integer_sequence<int, MTT / 2>{});
+            mx_for_each_ic([&](auto mc) {
+                constexpr int mt = decltype(mc)::value;
+                constexpr int W = (P + mt) & 1;
+                // (the pair treated in a tile's first block belongs to the tile before -- whole -- or is the dummy: never masked)
+                if constexpr (mt == 0) block<false, mt, W>(buf, lim, BIAS_OFF + bs_prev * (TW * 4) + (MTT - 1) * 128, rs_next, voff_next, wave);
+                else block<MASKED, mt, W>(buf, lim, BIAS_OFF + bs_cur * (TW * 4) + (mt - 1) * 128, rs_next, voff_next, wave);
+            }, std::make_integer_sequence<int, MTT>{});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(MXW_ABL & 8)) __builtin_amdgcn_s_barrier();
             buf ^= 1;
+            { const int o = bs_prev; bs_prev = bs_cur; bs_cur = bs_next; bs_next = o; }
             MXW_STAMP(2 + t - vt0);
         };
         const int t_full = min(vt1, sg.n_vocab / TW);
-        for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, t);
-        for (int t = max(vt0, t_full); t < vt1; ++t) tile(IC<1>{}, t);
+        int last_pair;                                       // the pair the last block wrote
+        if constexpr (MTT % 2 == 0) {
+            for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, IC<0>{}, t);
+            for (int t = max(vt0, t_full); t < vt1; ++t) tile(IC<1>{}, IC<0>{}, t);
+            last_pair = 1;
+        } else {
+            // an odd number of blocks per tile: the tiles alternate.  Whole tiles two at a time, then what is left (at most one whole
+            // tile and the segment's partial one)
+            int t = vt0, par = 0;
+            for (; t + 1 < t_full; t += 2) { tile(IC<0>{}, IC<0>{}, t); tile(IC<0>{}, IC<1>{}, t + 1); }
+            for (; t < vt1; ++t) {
+                const bool whole = t < t_full;
+                if (par == 0) { if (whole) tile(IC<0>{}, IC<0>{}, t); else tile(IC<1>{}, IC<0>{}, t); }
+                else { if (whole) tile(IC<0>{}, IC<1>{}, t); else tile(IC<1>{}, IC<1>{}, t); }
+                par ^= 1;
+            }
+            last_pair = (par + MTT) & 1;                    // (par = pair of the NEXT tile's first block; MTT odd: the last tile started on par ^ 1)
+        }
         {
             const int lim_last = sg.n_vocab - (vt1 - 1) * TW;
+            load_bias(BIAS_OFF + bs_prev * (TW * 4) + (MTT - 1) * 128);
+            if (last_pair) {
 #pragma unroll
-            for (int pc = 0; pc < NPIECE; ++pc) fold2<true>(fb, ib, MTT - 1, lim_last, pc);
+                for (int pc = 0; pc < NPIECE; ++pc) fold2(true, 1, MTT - 1, lim_last, pc);
+            } else {
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) fold2(true, 0, MTT - 1, lim_last, pc);
+            }
         }
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
+        for (int S = 0; S < RS; ++S) {
             const float m2 = __shfl_xor(m[S], 32), s2 = __shfl_xor(s[S], 32);
             const float mm = fmaxf(m[S], m2);
             const float ss = s[S] * __builtin_amdgcn_exp2f(m[S] - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
@@ -299,7 +372,7 @@ struct MxWide {
 };
 
 // (out of line: hosted inline, the three bodies of the D-softmax* kernel cost each other 64 spilled registers, some inside the tile loops)
-template <int NB, int NS16>
+template <int NB, int NS16, int RS, bool XB>
 __device__ __noinline__ void mxw_body(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm, float2 *prow,
                                       unsigned char *smem) {
     // (arguments of a real call arrive in vector registers: make the wave-uniform ones provably uniform again -- loop counters,
@@ -314,26 +387,26 @@ __device__ __noinline__ void mxw_body(const MxSeg &sg, int vt0, int vt1, int pt,
     u.n_vocab = uni(sg.n_vocab); u.k = uni(sg.k); u.t_off = uni(sg.t_off); u.nb = uni(sg.nb); u.tm_off = uni(sg.tm_off); u.seg = uni(sg.seg);
     u.descale = __int_as_float(uni(__float_as_int(sg.descale)));
     u.cs = __int_as_float(uni(__float_as_int(sg.cs)));
-    u.bias2 = nullptr;
-    MxWide<NB, NS16, mx_blocks_per_tile(NB)> w;
+    u.bias2 = static_cast<const float *>(unip(sg.bias2));
+    MxWide<NB, NS16, mx_blocks_per_tile(NB), RS, XB> w;
     w.run(u, uni(vt0), uni(vt1), uni(pt), uni(n_paths), static_cast<const unsigned char *>(unip(Tm)), uni(ld_tm),
           static_cast<float2 *>(const_cast<void *>(unip(prow))), static_cast<unsigned char *>(const_cast<void *>(unip(smem))));
 }
 
-template <int... SH>      // SH = NB0, NS0, NB1, NS1, ...
+template <int RS, bool XB, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
 struct MxwDispatch;
-template <>
-struct MxwDispatch<> {
+template <int RS, bool XB>
+struct MxwDispatch<RS, XB> {
     static __device__ __forceinline__ void run(const MxSeg &, int, int, int, int, int, const unsigned char *, int, float2 *, unsigned char *) {}
 };
-template <int NB, int NS16, int... REST>
-struct MxwDispatch<NB, NS16, REST...> {
+template <int RS, bool XB, int NB, int NS16, int... REST>
+struct MxwDispatch<RS, XB, NB, NS16, REST...> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int ns16, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                                float2 *prow, unsigned char *smem) {
         if (sg.nb == NB && ns16 == NS16) {
-            mxw_body<NB, NS16>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+            mxw_body<NB, NS16, RS, XB>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
         } else {
-            MxwDispatch<REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+            MxwDispatch<RS, XB, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
         }
     }
 };
@@ -349,38 +422,44 @@ static __device__ unsigned long long jlm_prof_wg_mxw[1024][4];
 #define MXW_WG_T1
 #endif
 
-template <int... SH>
+template <int RS, bool XB, int... SH>
 __global__ __launch_bounds__(256, 1) void vocab_lse_mixedw_kernel(MxArgs a, const unsigned char *__restrict__ Tm, int ld_tm, float2 *__restrict__ part,
                                                                   int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mxw_smem[];
+    constexpr int RW = 128 * RS;
     const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
     const int b = blockIdx.x;
     int p, pt;
     const int nb8 = (a.n_cols & ~7) * n_ptiles;
     if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
     else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
-    if (p >= a.n_cols || pt * 256 >= n_paths) return;
+    if (p >= a.n_cols || pt * RW >= n_paths) return;
     MXW_WG_T0
     for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
         const MxSeg sg = a.seg[a.sub_seg[r]];
         const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
         float2 *prow = part + (size_t)r * ld_part;
         if (r != a.col_first[p]) __syncthreads();
-        const int ns16 = (sg.k + 2 + 15) >> 4;
+        const int ns16 = XB ? 2 * sg.nb : (sg.k + 2 + 15) >> 4;
 #ifdef JLM_WGTIME
         si_last = a.sub_seg[r];
 #endif
-        MxwDispatch<SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mxw_smem);
+        MxwDispatch<RS, XB, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mxw_smem);
     }
     MXW_WG_T1
 }
-#define MXW_KERNEL_DSOFTMAX vocab_lse_mixedw_kernel<7, 13, 4, 7, 2, 4>
+// the shapes of BASELINE configs[1] (D-softmax* 200 / 100 / 50), two row sets per wave
+#define MXW_KERNEL_DSOFTMAX vocab_lse_mixedw_kernel<2, false, 7, 13, 4, 7, 2, 4>
+// a contraction of 512 (untied models at H = 512: the vocabulary matrix itself): sixteen 32-k blocks = 256 accumulation registers of
+// row operands, one row set per wave, external biases
+#define MXW_KERNEL_K512 vocab_lse_mixedw_kernel<1, true, 16, 32>
+
 
 #ifdef JLM_MX_RESOURCES
-#define MXW_RES(NB_, NS_) __global__ __launch_bounds__(256, 1) void mxw_res_##NB_##_##NS_(MxSeg sg, const unsigned char *Tm, int ld_tm, float2 *part) { \
-        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; MxWide<NB_, NS_, mx_blocks_per_tile(NB_)> w; \
+#define MXW_RES(NB_, NS_, RS_, XB_) __global__ __launch_bounds__(256, 1) void mxw_res_##NB_##_##NS_(MxSeg sg, const unsigned char *Tm, int ld_tm, float2 *part) { \
+        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; MxWide<NB_, NS_, mx_blocks_per_tile(NB_), RS_, XB_> w; \
         w.run(sg, 0, 100, blockIdx.x, 2560, Tm, ld_tm, part, sm_); }
-MXW_RES(2, 4) MXW_RES(4, 7) MXW_RES(7, 13)
+MXW_RES(2, 4, 2, false) MXW_RES(4, 7, 2, false) MXW_RES(7, 13, 2, false) MXW_RES(16, 32, 1, true)
 #endif
 
 }  // namespace
@@ -391,15 +470,20 @@ extern "C" int jlm_prof_read_wg_mxw(unsigned long long *out) {
 }
 #endif
 
-// Launch of the wide kernel for the shapes it hosts (the D-softmax* 200 / 100 / 50 model: every segment in the bias-column form
-// with (nb, f16 steps) in {(7, 13), (4, 7), (2, 4)}); called by jlm_vocab_lse_mixed (jlm_mixed.hip) with its column cuts.
+// Launch of the wide kernel for the shapes it hosts; called by jlm_vocab_lse_mixed (jlm_mixed.hip) with its column cuts.
+//   which 0: the D-softmax* 200 / 100 / 50 model (every segment in the bias-column form with (nb, f16 steps) in {(7, 13), (4, 7), (2, 4)}),
+//            256 rows per workgroup;
+//   which 1: ONE segment of k = 512 in the external-bias form (nb = 16), 128 rows per workgroup.
 // Returns 0, or -3 (LDS grant) / a negative HIP error like its caller.
-int jlm_mx_wide_launch(const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
+int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
                        int lds, hipStream_t st) {
-    static JlmLdsGrant grant;
-    if (int rc = jlm_grant_lds(grant, reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX), lds)) return rc;
-    hipLaunchKernelGGL(MXW_KERNEL_DSOFTMAX, dim3(a.n_cols * n_ptiles), dim3(256), lds, st, a, reinterpret_cast<const unsigned char *>(Tm), ld_tm, part,
-                       ld_part, n_rows_max, n_dev, n_ptiles);
+    static JlmLdsGrant grant[2];
+    const void *fn = which == 0 ? reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX) : reinterpret_cast<const void *>(MXW_KERNEL_K512);
+    if (int rc = jlm_grant_lds(grant[which], fn, lds)) return rc;
+    const dim3 grid(a.n_cols * n_ptiles), block(256);
+    const unsigned char *tm = reinterpret_cast<const unsigned char *>(Tm);
+    if (which == 0) hipLaunchKernelGGL(MXW_KERNEL_DSOFTMAX, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else hipLaunchKernelGGL(MXW_KERNEL_K512, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return 0;

@@ -143,7 +143,8 @@ struct JlmModel : torch::CustomClassHolder {
         }
         if (!mixed_idx.empty()) {
             const size_t n = mixed_idx.size();
-            TORCH_CHECK(!split.v.empty() && mixed_some.v.size() == n && mixed_t_scale.size() == n && mixed_descale.size() == n &&
+            // (an untied model has no rows-stationary split table: its one segment, k = H, is checked against the f32 segment)
+            TORCH_CHECK((!split.v.empty() || m.untied) && mixed_some.v.size() == n && mixed_t_scale.size() == n && mixed_descale.size() == n &&
                             mixed_s8.size() == n,
                         "jlm.Model: mixed segments need the split table and one block / scale / descale / s8 each");
             jlm_segment none{};
@@ -152,7 +153,7 @@ struct JlmModel : torch::CustomClassHolder {
             for (size_t j = 0; j < n; ++j) {
                 const int64_t si = mixed_idx[j];
                 TORCH_CHECK(si >= 0 && si < (int64_t)segs.v.size() && !mixed[si].B, "jlm.Model: bad mixed segment index");
-                const jlm_segment &a = mixed_some.v[j], &b = split.v[si];
+                const jlm_segment &a = mixed_some.v[j], &b = split.v.empty() ? segs.v[si] : split.v[si];
                 TORCH_CHECK(a.v_start == b.v_start && a.v_end == b.v_end && a.k == b.k && a.t_off == b.t_off,
                             "jlm.Model: a mixed segment must describe the same words and T columns as its split form");
                 TORCH_CHECK(mixed_some.keep[j].numel() >= (int64_t)(a.v_end - a.v_start) * a.ldb, "jlm.Model: mixed block too small");

@@ -342,6 +342,7 @@ class DeviceModel:
                 self.um_split = torch.zeros((self.V, self.H), dtype=torch.float32, device=self.device)
                 O.pack_split_f16(self.seg_B[0], 0, self.V, self.H, self.H, float(2.0 ** eU), self.um_split, 0, self.H)
                 self.um_descale = 2.0 ** -(14 + eU)
+                self._build_mixed_untied(pow2_below)
             if self.split_lstm:
                 H = self.H
                 wh = self._wmax[0]
@@ -412,7 +413,8 @@ class DeviceModel:
 
         # (round 5, ADVICE) a model the probe cannot run on -- no split LSTM step, no projection panel -- must not keep the int8
         # planes on the spread gate alone (that gate misses peaked logits): it stays on split rows
-        if not self.split_lstm or self.pmt_split is None or self.mode == "untied":
+        untied = self.mode == "untied"
+        if not self.split_lstm or (untied and self.um_split is None) or (not untied and self.pmt_split is None):
             return drop("the load-time probe does not cover this model (no split LSTM step / projection panel): split rows")
         torch, O = self.torch, _ops.backend()
         R, S, H = self.CALIB_ROWS, self.CALIB_STEPS, self.H
@@ -423,7 +425,7 @@ class DeviceModel:
         dev = self.device
         i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
         rowlist, prev, word = i32(np.arange(G)), i32(np.arange(G) - R), i32(word)
-        max_parts = 128
+        max_parts = max(128, (self.V + 127) // 128 + 1)      # (form 0 of an untied model: one slice per 128-word tile)
         dm = self.decode_model()
         lse = []
         with self._ctx():
@@ -532,6 +534,37 @@ class DeviceModel:
         nbytes = sum(msg["ldb"] * 4 for msg in self.mixed_segments) + 4 * 8
         self.ld_tm = (nbytes + 15) // 16 * 4
 
+    def _build_mixed_untied(self, pow2_below):
+        """Round 5: an untied model's vocabulary matrix UM^T [V, H] as mixed rows when H = 512 -- sixteen 32-k blocks per word, no
+        bias columns (the biases x log2 e go to the kernel separately) -- for jlm_vocab_lse_mixed's wide one-row-set form
+        (csrc/jlm_mixed_w.hip: the hypothesis rows' operands fill a wave's 256 accumulation registers).  The hypothesis side is
+        the state itself (model.py:189-191; |h| < 1: 2^eT = 2^14).  Same gates as ``_build_mixed``: JLM_LSE_MIXED=0, the blocks'
+        spread, then the load-time calibration (``_calibrate_mixed``)."""
+        if os.environ.get("JLM_LSE_MIXED", "1") == "0" or self.self_norm or self.H != 512 or self.n_segs != 1:
+            return
+        torch, O = self.torch, _ops.backend()
+        sg, blk = self.segments[0], self.seg_B[0]
+        nv, k = sg["v_end"] - sg["v_start"], sg["k"]
+        if k != self.H or nv <= 0 or nv * 16 * 128 >= (1 << 31):
+            return
+        rms = float(blk.pow(2).mean().sqrt().item())
+        self.mixed_spread = [float(blk.abs().max().item()) / rms if rms > 0.0 else float("inf")]
+        if self.mixed_spread[0] > float(os.environ.get("JLM_MIXED_MAX_SPREAD", "8")):
+            return
+        LOG2E = 1.4426950408889634
+        nb = k // 32
+        eB = pow2_below(2.0 ** 14, float(blk.abs().max().item()))
+        hmax = float((blk * float(2.0 ** eB)).to(torch.float16).to(torch.float32).abs().max().item())
+        s8 = 2.0 ** int(np.ceil(np.log2(max(hmax, 2.0 ** -100) / 127.0)))
+        eT = pow2_below(2.0 ** 15, LOG2E)
+        dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device=self.device)
+        O.pack_mixed(blk, 0, nv, k, sg["ldb"], self.b2, sg["v_start"], float(2.0 ** eB), float(2.0 ** eB * LOG2E), float(s8), dst, 32 * nb)
+        self.mixed_idx, self.seg_mixed = [0], [dst]
+        self.mixed_segments = [dict(v_start=sg["v_start"], v_end=sg["v_end"], k=k, t_off=sg["t_off"], ldb=32 * nb)]
+        self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [2.0 ** eT], [2.0 ** -(eT + eB)], [s8]
+        self.b2_log2 = (self.b2 * LOG2E).contiguous()
+        self.ld_tm = (32 * nb * 4 + 4 * 8 + 15) // 16 * 4
+
     def _ctx(self):
         """every launch of this model happens with ITS device current (streams, events and the launches of the HIP runtime
         follow the current device, not the tensors')"""
@@ -569,7 +602,7 @@ class DeviceModel:
                       [float(x) for x in self.split_descale], [int(x) for x in self.split_bias_col])
             else:
                 sp = ([], [], [], [], [])
-            if self.split_array is not None and getattr(self, "mixed_idx", None):
+            if (self.split_array is not None or self.mode == "untied") and getattr(self, "mixed_idx", None):
                 mx = ([int(x) for x in self.mixed_idx], list(self.seg_mixed), meta(self.mixed_segments),
                       [float(x) for x in self.mixed_t_scale], [float(x) for x in self.mixed_descale], [float(x) for x in self.mixed_s8])
             else:

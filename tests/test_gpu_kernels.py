@@ -751,7 +751,9 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
 @pytest.mark.parametrize("V,widths,bounds,R", [(3000, [200, 100, 52], [0, 700, 1900, 3000], 300), (50000, [200, 100, 52], [0, 12000, 30000, 50000], 2560),
                                                (777, [60], [0, 777], 40), (5000, [252], [0, 5000], 513), (1000, [4, 36], [0, 300, 1000], 33),
                                                # contractions that fill their last block: biases from bias2 (tied k = 256; k = 128 / 64)
-                                               (50000, [256], [0, 50000], 2560), (4001, [256], [0, 4001], 300), (3000, [128, 64], [0, 1700, 3000], 70)])
+                                               (50000, [256], [0, 50000], 2560), (4001, [256], [0, 4001], 300), (3000, [128, 64], [0, 1700, 3000], 70),
+                                               # k = 512 (an untied model's vocabulary matrix at H = 512): the wide kernel's one-row-set form, 128 rows per workgroup
+                                               (4001, [512], [0, 4001], 300), (50000, [512], [0, 50000], 2560), (777, [512], [0, 777], 129)])
 def test_vocab_lse_mixed(L, V, widths, bounds, R):
     """jlm_vocab_lse_mixed (f16 hi.hi + int8 cross terms, csrc/jlm_mixed.hip): log-sum-exp of T.B^T + b2 over the vocabulary
     against the f64 evaluation of the f32 operands; the logits behind it are good to ~1e-5 of the row's logit scale (a one-word

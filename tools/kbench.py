@@ -310,6 +310,7 @@ if __name__ == "__main__":
         bench_lse_split(50000, [256], R, "tied50k")
         bench_lse_mixed(50000, [252], R, "tied50k")          # (the widest contraction with room for the bias columns: nb = 8)
         bench_lse_mixed(50000, [256], R, "tied50k")          # the tied shape: biases from bias2
+        bench_lse_mixed(50000, [512], R, "untied50k")        # k = 512: the wide kernel's one-row-set form (an untied model's vocabulary matrix)
         bench_lse(12000, 200, R, "seg0")
         bench_lse(18000, 100, R, "seg1")
         bench_lse(20000, 50, R, "seg2")
