@@ -36,7 +36,7 @@
 using namespace jlm_mx;
 
 #ifndef JLM_MX_WIDE_DEFAULT
-#define JLM_MX_WIDE_DEFAULT 0
+#define JLM_MX_WIDE_DEFAULT -1
 #endif
 
 namespace {
@@ -483,8 +483,11 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
         if (int rc = jlm_mx_wide_launch(1, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
         return n_sub;
     }
-    if (which == 0 && wide) {
-        if (int rc = jlm_mx_wide_launch(0, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+    // JLM_MX_WIDE: 1 the wide kernel (jlm_mixed_w.hip) for every shape it hosts, 0 never, -1 (default) where it measures faster: the tied
+    // k = 256 shapes -- 116.6-118.0 vs 122.7-124.5 us at V = 50 k / 2 560 rows, 1 691 vs 1 813 us at V = 100 k / 20 480 rows; the
+    // D-softmax* launch measures the same on both (70.5 vs 70.0 us) and stays on the eight-wave kernel (profiles/r05_r_wide_tied.txt)
+    if ((which == 0 && wide > 0) || (which == 2 && wide != 0)) {
+        if (int rc = jlm_mx_wide_launch(which, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
         return n_sub;
     }
     static JlmLdsGrant grant[4];

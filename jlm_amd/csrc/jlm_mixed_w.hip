@@ -453,6 +453,8 @@ __global__ __launch_bounds__(256, 1) void vocab_lse_mixedw_kernel(MxArgs a, cons
 // a contraction of 512 (untied models at H = 512: the vocabulary matrix itself): sixteen 32-k blocks = 256 accumulation registers of
 // row operands, one row set per wave, external biases
 #define MXW_KERNEL_K512 vocab_lse_mixedw_kernel<1, true, 16, 32>
+// the tied k = 256 models (BASELINE configs[2..4]) with two row sets per wave: 2 x 128 = all 256 accumulation registers (JLM_MX_WIDE=1: A/B)
+#define MXW_KERNEL_TIED vocab_lse_mixedw_kernel<2, true, 8, 16>
 
 
 #ifdef JLM_MX_RESOURCES
@@ -473,17 +475,20 @@ extern "C" int jlm_prof_read_wg_mxw(unsigned long long *out) {
 // Launch of the wide kernel for the shapes it hosts; called by jlm_vocab_lse_mixed (jlm_mixed.hip) with its column cuts.
 //   which 0: the D-softmax* 200 / 100 / 50 model (every segment in the bias-column form with (nb, f16 steps) in {(7, 13), (4, 7), (2, 4)}),
 //            256 rows per workgroup;
-//   which 1: ONE segment of k = 512 in the external-bias form (nb = 16), 128 rows per workgroup.
+//   which 1: ONE segment of k = 512 in the external-bias form (nb = 16), 128 rows per workgroup;
+//   which 2: segments of k = 256 in the external-bias form (nb = 8), 256 rows per workgroup.
 // Returns 0, or -3 (LDS grant) / a negative HIP error like its caller.
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
                        int lds, hipStream_t st) {
-    static JlmLdsGrant grant[2];
-    const void *fn = which == 0 ? reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX) : reinterpret_cast<const void *>(MXW_KERNEL_K512);
+    static JlmLdsGrant grant[3];
+    const void *fn = which == 0 ? reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX) : which == 1 ? reinterpret_cast<const void *>(MXW_KERNEL_K512)
+                                                                                                : reinterpret_cast<const void *>(MXW_KERNEL_TIED);
     if (int rc = jlm_grant_lds(grant[which], fn, lds)) return rc;
     const dim3 grid(a.n_cols * n_ptiles), block(256);
     const unsigned char *tm = reinterpret_cast<const unsigned char *>(Tm);
     if (which == 0) hipLaunchKernelGGL(MXW_KERNEL_DSOFTMAX, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
-    else hipLaunchKernelGGL(MXW_KERNEL_K512, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else if (which == 1) hipLaunchKernelGGL(MXW_KERNEL_K512, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else hipLaunchKernelGGL(MXW_KERNEL_TIED, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return 0;
