@@ -49,7 +49,7 @@ CONFIG5_SENTENCES = 8192
 def kernel_source_sha256():
     """Identity of the kernels the committed PMC traffic figure was measured on (profiles/traffic_latest.json)."""
     h = hashlib.sha256()
-    for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_body.h", "jlm_common.h"):
+    for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_w.hip", "jlm_mixed_body.h", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -231,6 +231,9 @@ def main():
             kname = ("vocab_lse_mixedw_kernel<1, true, 16, 32> (jlm_vocab_lse_mixed: the wide one-row-set form for k = 512, csrc/jlm_mixed_w.hip; rows "
                      "packed by pack_t_mixed_kernel from the state's f32 copy)" if (mixed and getattr(m, "um_split", None) is not None) else
                      "gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
+                     "vocab_lse_mixedw_kernel<2, true, 8, 16> (jlm_vocab_lse_mixed: the wide form -- four waves x 64 rows, row operands in accumulation "
+                     "registers, csrc/jlm_mixed_w.hip; rows packed by pack_t_mixed_kernel behind the T projection)"
+                     if (mixed and m.n_segs == 1 and m.segments[0]["k"] == 256 and os.environ.get("JLM_MX_WIDE", "-1") != "0") else
                      "vocab_lse_mixed_kernel (jlm_vocab_lse_mixed; its rows packed by pack_t_mixed_kernel behind the T projection)" if mixed else
                      "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
