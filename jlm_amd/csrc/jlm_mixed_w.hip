@@ -78,6 +78,7 @@ struct MxWide {
 
     // one piece of the treatment of the finished pair (pf, pi) of row set S
     __device__ __forceinline__ void fold_piece(const bool MASKED, int S, f32x16 &pf, const i32x16 &pi, int mtp, int lim, int pc) {
+#pragma clang fp contract(off)          // every fused multiply-add below is written as one: the row sets must round alike
         if (pc < 16) {
             const int r = pc;
             float y = fmaf((float)pi[r], csr[S], pf[r]);
@@ -99,7 +100,9 @@ struct MxWide {
             const float e = (MXW_ABL & 2) ? x : __builtin_amdgcn_exp2f(x);
             if (r & 1) add1[S] += e; else add0[S] += e;
         } else if (pc == 41) {
-            s[S] = s[S] * sc_old[S] + (add0[S] + add1[S]);
+            // (an explicit fma: left to the compiler the two row sets got different contractions -- set 1 a fused multiply-add, set 0 not --
+            //  and identical rows 1-ulp different sums depending on the set they sat in: tools/probes/wide_identical_rows.py)
+            s[S] = fmaf(s[S], sc_old[S], add0[S] + add1[S]);
         }
     }
     // pieces alternate between the row sets: piece RS q + S -> set S piece q
@@ -364,7 +367,7 @@ struct MxWide {
         for (int S = 0; S < RS; ++S) {
             const float m2 = __shfl_xor(m[S], 32), s2 = __shfl_xor(s[S], 32);
             const float mm = fmaxf(m[S], m2);
-            const float ss = s[S] * __builtin_amdgcn_exp2f(m[S] - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+            const float ss = fmaf(s[S], __builtin_amdgcn_exp2f(m[S] - mm), s2 * __builtin_amdgcn_exp2f(m2 - mm));
             if (hf == 0 && row_ok[S]) part_row[prow[S]] = make_float2(mm * LN2, ss);
         }
         MXW_STAMP(63);

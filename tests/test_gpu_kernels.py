@@ -748,6 +748,34 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
     return segs, ts, ds, s8, Bs, keep, off, b2
 
 
+@pytest.mark.parametrize("V,widths,bounds,R,maxp", [(2000, [200, 100, 52], [0, 700, 1300, 2000], 48, 16), (2000, [200, 100, 52], [0, 700, 1300, 2000], 300, 96),
+                                                    (3000, [256], [0, 3000], 200, 24), (1500, [512], [0, 1500], 130, 12)])
+def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp):
+    """Round 5: IDENTICAL hypothesis rows (frame 0 of every decode: all sentences leave the <eos> state) must get bit-identical slices
+    whichever wave, row set or lane of the kernel they land in -- the order of a frame's live rows is not deterministic, so a
+    kernel that rounds one row set differently from the other (the wide kernel did: one set's `s * scale + sum` was contracted
+    into an fma, the other's was not) makes scores differ from run to run in their last bits.  Covers the eight-wave kernel, the
+    wide kernel's two-row-set form (tied k = 256 by default; every shape under JLM_MX_WIDE=1) and its one-row-set form (k = 512)."""
+    import ctypes
+    rng = np.random.default_rng(V + R)
+    b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    b2l = (b2 * 1.4426950408889634).contiguous()
+    bias2 = b2l.data_ptr() if widths[0] % 32 == 0 else None
+    T = torch.as_tensor(np.tile((np.tanh(rng.standard_normal((1, ldt))) * 0.7).astype(np.float32), (R, 1))).cuda()
+    nd = torch.as_tensor(np.array([R], dtype=np.int32)).cuda()
+    ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
+    part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
+    assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, None, R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
+    n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, maxp, R, nd.data_ptr(), _st())
+    assert n >= len(widths), n
+    torch.cuda.synchronize()
+    p = part[:n].cpu().numpy()
+    odd = np.argwhere((p != p[:, :1]).any(axis=2))
+    assert len(odd) == 0, ("rows that differ from row 0 (slice, row):", odd[:8].tolist())
+
+
 @pytest.mark.parametrize("V,widths,bounds,R", [(3000, [200, 100, 52], [0, 700, 1900, 3000], 300), (50000, [200, 100, 52], [0, 12000, 30000, 50000], 2560),
                                                (777, [60], [0, 777], 40), (5000, [252], [0, 5000], 513), (1000, [4, 36], [0, 300, 1000], 33),
                                                # contractions that fill their last block: biases from bias2 (tied k = 256; k = 128 / 64)
