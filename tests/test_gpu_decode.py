@@ -35,7 +35,9 @@ def _decoder(f, kind):
 TIE_REL = 1e-6        # two hypotheses whose reference scores are this close (relative) may come out in either order
 
 
-SCORE_ATOL_PER_FRAME = 1e-6
+# (JLM_PRECISION=f32 -- plain f32 accumulation on the f32 matrix pipe, a supported knob -- holds 1.5e-6 per frame: 2.4e-5 measured on
+#  peaked20-tied/dynamic at L = 20 where the default split-f16 path holds 1.1e-5; the knob sweep, tools/gpu_knobs.sh, runs this file under it)
+SCORE_ATOL_PER_FRAME = 1.5e-6 if os.environ.get("JLM_PRECISION", "f16x3") == "f32" else 1e-6
 SCORE_ATOL_FLOOR = 2e-6
 
 
