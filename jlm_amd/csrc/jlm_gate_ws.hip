@@ -1,5 +1,5 @@
-// jlm_gate_ws.hip -- the fused LSTM step of the decode, W-stationary persistent form (round 4; jlm_lstm_step_xg's default
-// at H = 512: csrc/jlm_gate.hip picks).  Reference: decoder/model.py:125-139 with the state gather of decoder/decoder.py:206-218.
+// jlm_gate_ws.hip -- the fused LSTM step of the decode, W-stationary persistent form (round 4; what jlm_lstm_step_xg launches at
+// H = 512 from 16 384 rows on: csrc/jlm_gate.hip picks by the launch's row bound).  Reference: decoder/model.py:125-139 with the state gather of decoder/decoder.py:206-218.
 //
 // Its own translation unit because it is compiled with  -mllvm -amdgpu-mfma-vgpr-form : the wave's 256 accumulation registers hold
 // its slice of the gate matrix for the whole kernel, so the MFMA accumulators must live in the architectural VGPRs -- left to its

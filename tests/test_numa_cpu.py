@@ -28,6 +28,9 @@ def test_cpulist_and_worker_cpus(tmp_path, monkeypatch):
     assert numa.worker_cpus(1, sysfs=root, pci_bus_id="0000:C5:00.0", allowed=allowed) == (1, set(range(8, 16)) | {24, 25, 26, 27})
     assert numa.worker_cpus(2, sysfs=root, pci_bus_id="0000:e5:00.0", allowed=allowed) == (-1, set())      # the kernel does not know
     assert numa.worker_cpus(3, sysfs=root, pci_bus_id="0000:ff:00.0", allowed=allowed) == (-1, set())      # no such device
+    # a process mask that only grazes the GPU's node: pinning would crowd the workers onto a CPU or two -- left unpinned
+    assert numa.worker_cpus(0, sysfs=root, pci_bus_id="0000:05:00.0", allowed={4, 5, 8, 9, 10, 11}) == (0, set())
+    assert numa.worker_cpus(0, sysfs=root, pci_bus_id="0000:05:00.0", allowed={4, 5, 8, 9, 10, 11}, min_cpus=2) == (0, {4, 5})
     monkeypatch.setenv("JLM_NUMA_PIN", "0")
     assert numa.worker_cpus(0, sysfs=root, pci_bus_id="0000:05:00.0", allowed=allowed) == (-1, set())
 
