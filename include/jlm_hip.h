@@ -347,6 +347,13 @@ int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_s
 int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
                         const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
                         const int *n_dev, void *stream);
+/* ABI 9: the same launch WITHOUT a running maximum where a kernel form for it exists (the wide kernel's tied k = 256 and k = 512 forms;
+ * every other shape runs exactly as jlm_vocab_lse_mixed): s = sum over the words of 2^(base-2 logit) against the fixed reference 0, slices
+ * (0, s) -- three VALU instructions per logit less.  Valid while every row's largest logit stays within about +-69 (base-2: +-100: f32
+ * range over 2^16 words); a row outside it comes back as s = 0 or inf.  The caller decides per model (jlm_decode_model.lse_fixed_ref). */
+int jlm_vocab_lse_mixed_fr(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
+                        const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                        const int *n_dev, void *stream);
 
 /* One launch over segments of BOTH formats (csrc/jlm_split.hip, vocab_lse_hybrid_kernel): mixed[i].B != NULL runs segment i on
  * its mixed rows (mixed[i].ldb = 32 nb; mx_descale[i], mx_s8[i] as for jlm_vocab_lse_mixed; Tm = rows packed by
@@ -409,6 +416,9 @@ typedef struct {
     /* untied model on split rows (ABI 4; untied_split != NULL): the vocabulary matrix UM^T [V, H] as split rows scaled by
      * 2^eB, untied_descale = 2^-(14 + eB); the state rows plan.h are split rows then, plan.T their plain f32 copy */
     const void *untied_split; float untied_descale;
+    /* ABI 9: 1 = the full-vocabulary normaliser on mixed rows runs jlm_vocab_lse_mixed_fr (no running maximum): set by the loader when
+     * the model's own log-normalisers (load-time probe) sit well inside the f32 range */
+    int lse_fixed_ref;
     /* T projection: [n_t, H] panel, plain or split rows */
     const float *pmt; const void *pmt_split; int n_t; float t_descale;
     /* full-vocabulary normaliser: split segments (NULL: f32 rows-stationary form) */

@@ -41,7 +41,7 @@ class DecodeModel(Structure):
                 ("untied", c_int), ("self_norm", c_int), ("split_lstm", c_int),
                 ("emb", c_void_p), ("ld_emb", c_int), ("wt", c_void_p), ("gate_bias", c_void_p), ("kpad", c_int), ("E", c_int),
                 ("gate_descale", c_float), ("h_scale", c_float),
-                ("wt8", c_void_p), ("xgate8", c_void_p), ("untied_split", c_void_p), ("untied_descale", c_float),
+                ("wt8", c_void_p), ("xgate8", c_void_p), ("untied_split", c_void_p), ("untied_descale", c_float), ("lse_fixed_ref", c_int),
                 ("pmt", c_void_p), ("pmt_split", c_void_p), ("n_t", c_int), ("t_descale", c_float),
                 ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
                 ("split_bias_col", POINTER(c_int)),
@@ -97,6 +97,9 @@ _SIGS = {
     "jlm_mixed_t_stride": ([POINTER(Segment), c_int], c_int),
     "jlm_pack_t_mixed": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
     "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
+                            c_int),
+    "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
+    "jlm_vocab_lse_mixed_fr": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
                             c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),

@@ -208,9 +208,9 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                     if (c < cap) cap = c;
                 }
                 int r = -2;
-                if (all_mixed)      // every segment on mixed rows
-                    r = jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, m->n_segs, p->Tm, p->ld_tm, p->part, rmax, cap,
-                                            bound, ndev, stream);
+                if (all_mixed)      // every segment on mixed rows (lse_fixed_ref: without a running maximum where the kernel has such a form)
+                    r = (m->lse_fixed_ref ? jlm_vocab_lse_mixed_fr : jlm_vocab_lse_mixed)(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2,
+                                                                                         m->n_segs, p->Tm, p->ld_tm, p->part, rmax, cap, bound, ndev, stream);
                 else if (hybrid)    // -2: a shape the hybrid kernel does not host -- the split rows of every segment exist
                     r = jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs,
                                              m->mixed_descale, m->mixed_s8, m->n_segs, m->b2, p->T, m->ldt, p->Tm, p->ld_tm, rows,

@@ -345,9 +345,9 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
                        int n_ptiles, int lds, hipStream_t st);
 
-extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
-                                   const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
-                                   const int *n_dev, void *stream) {
+static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
+                                const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                                const int *n_dev, void *stream, int fixed_ref) {
     const int *rows = nullptr;                       // the packed rows are compact (jlm_pack_t_mixed)
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || n_rows_max <= 0 || ld_tm != jlm_mixed_t_stride(segs_host, n_segs)) return -1;
     const float *T = reinterpret_cast<const float *>(Tm);
@@ -479,15 +479,21 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     hipStream_t st = (hipStream_t)stream;
     static int wide = -1;
     if (wide < 0) { const char *e = getenv("JLM_MX_WIDE"); wide = e ? atoi(e) : JLM_MX_WIDE_DEFAULT; }
+    // fixed_ref (jlm_vocab_lse_mixed_fr): the wide kernel's forms WITHOUT a running maximum -- s = sum 2^y against the reference 0, slices
+    // (0, s) -- where a form exists (tied k = 256, k = 512); any other shape runs as usual.  -3 % on those launches (113.5 vs 117 us,
+    // 1 589 vs 1 634 us at configs[2]'s shape: profiles/r05_u_fixed_ref.txt).  Valid while a row's largest base-2 logit stays within
+    // +-100 or so (f32 range, 2^16 words): the caller's decision (DeviceModel measures its model at load); a row outside it yields s = 0 or
+    // inf, never a plausible number.
+    const int fixref = fixed_ref;
     if (rows_wg == 128) {
-        if (int rc = jlm_mx_wide_launch(1, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+        if (int rc = jlm_mx_wide_launch(fixref ? 3 : 1, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
         return n_sub;
     }
     // JLM_MX_WIDE: 1 the wide kernel (jlm_mixed_w.hip) for every shape it hosts, 0 never, -1 (default) where it measures faster: the tied
     // k = 256 shapes -- 116.6-118.0 vs 122.7-124.5 us at V = 50 k / 2 560 rows, 1 691 vs 1 813 us at V = 100 k / 20 480 rows; the
     // D-softmax* launch measures the same on both (70.5 vs 70.0 us) and stays on the eight-wave kernel (profiles/r05_r_wide_tied.txt)
     if ((which == 0 && wide > 0) || (which == 2 && wide != 0)) {
-        if (int rc = jlm_mx_wide_launch(which, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
+        if (int rc = jlm_mx_wide_launch(which == 2 && fixref ? 4 : which, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
         return n_sub;
     }
     static JlmLdsGrant grant[4];
@@ -504,4 +510,16 @@ extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *de
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return n_sub;
+}
+
+extern "C" int jlm_vocab_lse_mixed(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
+                                   const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                                   const int *n_dev, void *stream) {
+    return vocab_lse_mixed_impl(segs_host, descale, s8, bias2, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream, 0);
+}
+
+extern "C" int jlm_vocab_lse_mixed_fr(const jlm_segment *segs_host, const float *descale, const float *s8, const float *bias2, int n_segs,
+                                      const void *Tm, int ld_tm, float *part, int ld_part, int max_parts, int n_rows_max,
+                                      const int *n_dev, void *stream) {
+    return vocab_lse_mixed_impl(segs_host, descale, s8, bias2, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream, 1);
 }

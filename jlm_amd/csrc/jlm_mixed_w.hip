@@ -47,7 +47,7 @@ namespace {
 // instructions; 1: contractions whose operands fill the accumulation registers by themselves -- k = 512: 256 of them), XB: the rows
 // carry no bias columns (k a multiple of 32): the tile's biases (base-2 units) come into LDS beside it, three slots, and join the
 // logits in the combine (as mx_body's XBIAS form).
-template <int NB, int NS16, int MTT, int RS, bool XB>
+template <int NB, int NS16, int MTT, int RS, bool XB, bool FR = false>
 struct MxWide {
     static_assert(RS == 1 || RS == 2, "one or two row sets per wave");
     static constexpr int ROWB = NB * 128;
@@ -57,7 +57,10 @@ struct MxWide {
     static constexpr int RW = 128 * RS;                   // hypothesis rows per workgroup
     static constexpr int NMF = NS16 + 2 * NB;             // matrix instructions of a block and row set
     static constexpr int NSLOT = 4 * RS * NB;             // issue slots of a block (RS per fragment; NS16 odd: RS of the last 32-k block's are empty)
-    static constexpr int NP1 = 42;                        // per row set: 16 x combine, 8 x max3, 1, 16 x (scale, exp2, add), 1
+    // per row set: 16 x combine, 8 x max3, 1, 16 x (scale, exp2, add), 1 -- FR (fixed reference): 16 x (combine, exp2, add), 1: no running
+    // maximum, s = sum 2^y against the reference 0 (valid while the row's largest base-2 logit stays inside +-100: jlm_vocab_lse_mixed's
+    // `fixed_ref` argument, decided by the load-time calibration; the slices then carry m = 0)
+    static constexpr int NP1 = FR ? 17 : 42;
     static constexpr int NPIECE = RS * NP1;
     static constexpr int SKIP = 2;                        // (the first slots carry nothing: the finished pairs' last instructions are still in the pipe)
     static constexpr int PP = (NPIECE + NSLOT - SKIP - 1) / (NSLOT - SKIP);
@@ -79,6 +82,19 @@ struct MxWide {
     // one piece of the treatment of the finished pair (pf, pi) of row set S
     __device__ __forceinline__ void fold_piece(const bool MASKED, int S, f32x16 &pf, const i32x16 &pi, int mtp, int lim, int pc) {
 #pragma clang fp contract(off)          // every fused multiply-add below is written as one: the row sets must round alike
+        if (FR) {
+            if (pc < 16) {
+                const int r = pc;
+                float y = fmaf((float)pi[r], csr[S], pf[r]);
+                y = XB ? fmaf(y, descale, bq[r >> 2][r & 3]) : y * descale;
+                if (MASKED && mtp * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim) y = JLM_NEG_BIG;
+                const float e = __builtin_amdgcn_exp2f(y);
+                if (r == 0) { add0[S] = e; add1[S] = 0.0f; } else if (r & 1) add1[S] += e; else add0[S] += e;
+            } else if (pc == 16) {
+                s[S] += add0[S] + add1[S];
+            }
+            return;
+        }
         if (pc < 16) {
             const int r = pc;
             float y = fmaf((float)pi[r], csr[S], pf[r]);
@@ -197,7 +213,7 @@ struct MxWide {
                 if (has_m) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (i == 0 && !(MXW_ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if ((i % RS) == RS - 1 && reads && !(MXW_ABL & 32)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (Q0 + i >= SKIP && !(MXW_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
+                if (Q0 + i >= SKIP && !(MXW_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, (FR ? 6 : 3) * PP, 0);
             }
         }, std::make_integer_sequence<int, NB>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -275,7 +291,7 @@ struct MxWide {
         // real fold scales to 0 (as mx_body's v[])
 #pragma unroll
         for (int S = 0; S < RS; ++S) {
-            m[S] = JLM_NEG_BIG; s[S] = 0.0f;
+            m[S] = FR ? 0.0f : JLM_NEG_BIG; s[S] = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[1][S][r] = -1.0e30f; acci[1][S][r] = 0; accf[0][S][r] = 0.0f; acci[0][S][r] = 0; }
         }
@@ -375,7 +391,7 @@ struct MxWide {
 };
 
 // (out of line: hosted inline, the three bodies of the D-softmax* kernel cost each other 64 spilled registers, some inside the tile loops)
-template <int NB, int NS16, int RS, bool XB>
+template <int NB, int NS16, int RS, bool XB, bool FR>
 __device__ __noinline__ void mxw_body(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm, float2 *prow,
                                       unsigned char *smem) {
     // (arguments of a real call arrive in vector registers: make the wave-uniform ones provably uniform again -- loop counters,
@@ -391,25 +407,25 @@ __device__ __noinline__ void mxw_body(const MxSeg &sg, int vt0, int vt1, int pt,
     u.descale = __int_as_float(uni(__float_as_int(sg.descale)));
     u.cs = __int_as_float(uni(__float_as_int(sg.cs)));
     u.bias2 = static_cast<const float *>(unip(sg.bias2));
-    MxWide<NB, NS16, mx_blocks_per_tile(NB), RS, XB> w;
+    MxWide<NB, NS16, mx_blocks_per_tile(NB), RS, XB, FR> w;
     w.run(u, uni(vt0), uni(vt1), uni(pt), uni(n_paths), static_cast<const unsigned char *>(unip(Tm)), uni(ld_tm),
           static_cast<float2 *>(const_cast<void *>(unip(prow))), static_cast<unsigned char *>(const_cast<void *>(unip(smem))));
 }
 
-template <int RS, bool XB, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
+template <int RS, bool XB, bool FR, int... SH>      // SH = NB0, NS0, NB1, NS1, ...
 struct MxwDispatch;
-template <int RS, bool XB>
-struct MxwDispatch<RS, XB> {
+template <int RS, bool XB, bool FR>
+struct MxwDispatch<RS, XB, FR> {
     static __device__ __forceinline__ void run(const MxSeg &, int, int, int, int, int, const unsigned char *, int, float2 *, unsigned char *) {}
 };
-template <int RS, bool XB, int NB, int NS16, int... REST>
-struct MxwDispatch<RS, XB, NB, NS16, REST...> {
+template <int RS, bool XB, bool FR, int NB, int NS16, int... REST>
+struct MxwDispatch<RS, XB, FR, NB, NS16, REST...> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int ns16, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                                float2 *prow, unsigned char *smem) {
         if (sg.nb == NB && ns16 == NS16) {
-            mxw_body<NB, NS16, RS, XB>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+            mxw_body<NB, NS16, RS, XB, FR>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
         } else {
-            MxwDispatch<RS, XB, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+            MxwDispatch<RS, XB, FR, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
         }
     }
 };
@@ -425,7 +441,7 @@ static __device__ unsigned long long jlm_prof_wg_mxw[1024][4];
 #define MXW_WG_T1
 #endif
 
-template <int RS, bool XB, int... SH>
+template <int RS, bool XB, bool FR, int... SH>
 __global__ __launch_bounds__(256, 1) void vocab_lse_mixedw_kernel(MxArgs a, const unsigned char *__restrict__ Tm, int ld_tm, float2 *__restrict__ part,
                                                                   int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mxw_smem[];
@@ -447,22 +463,25 @@ __global__ __launch_bounds__(256, 1) void vocab_lse_mixedw_kernel(MxArgs a, cons
 #ifdef JLM_WGTIME
         si_last = a.sub_seg[r];
 #endif
-        MxwDispatch<RS, XB, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mxw_smem);
+        MxwDispatch<RS, XB, FR, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mxw_smem);
     }
     MXW_WG_T1
 }
 // the shapes of BASELINE configs[1] (D-softmax* 200 / 100 / 50), two row sets per wave
-#define MXW_KERNEL_DSOFTMAX vocab_lse_mixedw_kernel<2, false, 7, 13, 4, 7, 2, 4>
+#define MXW_KERNEL_DSOFTMAX vocab_lse_mixedw_kernel<2, false, false, 7, 13, 4, 7, 2, 4>
 // a contraction of 512 (untied models at H = 512: the vocabulary matrix itself): sixteen 32-k blocks = 256 accumulation registers of
 // row operands, one row set per wave, external biases
-#define MXW_KERNEL_K512 vocab_lse_mixedw_kernel<1, true, 16, 32>
+#define MXW_KERNEL_K512 vocab_lse_mixedw_kernel<1, true, false, 16, 32>
 // the tied k = 256 models (BASELINE configs[2..4]) with two row sets per wave: 2 x 128 = all 256 accumulation registers (JLM_MX_WIDE=1: A/B)
-#define MXW_KERNEL_TIED vocab_lse_mixedw_kernel<2, true, 8, 16>
+#define MXW_KERNEL_TIED vocab_lse_mixedw_kernel<2, true, false, 8, 16>
+// ... the same with the fixed reference (FR): no running maximum
+#define MXW_KERNEL_TIED_FR vocab_lse_mixedw_kernel<2, true, true, 8, 16>
+#define MXW_KERNEL_K512_FR vocab_lse_mixedw_kernel<1, true, true, 16, 32>
 
 
 #ifdef JLM_MX_RESOURCES
 #define MXW_RES(NB_, NS_, RS_, XB_) __global__ __launch_bounds__(256, 1) void mxw_res_##NB_##_##NS_(MxSeg sg, const unsigned char *Tm, int ld_tm, float2 *part) { \
-        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; MxWide<NB_, NS_, mx_blocks_per_tile(NB_), RS_, XB_> w; \
+        extern __shared__ __attribute__((aligned(16))) unsigned char sm_[]; MxWide<NB_, NS_, mx_blocks_per_tile(NB_), RS_, XB_, false> w; \
         w.run(sg, 0, 100, blockIdx.x, 2560, Tm, ld_tm, part, sm_); }
 MXW_RES(2, 4, 2, false) MXW_RES(4, 7, 2, false) MXW_RES(7, 13, 2, false) MXW_RES(16, 32, 1, true)
 #endif
@@ -479,19 +498,24 @@ extern "C" int jlm_prof_read_wg_mxw(unsigned long long *out) {
 //   which 0: the D-softmax* 200 / 100 / 50 model (every segment in the bias-column form with (nb, f16 steps) in {(7, 13), (4, 7), (2, 4)}),
 //            256 rows per workgroup;
 //   which 1: ONE segment of k = 512 in the external-bias form (nb = 16), 128 rows per workgroup;
-//   which 2: segments of k = 256 in the external-bias form (nb = 8), 256 rows per workgroup.
+//   which 2: segments of k = 256 in the external-bias form (nb = 8), 256 rows per workgroup;
+//   which 3 / 4: forms 1 / 2 with the fixed reference (no running maximum).
 // Returns 0, or -3 (LDS grant) / a negative HIP error like its caller.
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
                        int lds, hipStream_t st) {
-    static JlmLdsGrant grant[3];
-    const void *fn = which == 0 ? reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX) : which == 1 ? reinterpret_cast<const void *>(MXW_KERNEL_K512)
-                                                                                                : reinterpret_cast<const void *>(MXW_KERNEL_TIED);
-    if (int rc = jlm_grant_lds(grant[which], fn, lds)) return rc;
+    static JlmLdsGrant grant[5];
+    const void *fns[5] = {reinterpret_cast<const void *>(MXW_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MXW_KERNEL_K512),
+                          reinterpret_cast<const void *>(MXW_KERNEL_TIED), reinterpret_cast<const void *>(MXW_KERNEL_K512_FR),
+                          reinterpret_cast<const void *>(MXW_KERNEL_TIED_FR)};
+    if (which < 0 || which > 4) return -1;
+    if (int rc = jlm_grant_lds(grant[which], fns[which], lds)) return rc;
     const dim3 grid(a.n_cols * n_ptiles), block(256);
     const unsigned char *tm = reinterpret_cast<const unsigned char *>(Tm);
     if (which == 0) hipLaunchKernelGGL(MXW_KERNEL_DSOFTMAX, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
     else if (which == 1) hipLaunchKernelGGL(MXW_KERNEL_K512, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
-    else hipLaunchKernelGGL(MXW_KERNEL_TIED, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else if (which == 2) hipLaunchKernelGGL(MXW_KERNEL_TIED, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else if (which == 3) hipLaunchKernelGGL(MXW_KERNEL_K512_FR, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
+    else hipLaunchKernelGGL(MXW_KERNEL_TIED_FR, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;
     return 0;

@@ -135,6 +135,7 @@ struct JlmModel : torch::CustomClassHolder {
         m.gate_descale = (float)getf(f, "gate_descale"); m.h_scale = (float)getf(f, "h_scale");
         m.wt8 = tptr<const void>(tensors, "wt8"); m.xgate8 = tptr<const float>(tensors, "xgate8");
         m.untied_split = tptr<const void>(tensors, "untied_split"); m.untied_descale = (float)getf(f, "untied_descale");
+        m.lse_fixed_ref = (int)geti(i, "lse_fixed_ref");
         m.pmt = tptr<const float>(tensors, "pmt"); m.pmt_split = tptr<const void>(tensors, "pmt_split");
         m.n_t = (int)geti(i, "n_t"); m.t_descale = (float)getf(f, "t_descale");
         if (!split.v.empty()) {

@@ -417,6 +417,14 @@ class DecodeEngine:
                 if self.keep_n_live:
                     self.last_n_live = p.h_nlive.numpy()[:lat.n_frames].copy()
         self.last_state = p
+        if getattr(self.m, "lse_fixed_ref", 0):
+            # the normaliser ran without a running maximum (jlm_vocab_lse_mixed_fr): a row whose logits left the range the load-time probe
+            # vouched for comes back as log 0 or log inf -- never a plausible score.  Loud, not silent:
+            sc, ln = p.h_score.numpy(), p.h_len.numpy()
+            if not np.isfinite(sc[ln > 0]).all():
+                p.busy = False
+                raise _lib.JlmHipError("a path score is not finite: this model's logits left the range the fixed-reference normaliser covers "
+                                       "(DeviceModel.mixed_calib); set JLM_MX_FIXREF=0")
         out = self._read_out(lat, p.h_nodes.numpy(), p.h_len.numpy(), p.h_score.numpy(), topN)
         p.busy = False
         return out

@@ -284,6 +284,7 @@ class DeviceModel:
             raise ValueError("JLM_PRECISION must be f16x3 or f32 (got %r)" % self.precision)
         self.split_array = None          # not None: the split-f16 segment table [(dict, tensor)] exists
         self.mixed_idx, self.ld_tm, self.b2_log2, self.mixed_spread = [], 0, None, []
+        self.lse_fixed_ref = 0
         self.split_lstm = False
         self.um_split = None
         if self.precision == "f16x3" and (self.stationary_ok or self.mode == "untied"):
@@ -383,6 +384,7 @@ class DeviceModel:
             self._calibrate_mixed()
 
     CALIB_ROWS, CALIB_STEPS, CALIB_SEED = 256, 3, 20240929
+    FIXED_REF_MAX_BITS = 40.0
 
     def _calibrate_mixed(self):
         """Load-time calibration of the mixed rows ON THIS MODEL (round 4).  The int8 cross terms are good to ~2^-20 of |t||b| per
@@ -409,6 +411,7 @@ class DeviceModel:
             self.mixed_idx, self.seg_mixed, self.mixed_segments = [], [], []
             self.mixed_t_scale, self.mixed_descale, self.mixed_s8 = [], [], []
             self.ld_tm, self.b2_log2 = 0, None
+            self.lse_fixed_ref = 0
             self._decode_model = None
 
         # (round 5, ADVICE) a model the probe cannot run on -- no split LSTM step, no projection panel -- must not keep the int8
@@ -453,6 +456,16 @@ class DeviceModel:
         keep = bool(np.isfinite(rms) and rms <= limit)
         self.mixed_calib = dict(rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst, limit=limit, kept=keep,
                                 lse_mean=float(np.mean(lse[0])))
+        # Round 5: the normaliser without a running maximum (jlm_vocab_lse_mixed_fr: sum 2^y against the reference 0, three VALU
+        # instructions per logit less; the wide kernel's tied k = 256 and k = 512 forms) is safe while a row's largest base-2 logit stays
+        # within +-100 (f32 range over 2^16 words).  log Z bounds the largest logit from above and, minus log V, from below: a model whose
+        # probe rows keep |log Z| log2 e under FIXED_REF_MAX_BITS = 40 (28 nats; Gaussian fixtures: 16, logits of +-20: ~30) has 60 bits to
+        # spare either way.  A row that leaves the range comes back as s = 0 or inf and DecodeEngine.collect raises.  JLM_MX_FIXREF=0: off.
+        bits = float(np.abs(lse[0]).max()) * 1.4426950408889634
+        self.lse_fixed_ref = int(keep and np.isfinite(bits) and bits <= self.FIXED_REF_MAX_BITS and os.environ.get("JLM_MX_FIXREF", "1") != "0")
+        self.mixed_calib.update(lse_abs_max_bits=bits, fixed_ref=bool(self.lse_fixed_ref))
+        if self.lse_fixed_ref:
+            self._decode_model = None            # (the probe ran on a model object built without the flag)
         if not keep:
             drop("log-normaliser rms difference above the limit", rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst,
                  lse_mean=float(np.mean(lse[0])))
@@ -583,7 +596,7 @@ class DeviceModel:
             if getattr(self, "b2_log2", None) is not None:
                 t["b2_log2"] = self.b2_log2
             i = dict(H=self.H, ldt=self.ldt, untied=int(self.mode == "untied"), self_norm=int(self.self_norm),
-                     split_lstm=int(self.split_lstm), ld_emb=self.Epad, kpad=self.kpad, E=self.Epad,
+                     split_lstm=int(self.split_lstm), ld_emb=self.Epad, kpad=self.kpad, E=self.Epad, lse_fixed_ref=int(getattr(self, "lse_fixed_ref", 0)),
                      n_t=(self.pmt.shape[0] if self.pmt is not None else 0))
             f = {}
             if self.pmt is not None:

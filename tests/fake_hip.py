@@ -594,6 +594,10 @@ class FakeLib:
             y2 = y2 + view(_p(bias2) + 4 * sg.v_start, nv, np.float32)[None, :]
         return y2.astype(np.float64) * 0.6931471805599453
 
+    def jlm_vocab_lse_mixed_fr(self, *a):
+        """(the fixed-reference form differs in rounding only: the double runs the same emulation)"""
+        return self.jlm_vocab_lse_mixed(*a)
+
     def jlm_vocab_lse_mixed(self, segs, descale, s8, bias2, n_segs, Tm, ld_tm, part, ld_part, max_parts, n_rows_max, n_dev, stream):
         if n_segs < 1 or n_segs > max_parts or ld_tm != self.jlm_mixed_t_stride(segs, n_segs):
             return -1

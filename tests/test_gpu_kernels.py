@@ -768,12 +768,19 @@ def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp):
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
     assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, None, R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
-    n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, maxp, R, nd.data_ptr(), _st())
-    assert n >= len(widths), n
-    torch.cuda.synchronize()
-    p = part[:n].cpu().numpy()
-    odd = np.argwhere((p != p[:, :1]).any(axis=2))
-    assert len(odd) == 0, ("rows that differ from row 0 (slice, row):", odd[:8].tolist())
+    lses = []
+    for entry in (L.jlm_vocab_lse_mixed, L.jlm_vocab_lse_mixed_fr):       # (_fr: without a running maximum where the kernel has such a form)
+        part.zero_()
+        n = entry(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, maxp, R, nd.data_ptr(), _st())
+        assert n >= len(widths), n
+        torch.cuda.synchronize()
+        p = part[:n].cpu().numpy()
+        odd = np.argwhere((p != p[:, :1]).any(axis=2))
+        assert len(odd) == 0, ("rows that differ from row 0 (slice, row):", odd[:8].tolist())
+        q = p[:, 0].astype(np.float64)
+        lses.append(np.log(np.sum(q[:, 1] * np.exp(q[:, 0] - q[:, 0].max()))) + q[:, 0].max())
+    # the two forms differ in rounding only
+    assert abs(lses[0] - lses[1]) <= 1e-6 * max(1.0, abs(lses[0])), lses
 
 
 @pytest.mark.parametrize("V,widths,bounds,R", [(3000, [200, 100, 52], [0, 700, 1900, 3000], 300), (50000, [200, 100, 52], [0, 12000, 30000, 50000], 2560),
