@@ -482,6 +482,8 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     // fixed_ref (jlm_vocab_lse_mixed_fr): the wide kernel's forms WITHOUT a running maximum -- s = sum 2^y against the reference 0, slices
     // (0, s) -- where a form exists (tied k = 256, k = 512); any other shape runs as usual.  -3 % on those launches (113.5 vs 117 us,
     // 1 589 vs 1 634 us at configs[2]'s shape: profiles/r05_u_fixed_ref.txt).  Valid while a row's largest base-2 logit stays within
+    // (The eight-wave kernel's D-softmax* bodies were built in this form too and measured SLOWER -- 68.9-73.8 vs 67.0 us per launch,
+    //  profiles/r05_v_fixed_ref_dsoftmax.txt -- and left as they were: that launch ignores the flag.)
     // +-100 or so (f32 range, 2^16 words): the caller's decision (DeviceModel measures its model at load); a row outside it yields s = 0 or
     // inf, never a plausible number.
     const int fixref = fixed_ref;
