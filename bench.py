@@ -221,10 +221,20 @@ def main():
         # every segment on mixed rows (jlm_vocab_lse_mixed): per 32 x 32 block and 32 k-values two f16 and two int8 matrix
         # instructions of 32 cycles each, against six f16 ones of the split form; counted here in f16-instruction units
         # (2 x 16 flop per row, word and instruction), k + 2 padded to whole f16 steps / int8 blocks
-        mixed = split and len(getattr(m, "mixed_idx", [])) == m.n_segs
+        heads = list(getattr(m, "mixed_head_split", None) or [])
+        mixed = split and len(getattr(m, "mixed_idx", [])) == m.n_segs and not any(heads)
+        hybrid = split and bool(getattr(m, "mixed_idx", [])) and not mixed
+        mx_exec = lambda sg, nv: 2.0 * 16 * ((sg["k"] + 2 + 15) // 16 + 2 * ((sg["k"] + 2 + 31) // 32)) * nv
         if mixed:
-            exec_per_row_vocab = sum(2.0 * 16 * ((sg["k"] + 2 + 15) // 16 + 2 * ((sg["k"] + 2 + 31) // 32)) * (sg["v_end"] - sg["v_start"])
-                                     for sg in m.segments)
+            exec_per_row_vocab = sum(mx_exec(sg, sg["v_end"] - sg["v_start"]) for sg in m.segments)
+        elif hybrid:
+            # (round 5) both formats in one launch: a segment on mixed rows but for the head that stays on split rows, or on split rows whole
+            exec_per_row_vocab = 0.0
+            for i, sg in enumerate(m.segments):
+                nv = sg["v_end"] - sg["v_start"]
+                j = m.mixed_idx.index(i) if i in m.mixed_idx else -1
+                cut = nv if j < 0 else (heads[j] if j < len(heads) else 0)
+                exec_per_row_vocab += SPLIT_PASSES * 2.0 * k16(sg) * cut + mx_exec(sg, nv - cut)
         v = kernel_stats(durs, rows, "vocab_lse", m.flops_per_row_vocab / (1 if m.stationary_ok else m.n_segs))
         roofline = None
         if v:
@@ -235,13 +245,18 @@ def main():
                      "registers, csrc/jlm_mixed_w.hip; rows packed by pack_t_mixed_kernel behind the T projection)"
                      if (mixed and m.n_segs == 1 and m.segments[0]["k"] == 256 and os.environ.get("JLM_MX_WIDE", "-1") != "0") else
                      "vocab_lse_mixed_kernel (jlm_vocab_lse_mixed; its rows packed by pack_t_mixed_kernel behind the T projection)" if mixed else
+                     "vocab_lse_hybrid_kernel (jlm_vocab_lse_hybrid: segments %s on mixed rows%s, the rest on split rows; the mixed segments' rows "
+                     "packed by pack_t_mixed_kernel)" % (list(m.mixed_idx), (" but for their first %s words" % heads) if any(heads) else "") if hybrid else
                      "vocab_lse_split8_kernel (jlm_vocab_lse_split)" if split else
                      "vocab_lse_stationary_kernel (jlm_vocab_lse_stationary)" if m.stationary_ok
                      else "gemm2_kernel<128x128,EpiLse> (jlm_vocab_lse_partials)")
             # `peak` prices ALGORITHMIC flops against the ceiling of the instructions the kernel issues: three f16 passes per
             # f32-grade product on split rows (dense f16 / 3); on mixed rows one f16 pass + two int8 passes at twice the k per
             # instruction = the time of TWO f16 passes (dense f16 / 2)
-            peak = (F16_MFMA_PEAK_TFLOPS / 2.0 if mixed else F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES) if split else F32_MFMA_PEAK_TFLOPS
+            # (both formats in one launch: the same pricing per segment -- dense f16 x algorithmic flops / executed f16-instruction flops)
+            peak = (F16_MFMA_PEAK_TFLOPS / 2.0 if mixed else
+                    F16_MFMA_PEAK_TFLOPS * m.flops_per_row_vocab / exec_per_row_vocab if hybrid else
+                    F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES) if split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_note = None, "not measured in this run (tools/gpu_traffic.sh + tools/traffic_report.py write profiles/traffic_latest.json)"
             tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
             if split and m.stationary_ok and os.path.exists(tpath):
@@ -253,7 +268,7 @@ def main():
                     traffic_note = ("profiles/traffic_latest.json was measured on other kernel sources / another fixture: omitted "
                                     "(its figure: %s bytes per call)" % tj.get("vocab_lse_hbm_bytes_per_call"))
             ex = v["tflops"] / m.flops_per_row_vocab * exec_per_row_vocab if split else v["tflops"]
-            form = ("mixed" if mixed else "hybrid" if (split and getattr(m, "mixed_idx", [])) else "split" if split else "f32")
+            form = ("mixed" if mixed else "hybrid" if hybrid else "split" if split else "f32")
             roofline = {"kernel": kname, "bound": "mfma", "achieved": round(v["tflops"], 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(v["tflops"] / peak, 4),
                         "lse_form": form, "lse_form_calibration": getattr(m, "mixed_calib", None),
@@ -269,6 +284,10 @@ def main():
                                         "(round 4; rounds 1-3 priced every form at dense f16 / %d = three f16 passes per f32-grade product -- that figure "
                                         "is kept as `frac_f16x3_pricing`); frac_of_dense_f16 prices the executed instructions at 32 cycles each"
                                         % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES)) if mixed else
+                                       ("both formats in one launch: mixed rows (one f16 + two int8 matrix instructions per 32 k-values and block) for the "
+                                        "words whose logit error the log-normaliser tolerates, split rows (three f16 passes) for the segment / head that "
+                                        "carries the probability mass (DeviceModel._calibrate_mixed); `peak` = %.1f dense f16 x algorithmic / executed flops"
+                                        % F16_MFMA_PEAK_TFLOPS) if hybrid else
                                        "f16 split x3 (v_mfma_f32_32x32x16_f16, f32 accumulate): `peak` = %.1f dense f16 / %d passes prices "
                                        "ALGORITHMIC flops; frac_of_dense_f16 prices the executed ones (3 passes, k padded to 16)"
                                        % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES) if split else "f32 (v_mfma_f32_32x32x2_f32)"),

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 9
+#define JLM_ABI_VERSION 10
 #define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
@@ -360,10 +360,16 @@ int jlm_vocab_lse_mixed_fr(const jlm_segment *segs_host, const float *descale, c
  * jlm_pack_t_mixed over the MIXED segments only, in segment order, for the same `rows`), the others on their split rows exactly as
  * jlm_vocab_lse_split (segs / t_scale / descale / bias_col cover every segment).  The int8 cross terms pay where the matrix
  * instructions dominate a block (k = 200, 100); where the fold does (k = 50) the three f16 passes stay.  -2: a shape the kernel
- * does not host (mixed: k + 2 in (192, 208] or (96, 112]; split: k <= 64 with its bias column): use jlm_vocab_lse_split. */
+ * does not host (mixed: k + 2 in (192, 208], (96, 112] or (32, 64]; split: k <= 208, not a multiple of 16, with its bias column): use
+ * jlm_vocab_lse_split.
+ * ABI 10, head_split (host array of n_segs ints, or NULL): the first head_split[i] words of MIXED segment i (a multiple of 128, less
+ * than the segment) run on its split rows, the rest on its mixed rows.  In a trained model the frequent words -- the low ids of the
+ * first segment -- carry the probability mass and with it the int8 cross terms' contribution to the log-normaliser's error (measured
+ * on logits of +-20: head segment 3.1e-6 rms, the other two 2e-8); three f16 passes for those few thousand words buy the split form's
+ * accuracy at the mixed form's cost for the other 90 % of the vocabulary.  The loader picks the cut (DeviceModel._calibrate_mixed). */
 int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t_scale, const float *descale, const int *bias_col,
-                         const jlm_segment *mixed, const float *mx_descale, const float *mx_s8, int n_segs, const float *b2,
-                         const float *T, int ldt, const void *Tm, int ld_tm, const int *rows, float *part, int ld_part,
+                         const jlm_segment *mixed, const float *mx_descale, const float *mx_s8, const int *head_split, int n_segs,
+                         const float *b2, const float *T, int ldt, const void *Tm, int ld_tm, const int *rows, float *part, int ld_part,
                          int max_parts, int n_rows_max, const int *n_dev, void *stream);
 
 /* ABI 6: the largest max_cands (a multiple of 256, as the plans round it) jlm_beam_step accepts for this beam,
@@ -428,6 +434,8 @@ typedef struct {
      * jlm_vocab_lse_mixed.  Used when the plan carries the packed-row buffer (plan.Tm). */
     const jlm_segment *mixed_segs; const float *mixed_t_scale; const float *mixed_descale; const float *mixed_s8;
     const float *mixed_bias2;       /* b2 log2(e) [V] for mixed segments without bias columns (NULL: none) */
+    /* ABI 10: [n_segs] or NULL -- the leading words of a mixed segment that stay on split rows (jlm_vocab_lse_hybrid head_split) */
+    const int *mixed_head_split;
 } jlm_decode_model;
 
 typedef struct {

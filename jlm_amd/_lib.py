@@ -46,7 +46,7 @@ class DecodeModel(Structure):
                 ("split_segs", POINTER(Segment)), ("split_t_scale", POINTER(c_float)), ("split_descale", POINTER(c_float)),
                 ("split_bias_col", POINTER(c_int)),
                 ("mixed_segs", POINTER(Segment)), ("mixed_t_scale", POINTER(c_float)), ("mixed_descale", POINTER(c_float)),
-                ("mixed_s8", POINTER(c_float)), ("mixed_bias2", c_void_p)]
+                ("mixed_s8", POINTER(c_float)), ("mixed_bias2", c_void_p), ("mixed_head_split", POINTER(c_int))]
 
 
 class DecodePlan(Structure):
@@ -93,7 +93,7 @@ _SIGS = {
     "jlm_beam_step_max_cands": ([c_int, c_int, c_int], c_int),
     "jlm_pack_mixed": ([P, c_int, c_int, c_int, P, c_float, c_float, c_float, P, c_int, P], c_int),
     "jlm_vocab_lse_hybrid": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(Segment), POINTER(c_float),
-                              POINTER(c_float), c_int, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
+                              POINTER(c_float), POINTER(c_int), c_int, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_mixed_t_stride": ([POINTER(Segment), c_int], c_int),
     "jlm_pack_t_mixed": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
     "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
@@ -132,7 +132,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 9:
+        if l.jlm_abi_version() != 10:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

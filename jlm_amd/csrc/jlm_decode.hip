@@ -150,6 +150,10 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 if (!JLM_SKIPPED(32)) JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, p->T, m->ldt, rows, f == 0 ? B : rmax, ndev, p->Tm, p->ld_tm, stream));
                 hybrid = true;
                 all_mixed = n_only == m->n_segs;
+                // (ABI 10) a segment whose head stays on split rows: the launch over both formats
+                if (all_mixed && m->mixed_head_split && m->split_segs)
+                    for (int i = 0; i < m->n_segs; ++i)
+                        if (m->mixed_head_split[i] > 0) all_mixed = false;
             }
         }
         const int cell = f * B;
@@ -213,8 +217,8 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                                                                                          m->n_segs, p->Tm, p->ld_tm, p->part, rmax, cap, bound, ndev, stream);
                 else if (hybrid)    // -2: a shape the hybrid kernel does not host -- the split rows of every segment exist
                     r = jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs,
-                                             m->mixed_descale, m->mixed_s8, m->n_segs, m->b2, p->T, m->ldt, p->Tm, p->ld_tm, rows,
-                                             p->part, rmax, cap, bound, ndev, stream);
+                                             m->mixed_descale, m->mixed_s8, m->mixed_head_split, m->n_segs, m->b2, p->T, m->ldt, p->Tm,
+                                             p->ld_tm, rows, p->part, rmax, cap, bound, ndev, stream);
                 if (r == -2)
                     r = m->split_segs
                             ? jlm_vocab_lse_split(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col,
@@ -278,9 +282,14 @@ extern "C" int jlm_lse_probe(const jlm_decode_model *m, const int *rowlist, cons
         if (m->mixed_segs[i].B) { only[n_only] = m->mixed_segs[i]; only_ts[n_only++] = m->mixed_t_scale[i]; }
     if (!n_only || jlm_mixed_t_stride(only, n_only) != ld_tm) return -1;
     JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
-    if (n_only == m->n_segs)
+    bool cut = false;
+    if (m->mixed_head_split)
+        for (int i = 0; i < m->n_segs; ++i)
+            if (m->mixed_segs[i].B && m->mixed_head_split[i] > 0) cut = true;
+    if (n_only == m->n_segs && !cut)
         return jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, m->n_segs, Tm, ld_tm, part, rows, max_parts,
                                    rows, nullptr, stream);
     return jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs, m->mixed_descale,
-                                m->mixed_s8, m->n_segs, m->b2, T, m->ldt, Tm, ld_tm, rl, part, rows, max_parts, rows, nullptr, stream);
+                                m->mixed_s8, m->mixed_head_split, m->n_segs, m->b2, T, m->ldt, Tm, ld_tm, rl, part, rows, max_parts, rows,
+                                nullptr, stream);
 }

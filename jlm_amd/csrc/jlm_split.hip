@@ -987,24 +987,68 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_hybrid_kernel(LseHybridArgs 
             unsigned char *sm8 = reinterpret_cast<unsigned char *>(smem);
             if (sg.nb == 7 && ns16 == 13) jlm_mx::mx_body<7, 13, 2>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, nullptr, prow, sm8);
             else if (sg.nb == 4 && ns16 == 7) jlm_mx::mx_body<4, 7, 4>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, nullptr, prow, sm8);      // (packed rows: compact)
+            else if (sg.nb == 2 && ns16 == 4) jlm_mx::mx_body<2, 4, 8>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, nullptr, prow, sm8);
         } else {
             const jlm_segment sg = a.sp.seg[si];
             const int ns = (sg.k + 15) >> 4;
             if (ns <= 2) lse_split_body_h<2, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
-            else lse_split_body_h<4, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+            else if (ns <= 4) lse_split_body_h<4, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+            else if (ns <= 7) lse_split_body_h<7, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);
+            else lse_split_body_h<13, 4, 8>(sg, a.sp.t_scale[si], a.sp.descale[si], vt0, vt1, pt, n_paths, T, ldt, rows, prow, smem);       // (round 5: a segment's head)
         }
     }
 }
 
 // segs / t_scale / descale / bias_col: as for jlm_vocab_lse_split, for EVERY segment (the T column offsets of the mixed ones are
 // read from here too).  mixed[i].B != NULL: segment i runs on its mixed rows (mixed[i].ldb = 32 nb; mx_descale / mx_s8 as for
-// jlm_vocab_lse_mixed), else on its split rows.  -2: a shape this kernel does not host (mixed: k + 2 in (192, 208] or (96, 112];
-// split: k <= 64, with a bias column) -- the caller falls back to jlm_vocab_lse_split.
-extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t_scale, const float *descale, const int *bias_col,
-                                    const jlm_segment *mixed, const float *mx_descale, const float *mx_s8, int n_segs, const float *b2,
+// jlm_vocab_lse_mixed), else on its split rows.  -2: a shape this kernel does not host (mixed: k + 2 in (192, 208], (96, 112] or
+// (32, 64]; split: k <= 208 and no multiple of 16, with a bias column) -- the caller falls back to jlm_vocab_lse_split.
+// ABI 10, head_split (NULL: none): the first head_split[i] words (a multiple of 128) of MIXED segment i run on its split rows -- the
+// words that carry a trained model's probability mass, and so the int8 cross terms' share of the log-normaliser's error -- the rest
+// on mixed rows.  The segment becomes two internal ones (same T columns, same packed hypothesis rows, same scale slot).
+extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host_in, const float *t_scale_in, const float *descale_in, const int *bias_col_in,
+                                    const jlm_segment *mixed_in, const float *mx_descale_in, const float *mx_s8_in, const int *head_split,
+                                    int n_segs, const float *b2,
                                     const float *T, int ldt, const void *Tm, int ld_tm, const int *rows, float *part, int ld_part,
                                     int max_parts, int n_rows_max, const int *n_dev, void *stream) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4 || n_rows_max <= 0) return -1;
+    // internal segments: a mixed segment with a head is listed twice -- its head as a split segment, the rest as a mixed one
+    jlm_segment segs_host[JLM_MAX_SEGMENTS], mixed[JLM_MAX_SEGMENTS];
+    float t_scale[JLM_MAX_SEGMENTS], descale[JLM_MAX_SEGMENTS], mx_descale[JLM_MAX_SEGMENTS], mx_s8[JLM_MAX_SEGMENTS];
+    int bias_col_v[JLM_MAX_SEGMENTS], slot_of[JLM_MAX_SEGMENTS], tmoff_of[JLM_MAX_SEGMENTS];
+    const int *bias_col = bias_col_in ? bias_col_v : nullptr;
+    {
+        int n = 0, slot = 0, tmo = 0;
+        const jlm_segment none{};
+        for (int i = 0; i < n_segs; ++i) {
+            const bool mx = mixed_in && mixed_in[i].B;
+            const int nv = segs_host_in[i].v_end - segs_host_in[i].v_start;
+            int cut = (mx && head_split) ? head_split[i] : 0;
+            if (cut < 0 || cut % 128) return -1;
+            if (cut >= nv) return -1;                // (the whole segment on split rows is said with mixed[i].B == NULL)
+            auto put = [&](const jlm_segment &sp, const jlm_segment &m) -> bool {
+                if (n >= JLM_MAX_SEGMENTS) return false;
+                segs_host[n] = sp; mixed[n] = m;
+                t_scale[n] = t_scale_in[i]; descale[n] = descale_in[i];
+                bias_col_v[n] = bias_col_in ? bias_col_in[i] : -1;
+                mx_descale[n] = mx ? mx_descale_in[i] : 0.0f; mx_s8[n] = mx ? mx_s8_in[i] : 0.0f;
+                slot_of[n] = slot; tmoff_of[n] = tmo;
+                ++n;
+                return true;
+            };
+            if (cut > 0) {
+                jlm_segment hd = segs_host_in[i];
+                hd.v_end = hd.v_start + cut;
+                if (!put(hd, none)) return -2;
+                jlm_segment sp = segs_host_in[i], m = mixed_in[i];
+                sp.v_start += cut; m.v_start += cut;        // (B of the split view is not read for a mixed segment)
+                m.B = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(m.B) + (size_t)cut * m.ldb * 4);
+                if (!put(sp, m)) return -2;
+            } else if (!put(segs_host_in[i], mx ? mixed_in[i] : none)) return -2;
+            if (mx) { ++slot; tmo += ((segs_host_in[i].k + 2 + 31) / 32) * 128; }
+        }
+        n_segs = n;
+    }
     LseHybridArgs h;
     unsigned char is_mixed[JLM_MAX_SEGMENTS];
     h.mixed_mask = 0;
@@ -1016,10 +1060,10 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
     int ntiles[JLM_MAX_SEGMENTS];
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
     long n_tiles_all = 0;
-    int lds = (2 * 128 * 64 + 3 * 128) * 4, tm_off = 0, any_mixed = 0, n_mixed = 0;
+    int lds = (2 * 128 * 64 + 3 * 128) * 4, any_mixed = 0;
     for (int i = 0; i < n_segs; ++i) {
         const jlm_segment &sg = segs_host[i];
-        is_mixed[i] = (mixed && mixed[i].B) ? 1 : 0;
+        is_mixed[i] = mixed[i].B ? 1 : 0;
         h.mixed_mask |= (unsigned)is_mixed[i] << i;
         a.seg[i] = sg;
         a.bias[i] = b2 + sg.v_start;
@@ -1028,12 +1072,12 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
         a.bias_col[i] = (short)(bias_col ? bias_col[i] : -1);
         if (is_mixed[i]) {
             const int nb = (sg.k + 2 + 31) / 32, ns16 = (sg.k + 2 + 15) / 16;
-            if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7)) || mixed[i].ldb != 32 * nb || sg.k % 4 || sg.t_off % 4) return -2;
+            if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4)) || mixed[i].ldb != 32 * nb || sg.k % 4 || sg.t_off % 4) return -2;
             if ((long)(sg.v_end - sg.v_start) * nb * 128 >= (1l << 31)) return -2;
             jlm_mx::MxSeg &m = h.mx[i];
             m.B = reinterpret_cast<const unsigned char *>(mixed[i].B);
             m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
-            m.tm_off = tm_off; m.seg = n_mixed++; m.bias2 = nullptr;
+            m.tm_off = tmoff_of[i]; m.seg = slot_of[i]; m.bias2 = nullptr;
             m.descale = mx_descale[i];
             m.cs = mx_s8[i] * (1.0f / 2048.0f);
             const int mtt = jlm_mx::mx_blocks_per_tile(nb);
@@ -1045,12 +1089,10 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t
         } else {
             const int ns = (sg.k + 15) / 16;
             const int bc = bias_col ? bias_col[i] : -1;
-            if (ns > 4 || bc != sg.k || sg.k % 16 == 0 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4) return -2;
+            if (ns > 13 || (ns > 7 && ns < 13) || bc != sg.k || sg.k % 16 == 0 || sg.k % 4 || sg.ldb % 16 || sg.ldb < ns * 16 || sg.t_off % 4) return -2;
             ntiles[i] = (sg.v_end - sg.v_start + 127) / 128;
             ctile[i] = 2 * ns + c0x2;
         }
-        // (every segment has its slot in the packed rows, mixed or not: jlm_pack_t_mixed packs what it is told to)
-        if (is_mixed[i]) tm_off += ((sg.k + 2 + 31) / 32) * 128;
         if (ntiles[i] > 65535) return -2;
         total += ctile[i] * ntiles[i];
         n_tiles_all += ntiles[i];

@@ -111,6 +111,7 @@ struct JlmModel : torch::CustomClassHolder {
     std::vector<int> bias_col;
     std::vector<jlm_segment> mixed;                 // n_segs entries, B == NULL where the segment has no mixed rows
     std::vector<float> mx_t_scale, mx_descale, mx_s8;
+    std::vector<int> mx_head_split;                 // n_segs entries (ABI 10)
     jlm_decode_model m{};
     // mixed_*: the segments of the full-vocabulary normaliser that also exist as mixed rows (ABI 7): their indices, blocks,
     // (v_start, v_end, k, t_off, ldb) and the three scales, one entry per such segment
@@ -118,7 +119,7 @@ struct JlmModel : torch::CustomClassHolder {
              std::vector<int64_t> split_meta, std::vector<double> split_t_scale, std::vector<double> split_descale,
              std::vector<int64_t> split_bias_col, std::vector<int64_t> mixed_idx, std::vector<Tensor> mixed_B,
              std::vector<int64_t> mixed_meta, std::vector<double> mixed_t_scale, std::vector<double> mixed_descale,
-             std::vector<double> mixed_s8)
+             std::vector<double> mixed_s8, std::vector<int64_t> mixed_head_split)
         : tensors(std::move(t)), segs(seg_B, seg_meta), split(split_B, split_meta), mixed_some(mixed_B, mixed_meta) {
         for (double x : split_t_scale) t_scale.push_back((float)x);
         for (double x : split_descale) descale.push_back((float)x);
@@ -146,11 +147,12 @@ struct JlmModel : torch::CustomClassHolder {
             const size_t n = mixed_idx.size();
             // (an untied model has no rows-stationary split table: its one segment, k = H, is checked against the f32 segment)
             TORCH_CHECK((!split.v.empty() || m.untied) && mixed_some.v.size() == n && mixed_t_scale.size() == n && mixed_descale.size() == n &&
-                            mixed_s8.size() == n,
-                        "jlm.Model: mixed segments need the split table and one block / scale / descale / s8 each");
+                            mixed_s8.size() == n && (mixed_head_split.empty() || mixed_head_split.size() == n),
+                        "jlm.Model: mixed segments need the split table and one block / scale / descale / s8 (/ head_split) each");
             jlm_segment none{};
             mixed.assign(segs.v.size(), none);
             mx_t_scale.assign(segs.v.size(), 0.0f); mx_descale.assign(segs.v.size(), 0.0f); mx_s8.assign(segs.v.size(), 0.0f);
+            mx_head_split.assign(segs.v.size(), 0);
             for (size_t j = 0; j < n; ++j) {
                 const int64_t si = mixed_idx[j];
                 TORCH_CHECK(si >= 0 && si < (int64_t)segs.v.size() && !mixed[si].B, "jlm.Model: bad mixed segment index");
@@ -160,7 +162,14 @@ struct JlmModel : torch::CustomClassHolder {
                 TORCH_CHECK(mixed_some.keep[j].numel() >= (int64_t)(a.v_end - a.v_start) * a.ldb, "jlm.Model: mixed block too small");
                 mixed[si] = a;
                 mx_t_scale[si] = (float)mixed_t_scale[j]; mx_descale[si] = (float)mixed_descale[j]; mx_s8[si] = (float)mixed_s8[j];
+                if (!mixed_head_split.empty()) {
+                    const int64_t c = mixed_head_split[j];
+                    TORCH_CHECK(c >= 0 && c % 128 == 0 && c < a.v_end - a.v_start && (c == 0 || !split.v.empty()),
+                                "jlm.Model: head_split is a multiple of 128 below the segment's size, and needs the split rows");
+                    mx_head_split[si] = (int)c;
+                }
             }
+            m.mixed_head_split = mx_head_split.data();
             m.mixed_segs = mixed.data(); m.mixed_t_scale = mx_t_scale.data(); m.mixed_descale = mx_descale.data();
             m.mixed_s8 = mx_s8.data();
             m.mixed_bias2 = tptr<const float>(tensors, "b2_log2");
@@ -449,7 +458,7 @@ TORCH_LIBRARY(jlm, m) {
     m.class_<JlmModel>("Model").def(
         torch::init<TDict, IDict, FDict, std::vector<Tensor>, std::vector<int64_t>, std::vector<Tensor>, std::vector<int64_t>,
                     std::vector<double>, std::vector<double>, std::vector<int64_t>, std::vector<int64_t>, std::vector<Tensor>,
-                    std::vector<int64_t>, std::vector<double>, std::vector<double>, std::vector<double>>());
+                    std::vector<int64_t>, std::vector<double>, std::vector<double>, std::vector<double>, std::vector<int64_t>>());
     m.class_<JlmPlan>("Plan").def(torch::init<TDict, IDict>());
     m.def("decode_frames(__torch__.torch.classes.jlm.Model model, __torch__.torch.classes.jlm.Plan plan, int n_frames, int vs_max, "
           "int di_max, int dd_max, bool use_side, bool timed, int lse_cu_share_pct) -> int", decode_frames);

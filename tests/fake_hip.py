@@ -43,7 +43,7 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 9
+        return 10
 
     def jlm_lse_probe(self, m, rowlist, prev, word, steps, rows, h, c, T, Tm, ld_tm, form, part, max_parts, stream):
         """ABI 8 (csrc/jlm_decode.hip): `steps` LSTM steps from the zero state, T of the last block, its normaliser slices"""
@@ -73,11 +73,13 @@ class FakeLib:
         rc = self.jlm_pack_t_mixed(only, [m.mixed_t_scale[i] for i in idx], len(idx), T, m.ldt, rl, rows, None, Tm, ld_tm, stream)
         if rc:
             return rc
-        if len(idx) == m.n_segs:
+        cut = bool(m.mixed_head_split) and any(m.mixed_head_split[i] > 0 for i in idx)
+        if len(idx) == m.n_segs and not cut:
             return self.jlm_vocab_lse_mixed(m.mixed_segs, m.mixed_descale, m.mixed_s8, m.mixed_bias2, m.n_segs, Tm, ld_tm, part, rows,
                                             max_parts, rows, None, stream)
         return self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs, m.mixed_descale,
-                                         m.mixed_s8, m.n_segs, m.b2, T, m.ldt, Tm, ld_tm, rl, part, rows, max_parts, rows, None, stream)
+                                         m.mixed_s8, m.mixed_head_split, m.n_segs, m.b2, T, m.ldt, Tm, ld_tm, rl, part, rows, max_parts, rows,
+                                         None, stream)
 
     def jlm_beam_step_max_cands(self, beam, n_frames, mode):
         """the launcher's LDS formula (csrc/jlm_beam.hip, beam_step_lds_bytes)"""
@@ -165,7 +167,7 @@ class FakeLib:
                     if r:
                         return r
                     hybrid = True
-                    all_mixed = len(idx) == m.n_segs
+                    all_mixed = len(idx) == m.n_segs and not (bool(m.mixed_head_split) and any(m.mixed_head_split[i] > 0 for i in idx))
             cell = f * B
             perm = dynamic and bool(p.di_wwords) and bool(p.sg_wword)
             r = self.jlm_edge_logits_perm(m.segs, m.n_segs, m.b2, p.T, m.ldt, off(p.g0, cell), st.cnt, off(p.cidx, cell),
@@ -207,8 +209,8 @@ class FakeLib:
                                                      p.max_parts, bound, ndev, stream)
                     elif hybrid:
                         r = self.jlm_vocab_lse_hybrid(m.split_segs, m.split_t_scale, m.split_descale, m.split_bias_col, m.mixed_segs,
-                                                      m.mixed_descale, m.mixed_s8, m.n_segs, m.b2, p.T, m.ldt, p.Tm, p.ld_tm, rows,
-                                                      p.part, rmax, p.max_parts, bound, ndev, stream)
+                                                      m.mixed_descale, m.mixed_s8, m.mixed_head_split, m.n_segs, m.b2, p.T, m.ldt, p.Tm,
+                                                      p.ld_tm, rows, p.part, rmax, p.max_parts, bound, ndev, stream)
                     if r != -2:
                         pass
                     elif split:
@@ -616,41 +618,54 @@ class FakeLib:
             off += segs[i].ldb * 4
         return n_segs
 
-    def jlm_vocab_lse_hybrid(self, segs, t_scale, descale, bias_col, mixed, mx_descale, mx_s8, n_segs, b2, T, ldt, Tm, ld_tm, rows,
-                             part, ld_part, max_parts, n_rows_max, n_dev, stream):
+    def jlm_vocab_lse_hybrid(self, segs, t_scale, descale, bias_col, mixed, mx_descale, mx_s8, head_split, n_segs, b2, T, ldt, Tm, ld_tm,
+                             rows, part, ld_part, max_parts, n_rows_max, n_dev, stream):
         """mixed[i].B: segment i from its mixed rows and the packed hypothesis rows, else from its split rows (the contract of
-        jlm_vocab_lse_split); -2 for the shapes the kernel does not host"""
+        jlm_vocab_lse_split); -2 for the shapes the kernel does not host.  ABI 10: the first head_split[i] words of a mixed segment from
+        its split rows (one more slice per such segment)"""
         if n_segs < 1 or n_segs > max_parts:
             return -1
         is_mixed = [bool(mixed[i].B) for i in range(n_segs)]
         if not any(is_mixed):
             return -2
+        cut = [int(head_split[i]) if (head_split is not None and bool(head_split) and is_mixed[i]) else 0 for i in range(n_segs)]
         for i in range(n_segs):
             k = segs[i].k
+            if cut[i] < 0 or cut[i] % 128 or cut[i] >= segs[i].v_end - segs[i].v_start:
+                return -1
             if is_mixed[i]:
-                if ((k + 2 + 31) // 32, (k + 2 + 15) // 16) not in ((7, 13), (4, 7)) or mixed[i].ldb != 32 * ((k + 2 + 31) // 32):
+                if ((k + 2 + 31) // 32, (k + 2 + 15) // 16) not in ((7, 13), (4, 7), (2, 4)) or mixed[i].ldb != 32 * ((k + 2 + 31) // 32):
                     return -2
-            elif k > 64 or bias_col is None or bias_col[i] != k or k % 16 == 0:
-                return -2
+            if not is_mixed[i] or cut[i]:
+                ns = (k + 15) // 16
+                if ns > 13 or 7 < ns < 13 or bias_col is None or bias_col[i] != k or k % 16 == 0:
+                    return -2
+        if n_segs + sum(1 for c in cut if c) > min(max_parts, 8):
+            return -2
         n = _n(n_rows_max, n_dev)
-        pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
-        one = type(segs[0]) * 1
-        tm_off = slot = 0
+        n_out = n_segs + sum(1 for c in cut if c)
+        pv = view(part, n_out * ld_part * 2, np.float32).reshape(n_out, ld_part, 2)
+        Seg = type(segs[0])
+        one = Seg * 1
+        tm_off = slot = o = 0
         for i in range(n_segs):
-            if is_mixed[i]:
-                if n:
-                    y = self._mixed_logits(mixed[i], Tm, ld_tm, tm_off, slot, n, mx_descale[i], mx_s8[i])
-                    mx = y.max(axis=1)
-                    pv[i, :n, 0] = mx
-                    pv[i, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
-                tm_off += mixed[i].ldb * 4
-                slot += 1
-            else:
-                r = self.jlm_vocab_lse_split(one(segs[i]), [t_scale[i]], [descale[i]], [bias_col[i]], 1, b2, T, ldt, rows,
-                                             _p(part) + 8 * i * ld_part, ld_part, 1, n_rows_max, n_dev, stream)
+            if not is_mixed[i] or cut[i]:
+                sg = Seg(segs[i].v_start, segs[i].v_start + cut[i] if cut[i] else segs[i].v_end, segs[i].k, segs[i].t_off, segs[i].B, segs[i].ldb)
+                r = self.jlm_vocab_lse_split(one(sg), [t_scale[i]], [descale[i]], [bias_col[i]], 1, b2, T, ldt, rows,
+                                             _p(part) + 8 * o * ld_part, ld_part, 1, n_rows_max, n_dev, stream)
                 if r != 1:
                     return r
-        return n_segs
+                o += 1
+            if is_mixed[i]:
+                if n:
+                    y = self._mixed_logits(mixed[i], Tm, ld_tm, tm_off, slot, n, mx_descale[i], mx_s8[i])[:, cut[i]:]
+                    mx = y.max(axis=1)
+                    pv[o, :n, 0] = mx
+                    pv[o, :n, 1] = np.exp(y - mx[:, None]).sum(axis=1)
+                tm_off += mixed[i].ldb * 4
+                slot += 1
+                o += 1
+        return n_out
 
     def jlm_lse_combine(self, part, ld_part, n_tiles, rows, lse, n_rows_max, n_dev, stream):
         n = _n(n_rows_max, n_dev)
@@ -941,7 +956,7 @@ class FakeLib:
 # -- and hands them to the numpy double of the C ABI above, so the host code is driven through the same two layers.
 class _FakeModel:
     def __init__(self, t, i, f, seg_B, seg_meta, split_B, split_meta, t_scale, descale, bias_col, mixed_idx=(), mixed_B=(), mixed_meta=(),
-                 mixed_t_scale=(), mixed_descale=(), mixed_s8=()):
+                 mixed_t_scale=(), mixed_descale=(), mixed_s8=(), mixed_head_split=()):
         from jlm_amd import _lib
         self.keep = (t, list(seg_B), list(split_B), list(mixed_B))
 
@@ -985,6 +1000,12 @@ class _FakeModel:
             m.mixed_descale = ctypes.cast(self.mds, ctypes.POINTER(ctypes.c_float))
             m.mixed_s8 = ctypes.cast(self.ms8, ctypes.POINTER(ctypes.c_float))
             m.mixed_bias2 = ptr("b2_log2")
+            self.mhs = (ctypes.c_int * n)()
+            for j, si in enumerate(mixed_idx):
+                c = int(mixed_head_split[j]) if len(mixed_head_split) else 0
+                assert c >= 0 and c % 128 == 0 and c < some[j].v_end - some[j].v_start
+                self.mhs[si] = c
+            m.mixed_head_split = ctypes.cast(self.mhs, ctypes.POINTER(ctypes.c_int))
 
 
 class _FakePlan:

@@ -893,11 +893,16 @@ def test_vocab_lse_mixed_spread(L, tails):
         assert spread > 8, spread             # these are the blocks the loader keeps on split rows
 
 
+@pytest.mark.parametrize("form", ["tail-split", "head-256", "first-split", "heads"])
 @pytest.mark.parametrize("V,bounds,R", [(50000, [0, 12000, 30000, 50000], 2560), (3100, [0, 700, 1900, 3100], 300)])
-def test_vocab_lse_hybrid(L, V, bounds, R):
+def test_vocab_lse_hybrid(L, V, bounds, R, form):
     """jlm_vocab_lse_hybrid: the D-softmax* shapes in one launch -- k = 200 and k = 100 on mixed rows (int8 cross terms), k = 50 on
-    split rows (three f16 passes) -- against the f64 evaluation of the f32 operands"""
+    split rows (three f16 passes) -- against the f64 evaluation of the f32 operands.  ABI 10: the head of a mixed segment on its split
+    rows (`head-256`: the first 256 words of the first segment; `heads`: of the first two), a whole long segment on split rows beside
+    mixed ones (`first-split`: what the loader falls back to for a model whose first segment carries the error)"""
     import ctypes
+    mixed_set, heads = {"tail-split": ((0, 1), None), "head-256": ((0, 1, 2), [256, 0, 0]), "first-split": ((1, 2), None),
+                        "heads": ((0, 1, 2), [128, 384, 0])}[form]
     widths = [200, 100, 52]
     rng = np.random.default_rng(V + R)
     b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
@@ -915,23 +920,25 @@ def test_vocab_lse_hybrid(L, V, bounds, R):
         sts[i] = 2.0 ** 10
         sds[i] = 2.0 ** -(10 + 6)
     mixed = (_lib.Segment * n)()
-    for i in range(2):
+    for i in mixed_set:
         mixed[i] = mx[i]
-    only = (_lib.Segment * 2)(mx[0], mx[1])
+    nm = len(mixed_set)
+    only = (_lib.Segment * nm)(*[mx[i] for i in mixed_set])
     G = R + 9
     T_np = (np.tanh(rng.standard_normal((G, ldt))) * rng.uniform(0.05, 1.0, size=(G, 1))).astype(np.float32)
     T = torch.as_tensor(T_np).cuda()
     rows_np = rng.permutation(G)[:R].astype(np.int32)
     rows = torch.as_tensor(rows_np).cuda()
     nd = torch.as_tensor(np.array([R - 2], dtype=np.int32)).cuda()
-    ld_tm = L.jlm_mixed_t_stride(only, 2)
+    ld_tm = L.jlm_mixed_t_stride(only, nm)
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
-    assert L.jlm_pack_t_mixed(only, (ctypes.c_float * 2)(ts[0], ts[1]), 2, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
+    assert L.jlm_pack_t_mixed(only, (ctypes.c_float * nm)(*[ts[i] for i in mixed_set]), nm, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
                               Tm.data_ptr(), ld_tm, _st()) == 0
-    part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
-    nn = L.jlm_vocab_lse_hybrid(sp, sts, sds, bc, mixed, ds, s8, n, b2.data_ptr(), T.data_ptr(), ldt, Tm.data_ptr(), ld_tm,
-                                rows.data_ptr(), part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
-    assert nn >= n, nn
+    part = torch.zeros((100, R, 2), dtype=torch.float32, device="cuda")
+    hs = (ctypes.c_int * n)(*heads) if heads else None
+    nn = L.jlm_vocab_lse_hybrid(sp, sts, sds, bc, mixed, ds, s8, hs, n, b2.data_ptr(), T.data_ptr(), ldt, Tm.data_ptr(), ld_tm,
+                                rows.data_ptr(), part.data_ptr(), R, 100, R, nd.data_ptr(), _st())
+    assert nn >= n + (sum(1 for c in heads if c) if heads else 0), nn
     torch.cuda.synchronize()
     p = part[:nn, :R - 2].cpu().numpy().astype(np.float64)
     with np.errstate(divide="ignore"):

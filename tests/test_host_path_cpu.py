@@ -403,11 +403,13 @@ def test_packed_rows_take_32_blocks_at_most(tmp_path, fake):
     assert m.split_array is not None and m.mixed_idx == [] and m.ld_tm == 0 and m.mixed_calib is None
 
 
-@pytest.mark.parametrize("mult,kept", [(1.0, True), (40.0, False)])
+@pytest.mark.parametrize("mult,kept", [(1.0, True), (40.0, False), ((40.0, 1.0, 1.0), "first-split"), ("words<128", "head")])
 def test_load_time_calibration_follows_the_logit_range(tmp_path, fake, monkeypatch, mult, kept):
     """DeviceModel._calibrate_mixed over the numpy double: the same model keeps its mixed rows with its output embeddings as they are and
-    loses them with the embeddings x 40 (logits of +-40: the int8 cross terms would move path scores beyond the tolerance) -- and the
-    decode equals the oracle either way."""
+    loses them with the embeddings x 40 (logits of +-40: the int8 cross terms would move path scores beyond the tolerance); with only
+    the FIRST segment's embeddings x 40 -- the frequent words carry the mass, as in a trained model -- that segment goes to split rows and
+    the other two stay mixed (round 5: jlm_vocab_lse_hybrid hosts the long split body); with every embedding x 10 and a bias that puts
+    the mass on the first 128 words, those words alone (head_split) -- and the decode equals the oracle every time."""
     for k in ("JLM_MIXED_MAX_LSE_RMS", "JLM_MIXED_MAX_SPREAD", "JLM_LSE_MIXED"):
         monkeypatch.delenv(k, raising=False)
     root = str(tmp_path)
@@ -415,8 +417,15 @@ def test_load_time_calibration_follows_the_logit_range(tmp_path, fake, monkeypat
     _lex, _rd = synth.write_lexicon(root, 2000, alphabet=12)
     w = synth.make_weights(cfg, scale=0.1)
     for key in list(w):
-        if key.startswith("LM"):
-            w[key] = (w[key] * np.float32(mult)).astype(np.float32)
+        if key.startswith("LM") and mult == "words<128":
+            w[key] = (w[key] * np.float32(10.0)).astype(np.float32)
+        elif key.startswith("LM"):
+            f_ = mult[int(key[2:])] if isinstance(mult, tuple) else mult
+            w[key] = (w[key] * np.float32(f_)).astype(np.float32)
+    if kept == "head":
+        w["b2"][:128] += np.float32(12.0)            # (embeddings x 10 everywhere, the mass on the first 128 words: 1.1e-5 rms on mixed rows, 7.5e-8 with that head on split rows)
+        from jlm_amd.model import DeviceModel
+        monkeypatch.setattr(DeviceModel, "HEAD_SPLITS", (128, 256))
     import json
     import pickle
     d = os.path.join(root, "train", "experiments", "1")
@@ -430,7 +439,11 @@ def test_load_time_calibration_follows_the_logit_range(tmp_path, fake, monkeypat
     dec = Decoder(1)
     dec.perf_timing = False
     m = dec.model.dev
-    assert m.mixed_calib is not None and m.mixed_calib["kept"] == kept and bool(m.mixed_idx) == kept, m.mixed_calib
+    assert m.mixed_calib is not None and m.mixed_calib["kept"] == bool(kept) and bool(m.mixed_idx) == bool(kept), m.mixed_calib
+    if kept == "head":
+        assert m.mixed_idx == [0, 1, 2] and m.mixed_head_split == [128, 0, 0] and m.mixed_calib["head_split"] == 128, m.mixed_calib
+    if kept == "first-split":
+        assert m.mixed_idx == [1, 2] and m.mixed_calib["split_segments"] == [0] and m.mixed_calib["lse_rms_diff_all_mixed"] > 1e-6, m.mixed_calib
     sents = synth.make_ragged_sentences(5, 2, 9, seed=5, alphabet=12)
     o = orc.OracleDecoder(root, 1)
     for s, g in zip(sents, dec.decode_batch(sents, beam_width=6)):

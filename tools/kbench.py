@@ -172,8 +172,9 @@ def bench_lse_mixed(V, widths, R, tag):
     report("pack_t_mixed         %s R=%d" % (tag, R), 1.0, timeit(g))
 
 
-def bench_lse_hybrid(V, widths, R, tag, n_mixed=2):
-    """jlm_vocab_lse_hybrid: the first n_mixed segments on mixed rows, the rest on split rows with a bias column"""
+def bench_lse_hybrid(V, widths, R, tag, mixed_set=(0, 1), heads=None):
+    """jlm_vocab_lse_hybrid: the segments of mixed_set on mixed rows, the rest on split rows with a bias column; heads: the leading words
+    of a mixed segment that stay on split rows (ABI 10)"""
     if flt and flt not in "lse":
         return
     if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "hybrid mixed split " + tag:
@@ -199,7 +200,7 @@ def bench_lse_hybrid(V, widths, R, tag, n_mixed=2):
         if bcol[i] >= 0:
             assert L.jlm_pack_split_f16_col(b2.data_ptr() + 4 * bounds[i], nv, 1024.0, sp[i].B, sp[i].ldb, bcol[i], st) == 0
         ts[i], ds[i] = 16.0, 1.0 / (16.0 * 1024.0)
-        if i < n_mixed:
+        if i in mixed_set:
             nb = (kp + 2 + 31) // 32
             dst = torch.zeros((nv, 32 * nb), device=dev)
             assert L.jlm_pack_mixed(Bm.data_ptr(), nv, kp, kp, b2.data_ptr() + 4 * bounds[i], 2.0 ** 15, 2.0 ** 15 * 1.4427, 2.0 ** 7,
@@ -213,17 +214,21 @@ def bench_lse_hybrid(V, widths, R, tag, n_mixed=2):
     part = torch.empty((96, R, 2), device=dev)
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     rows = torch.arange(R, device=dev, dtype=torch.int32)
-    only = (_lib.Segment * n_mixed)(*[mx[i] for i in range(n_mixed)])
+    n_mixed = len(mixed_set)
+    only = (_lib.Segment * n_mixed)(*[mx[i] for i in mixed_set])
+    only_ts = (ctypes.c_float * n_mixed)(*[mts[i] for i in mixed_set])
     ld_tm = L.jlm_mixed_t_stride(only, n_mixed)
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
-    g = lambda: L.jlm_pack_t_mixed(only, mts, n_mixed, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
+    g = lambda: L.jlm_pack_t_mixed(only, only_ts, n_mixed, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
-    f = lambda: L.jlm_vocab_lse_hybrid(sp, ts, ds, bcol, mx, mds, ms8, n, b2.data_ptr(), T.data_ptr(), off, Tm.data_ptr(), ld_tm,
+    hs = (ctypes.c_int * n)(*heads) if heads else None
+    f = lambda: L.jlm_vocab_lse_hybrid(sp, ts, ds, bcol, mx, mds, ms8, hs, n, b2.data_ptr(), T.data_ptr(), off, Tm.data_ptr(), ld_tm,
                                        rows.data_ptr(), part.data_ptr(), R, 96, R, nd.data_ptr(), st)
     print("parts:", f())
-    report("vocab_lse_hybrid     %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
+    what = "mixed %s heads %s" % (list(mixed_set), heads)
+    report("vocab_lse_hybrid     %s V=%d k=%s R=%d %s" % (tag, V, widths, R, what), flops, timeit(f))
     report("pack_t_mixed (%d seg) %s R=%d" % (n_mixed, tag, R), 1.0, timeit(g))
-    report("pack_t + hybrid      %s R=%d" % (tag, R), flops, timeit(lambda: (g(), f())))
+    report("pack_t + hybrid      %s R=%d %s" % (tag, R, what), flops, timeit(lambda: (g(), f())))
 
 
 def bench_gate(H, E, R):
@@ -302,6 +307,11 @@ if __name__ == "__main__":
         bench_lse_split(50000, [200, 100, 50], R, "dsoftmax*", bias_col=True)
         bench_lse_mixed(50000, [200, 100, 50], R, "dsoftmax*")
         bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*")
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*", mixed_set=(0, 1, 2))
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*", mixed_set=(0, 1, 2), heads=[2048, 0, 0])
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*", mixed_set=(0, 1, 2), heads=[8192, 0, 0])
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*", mixed_set=(1, 2))
+        bench_lse_hybrid(50000, [200, 100, 50], R, "dsoftmax*", mixed_set=(1,))
         if os.environ.get("KBENCH_SEGS"):
             for V1, k1 in ((12000, 200), (18000, 100), (20000, 50)):
                 bench_lse_split(V1, [k1], R, "seg-k%d" % k1, bias_col=True)
