@@ -385,12 +385,20 @@ class DeviceModel:
 
     CALIB_ROWS, CALIB_STEPS, CALIB_SEED = 256, 3, 20240929
     FIXED_REF_MAX_BITS = 40.0
-    HEAD_SPLITS = (1024, 2048, 4096, 8192)
+    # Heads of the first segment that the loader may keep on split rows (jlm_vocab_lse_hybrid head_split).  EMPTY by default: on the
+    # trained-model-like fixture (peaked20-vtable) a head of 2 048 .. 8 192 words brings the probe's rms from 3.0e-6 to 3e-7 .. 8e-7, and
+    # the golden decodes still miss the reference scores by 4.6e-5 .. 4.8e-5 (every segment mixed: 7.2e-5; first segment on split rows:
+    # 1.3e-5, the split form's own figure; profiles/r05_x_form_vs_score.txt) -- the rows whose mass sits on a word behind the head keep
+    # the whole error, a tail the rms of 256 probe rows does not show and their maximum shows only for some seeds.  A caller with evidence
+    # that its model's mass follows word frequency sets e.g. (1024, 2048, 4096, 8192); the kernel form is tested either way.
+    HEAD_SPLITS = ()
+    # acceptance of a form: rms <= limit AND no probe row above CALIB_MAX_FACTOR x limit (Gaussian-like error: max / rms = 4 .. 5 over 256 rows)
+    CALIB_MAX_FACTOR = 8.0
 
     def _head_split_possible(self):
         """the first segment's head can stay on split rows: every segment on mixed rows in a shape the two-format launch hosts
         (csrc/jlm_split.hip jlm_vocab_lse_hybrid: k + 2 <= 208 with bias columns), the first one the model's first words"""
-        if not self.HEAD_SPLITS or self.mode == "untied" or self.split_array is None:
+        if self.mode == "untied" or self.split_array is None:
             return False
         if list(self.mixed_idx) != list(range(self.n_segs)) or not self.mixed_segments or self.mixed_segments[0]["v_start"] != 0:
             return False
@@ -474,7 +482,8 @@ class DeviceModel:
             lse.append(r)
         err = lambda a: (float(np.sqrt(np.mean((a - lse[0]) ** 2))), float(np.abs(a - lse[0]).max()))
         rms, worst = err(lse[1])
-        keep = bool(np.isfinite(rms) and rms <= limit)
+        ok = lambda rms, worst, f=1.0: bool(np.isfinite(rms) and rms <= f * limit and worst <= self.CALIB_MAX_FACTOR * f * limit)
+        keep = ok(rms, worst)
         self.mixed_calib = dict(rows=R, steps=S, lse_rms_diff=rms, lse_max_diff=worst, limit=limit, kept=keep,
                                 lse_mean=float(np.mean(lse[0])))
         # Round 5 (ABI 10): above the limit, keep the words that carry the error on split rows and the rest on mixed rows
@@ -482,8 +491,7 @@ class DeviceModel:
         # trained model's mass sits on the frequent words -- the low ids (the lexicon is sorted by frequency, decoder.py:54-77; D-softmax's
         # segments are cut along it).  Measured on logits of +-20 (peaked20-vtable): the first segment's 12 000 words carry 0.935 of the
         # mass and all of the 3.1e-6 rms; the other 38 000 add 2e-8.  Two forms, tried in order of cost:
-        #   a HEAD of the first segment (HEAD_SPLITS words) on split rows -- accepted only with margin (half the limit, and no probe row
-        #     above five times the limit: a head that leaves single rows far out has not caught the words that matter);
+        #   a HEAD of the first segment (HEAD_SPLITS words; none by default -- see there) on split rows, accepted at half the limit;
         #   the whole first segment on split rows, the others mixed -- accepted at the limit like any other form.
         if not keep and np.isfinite(rms) and self._head_split_possible():
             full = dict(lse_rms_diff_all_mixed=rms, lse_max_diff_all_mixed=worst)
@@ -496,7 +504,7 @@ class DeviceModel:
                 if isinstance(r, str):
                     break
                 rms, worst = err(r)
-                if np.isfinite(rms) and rms <= 0.5 * limit and worst <= 5.0 * limit:
+                if ok(rms, worst, 0.5):
                     keep = True
                     self.mixed_calib.update(full, lse_rms_diff=rms, lse_max_diff=worst, kept=True, head_split=cut)
                     break
@@ -512,7 +520,7 @@ class DeviceModel:
                     r = probe(1)
                     if not isinstance(r, str):
                         rms, worst = err(r)
-                        if np.isfinite(rms) and rms <= limit:
+                        if ok(rms, worst):
                             keep = True
                             self.mixed_calib.update(full, lse_rms_diff=rms, lse_max_diff=worst, kept=True, head_split=nv0,
                                                     split_segments=[0])

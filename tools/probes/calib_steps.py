@@ -23,5 +23,6 @@ for name in names:
                 print("%-16s steps %2d seed %8d: no calibration (no mixed rows built)" % (name, steps, seed)); continue
             print("%-16s steps %2d seed %8d: rms %.3e max %.3e |logZ| %.1f bits kept %s fixed_ref %s%s" % (
                 name, steps, seed, c.get("lse_rms_diff", float("nan")), c.get("lse_max_diff", float("nan")), c.get("lse_abs_max_bits", float("nan")),
-                c.get("kept"), c.get("fixed_ref"), ("  (" + c["reason"] + ")") if c.get("reason") else ""))
+                c.get("kept"), c.get("fixed_ref"), (("  head_split %s%s" % (c["head_split"], " (first segment)" if c.get("split_segments") else "")) if c.get("head_split") else "") +
+                (("  (" + c["reason"] + ")") if c.get("reason") else "")))
             del m; torch.cuda.empty_cache()
