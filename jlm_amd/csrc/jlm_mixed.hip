@@ -342,9 +342,6 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
 }
 
 // the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
-// (jlm_mixed_fs.hip: the format-sliced wave pairs, JLM_MX_FS=1)
-int jlm_mx_fs_launch(const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
-                     hipStream_t st);
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
                        int n_ptiles, int lds, hipStream_t st);
 
@@ -497,12 +494,6 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     // JLM_MX_WIDE: 1 the wide kernel (jlm_mixed_w.hip) for every shape it hosts, 0 never, -1 (default) where it measures faster: the tied
     // k = 256 shapes -- 116.6-118.0 vs 122.7-124.5 us at V = 50 k / 2 560 rows, 1 691 vs 1 813 us at V = 100 k / 20 480 rows; the
     // D-softmax* launch measures the same on both (70.5 vs 70.0 us) and stays on the eight-wave kernel (profiles/r05_r_wide_tied.txt)
-    static int fs = -1;
-    if (fs < 0) { const char *e = getenv("JLM_MX_FS"); fs = e ? atoi(e) : 0; }
-    if (which == 0 && fs > 0) {
-        if (int rc = jlm_mx_fs_launch(a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, st)) return rc;
-        return n_sub;
-    }
     if ((which == 0 && wide > 0) || (which == 2 && wide != 0)) {
         if (int rc = jlm_mx_wide_launch(which == 2 && fixref ? 4 : which, a, Tm, ld_tm, part2, ld_part, n_rows_max, n_dev, n_ptiles, lds, st)) return rc;
         return n_sub;

@@ -7,7 +7,7 @@ TAG=$1; FLAGS=$2; shift 2
 cd "$(dirname "$0")/../jlm_amd/csrc"
 mkdir -p ../../build_prof/$TAG
 OBJS=""
-for s in jlm_gemm jlm_beam jlm_split jlm_gate jlm_mixed jlm_mixed_fs jlm_decode jlm_gate_ws jlm_mixed_w; do
+for s in jlm_gemm jlm_beam jlm_split jlm_gate jlm_mixed jlm_decode jlm_gate_ws jlm_mixed_w; do
   if [[ " $* " == *" $s.hip "* ]]; then
     X=""; { [ $s = jlm_gate_ws ] || [ $s = jlm_mixed_w ]; } && X="-mllvm -amdgpu-mfma-vgpr-form"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS $X -c -o ../../build_prof/$TAG/$s.o $s.hip &
