@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* Library / device probe.  Returns the ABI version (JLM_ABI_VERSION). */
-#define JLM_ABI_VERSION 10
+#define JLM_ABI_VERSION 11
 #define JLM_MAX_BEAM 1024           /* ABI 6: jlm_beam_step takes beams above one wave (64): a lane owns several ranks */
 int jlm_abi_version(void);
 /* Writes gfx arch name (e.g. "gfx950:sramecc+:xnack-") of device `dev`. */
@@ -338,6 +338,18 @@ int jlm_pack_mixed(const float *src, int rows, int k, int ld, const float *bias,
 int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs);
 int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
                      int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream);
+/* ABI 11 (round 6): mx6 rows -- the two cross terms of the split product as FP6 (e2m3) x FP6 on the block-scaled matrix instruction
+ * (v_mfma_scale_f32_32x32x64_f8f6f4: one instruction per 32 k-values for both terms, accumulated into the f16 pass's f32 accumulator;
+ * csrc/jlm_mx6_body.h, csrc/jlm_mx6.hip; reference project + softmax, decoder/model.py:141-193, 15-20).  Same 128-byte blocks, strides
+ * and buffers as the int8 form; granules 4-6 of a block hold the FP6 planes (hi6, lo6) and granule 7 of a row's first block their E8M0
+ * scales, one per plane and 32 k-values.  Selected by s8 = 0:
+ *   jlm_pack_mixed(..., s8 = 0, ...)           packs a vocabulary block as mx6 rows (at most 8 blocks per row: k + 2 <= 256 or k = 256);
+ *   jlm_pack_t_mixed6                            packs hypothesis rows in that form (same arguments and stride as jlm_pack_t_mixed);
+ *   jlm_vocab_lse_mixed(_fr)(..., s8[i] = 0 for EVERY segment, ...)  runs the launch on mx6 rows (-2: formats mixed within a launch,
+ *                                                or k = 512); jlm_vocab_lse_hybrid takes int8 rows only (-2);
+ *   jlm_decode_model.mixed_s8[i] = 0 for every mixed segment makes jlm_decode_frames / jlm_lse_probe use the two above. */
+int jlm_pack_t_mixed6(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                      int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream);
 /* segs[i].B = mixed rows, segs[i].ldb = 32 nb, segs[i].k the true contraction length; descale[i] = 2^-(eT_i + eB_i), s8[i] as
  * above; Tm = the packed hypothesis rows.  Same partial-slice contract and return value as jlm_vocab_lse_split; -2: a shape
  * this form does not take (more than 8 blocks; segments of both bias forms in one launch).

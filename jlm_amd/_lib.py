@@ -96,12 +96,12 @@ _SIGS = {
                               POINTER(c_float), POINTER(c_int), c_int, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P, P], c_int),
     "jlm_mixed_t_stride": ([POINTER(Segment), c_int], c_int),
     "jlm_pack_t_mixed": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
+    "jlm_pack_t_mixed6": ([POINTER(Segment), POINTER(c_float), c_int, P, c_int, P, c_int, P, P, c_int, P], c_int),
     "jlm_vocab_lse_mixed": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
                             c_int),
     "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_vocab_lse_mixed_fr": ([POINTER(Segment), POINTER(c_float), POINTER(c_float), P, c_int, P, c_int, P, c_int, c_int, c_int, P, P],
                             c_int),
-    "jlm_backtrace": ([POINTER(Lattice), POINTER(BeamState), P, P, P, c_int, P], c_int),
     "jlm_softmax_rows": ([P, P, c_int, c_int, c_int, c_int, P], c_int),
     "jlm_decode_frames": ([POINTER(DecodeModel), POINTER(DecodePlan), POINTER(Lattice), POINTER(BeamState), P, P, P], c_int),
     "jlm_lse_probe": ([POINTER(DecodeModel), P, P, P, c_int, c_int, P, P, P, P, c_int, c_int, P, c_int, P], c_int),
@@ -132,7 +132,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
-        if l.jlm_abi_version() != 10:
+        if l.jlm_abi_version() != 11:
             raise JlmHipError("libjlm_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -39,6 +39,16 @@ thread_local EventPool g_events;
 
 }  // namespace
 
+// ABI 11: the model's mixed segments are mx6 rows (FP6 cross-term planes, csrc/jlm_mx6_body.h) when their s8 is 0 -- the hypothesis
+// rows are then packed by jlm_pack_t_mixed6; a model mixes the two formats in no launch (jlm_vocab_lse_mixed: -2)
+static inline bool jlm_model_mx6(const jlm_decode_model *m) {
+    if (!m->mixed_segs || !m->mixed_s8) return false;
+    for (int i = 0; i < m->n_segs; ++i)
+        if (m->mixed_segs[i].B) return m->mixed_s8[i] == 0.0f;
+    return false;
+}
+#define JLM_PACK_T_MIXED(m) (jlm_model_mx6(m) ? jlm_pack_t_mixed6 : jlm_pack_t_mixed)
+
 extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_plan *p, const jlm_lattice *lat,
                                  const jlm_beam_state *st_in, void *stream, void *side_stream, void *const *events) {
     const int B = lat->n_sent, beam = lat->beam, F = lat->n_frames;
@@ -147,7 +157,7 @@ extern "C" int jlm_decode_frames(const jlm_decode_model *m, const jlm_decode_pla
                 if (m->mixed_segs[i].B) { only[n_only] = m->mixed_segs[i]; only_ts[n_only++] = m->mixed_t_scale[i]; }
             if (n_only) {
                 if (jlm_mixed_t_stride(only, n_only) != p->ld_tm) return -1;
-                if (!JLM_SKIPPED(32)) JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, p->T, m->ldt, rows, f == 0 ? B : rmax, ndev, p->Tm, p->ld_tm, stream));
+                if (!JLM_SKIPPED(32)) JLM_TRY(JLM_PACK_T_MIXED(m)(only, only_ts, n_only, p->T, m->ldt, rows, f == 0 ? B : rmax, ndev, p->Tm, p->ld_tm, stream));
                 hybrid = true;
                 all_mixed = n_only == m->n_segs;
                 // (ABI 10) a segment whose head stays on split rows: the launch over both formats
@@ -260,9 +270,9 @@ extern "C" int jlm_lse_probe(const jlm_decode_model *m, const int *rowlist, cons
         }
         if (!m->mixed_segs || !m->mixed_segs[0].B || !Tm) return -2;
         if (jlm_mixed_t_stride(m->mixed_segs, 1) != ld_tm) return -1;
-        JLM_TRY(jlm_pack_t_mixed(m->mixed_segs, m->mixed_t_scale, 1, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
-        return jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, 1, Tm, ld_tm, part, rows, max_parts, rows,
-                                   nullptr, stream);
+        JLM_TRY(JLM_PACK_T_MIXED(m)(m->mixed_segs, m->mixed_t_scale, 1, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
+        return (m->lse_fixed_ref ? jlm_vocab_lse_mixed_fr : jlm_vocab_lse_mixed)(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, 1, Tm,
+                                                                                 ld_tm, part, rows, max_parts, rows, nullptr, stream);
     }
     if (!m->split_segs || !m->pmt_split) return -2;
     for (int t = 1; t <= steps; ++t)
@@ -281,14 +291,14 @@ extern "C" int jlm_lse_probe(const jlm_decode_model *m, const int *rowlist, cons
     for (int i = 0; i < m->n_segs; ++i)
         if (m->mixed_segs[i].B) { only[n_only] = m->mixed_segs[i]; only_ts[n_only++] = m->mixed_t_scale[i]; }
     if (!n_only || jlm_mixed_t_stride(only, n_only) != ld_tm) return -1;
-    JLM_TRY(jlm_pack_t_mixed(only, only_ts, n_only, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
+    JLM_TRY(JLM_PACK_T_MIXED(m)(only, only_ts, n_only, T, m->ldt, rl, rows, nullptr, Tm, ld_tm, stream));
     bool cut = false;
     if (m->mixed_head_split)
         for (int i = 0; i < m->n_segs; ++i)
             if (m->mixed_segs[i].B && m->mixed_head_split[i] > 0) cut = true;
-    if (n_only == m->n_segs && !cut)
-        return jlm_vocab_lse_mixed(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2, m->n_segs, Tm, ld_tm, part, rows, max_parts,
-                                   rows, nullptr, stream);
+    if (n_only == m->n_segs && !cut)       // (the form the decode launches: without a running maximum when the model says so)
+        return (m->lse_fixed_ref ? jlm_vocab_lse_mixed_fr : jlm_vocab_lse_mixed)(m->mixed_segs, m->mixed_descale, m->mixed_s8, m->mixed_bias2,
+                                                                                 m->n_segs, Tm, ld_tm, part, rows, max_parts, rows, nullptr, stream);
     return jlm_vocab_lse_hybrid(m->split_segs, m->split_t_scale, m->split_descale, m->split_bias_col, m->mixed_segs, m->mixed_descale,
                                 m->mixed_s8, m->mixed_head_split, m->n_segs, m->b2, T, m->ldt, Tm, ld_tm, rl, part, rows, max_parts, rows,
                                 nullptr, stream);

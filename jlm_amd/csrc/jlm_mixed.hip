@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "jlm_mixed_body.h"
+#include "jlm_mx6_body.h"
 using namespace jlm_mx;
 
 #ifndef JLM_MX_WIDE_DEFAULT
@@ -173,6 +174,136 @@ __global__ __launch_bounds__(256) void pack_t_mixed_kernel(MxTArgs a, const floa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ mx6 rows (round 6, jlm_mx6_body.h)
+// vocabulary rows: one thread per (row, 32-k block).  hi as in pack_mixed_kernel (bias columns included); the FP6 planes -- hi6 = FP6 of
+// the f16 hi, lo6 = FP6 of the f32 residual, each with the block's own E8M0 scale -- cover the REAL k-values only (the bias columns are
+// exact in the f16 product).  Block 0's granule 7 collects the row's scale bytes: thread (r, j) writes bytes j and 8 + j of it.
+__global__ __launch_bounds__(256) void pack_mx6_kernel(const float *__restrict__ src, int rows, int k, int ld, const float *__restrict__ bias,
+                                                       float scale, float bias_scale, unsigned char *__restrict__ dst, int nb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nb) return;
+    const int r = idx / nb, j = idx - r * nb;
+    _Float16 hi[32];
+    float hf32[32], lo[32];
+    float amax_h = 0.0f, amax_l = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int kk = 32 * j + e;
+        const bool real = kk < k;
+        float x = 0.0f;
+        if (real) x = src[(size_t)r * ld + kk] * scale;
+        asm volatile("" : "+v"(x));                  // (the scaled value is used twice: jlm_common.h jlm_split2)
+        _Float16 h = (_Float16)x;
+        asm volatile("" : "+v"(h));
+        float l = x - (float)h;
+        if (!real) {
+            const float xb = (bias && k + 2 <= 32 * nb) ? bias[r] * bias_scale : 0.0f;
+            const _Float16 bh = (_Float16)xb;
+            if (kk == k) h = bh;
+            else if (kk == k + 1) h = (_Float16)((xb - (float)bh) * 2048.0f);
+            else h = (_Float16)0.0f;
+            l = 0.0f;
+        }
+        hi[e] = h;
+        hf32[e] = real ? (float)h : 0.0f;
+        lo[e] = l;
+        amax_h = fmaxf(amax_h, fabsf(hf32[e]));
+        amax_l = fmaxf(amax_l, fabsf(l));
+    }
+    const int bh_ = mx6_block_byte(amax_h), bl_ = mx6_block_byte(amax_l);
+    unsigned ph[6], pl[6];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned ch[16], cl[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ch[e] = mx6_code(hf32[16 * half + e], bh_); cl[e] = mx6_code(lo[16 * half + e], bl_); }
+        mx6_pack16(ch, ph + 3 * half);
+        mx6_pack16(cl, pl + 3 * half);
+    }
+    unsigned char *o = dst + ((size_t)r * nb + j) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(o + 16 * q) = *reinterpret_cast<const f32x4 *>(hi + 8 * q);
+    // granule 4: half 0 (hi6) dwords 0-3; granule 5: [hi6 dwords 4-5 | lo6 dwords 4-5]; granule 6: half 1 (lo6) dwords 0-3
+    *reinterpret_cast<i32x4 *>(o + 64) = i32x4{(int)ph[0], (int)ph[1], (int)ph[2], (int)ph[3]};
+    *reinterpret_cast<i32x4 *>(o + 80) = i32x4{(int)ph[4], (int)ph[5], (int)pl[4], (int)pl[5]};
+    *reinterpret_cast<i32x4 *>(o + 96) = i32x4{(int)pl[0], (int)pl[1], (int)pl[2], (int)pl[3]};
+    unsigned char *g7 = dst + (size_t)r * nb * 128 + 112;
+    g7[j] = (unsigned char)bh_;
+    g7[8 + j] = (unsigned char)bl_;
+    if (j == 0) { for (int jj = nb; jj < 8; ++jj) { g7[jj] = 0; g7[8 + jj] = 0; } }
+    else *reinterpret_cast<i32x4 *>(o + 112) = i32x4{0, 0, 0, 0};
+}
+
+// hypothesis rows: pack_t_mixed_kernel's scheme (one wave per row, lane = 16-value group of the row's segments) with FP6 planes.  The
+// halves are SWAPPED against the vocabulary rows (half 0 = lo6, half 1 = hi6): the instruction pairs k-slot with k-slot.
+__global__ __launch_bounds__(256) void pack_t_mx6_kernel(MxTArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
+                                                         int n_rows_max, const int *__restrict__ n_dev, unsigned char *__restrict__ Tm, int ld_tm) {
+    const int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int g = rows ? rows[r] : r;
+    const int lane = threadIdx.x & 63;
+    const float *trow = T + (size_t)g * ldt;
+    unsigned char *oblk = Tm + mx_tm_block(r, ld_tm);
+    int total = 0;
+    for (int si = 0; si < a.n_segs; ++si) total += 2 * a.seg[si].nb;
+    const int grp = lane;
+    int si = 0, base = 0;
+    while (si + 1 < a.n_segs && grp >= base + 2 * a.seg[si].nb) { base += 2 * a.seg[si].nb; ++si; }
+    const bool act = grp < total;
+    const MxTSeg sg = a.seg[si];
+    const int gs = grp - base;                        // group inside the segment: block gs >> 1, half gs & 1 (partner lane ^ 1: base is even)
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k0 = 16 * gs + 4 * q;
+        v[q] = *reinterpret_cast<const f32x4 *>(trow + sg.t_off + ((act && k0 < sg.k) ? k0 : 0));
+    }
+    _Float16 hi[16];
+    float hf32[16], lo[16];
+    float amax_h = 0.0f, amax_l = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = 16 * gs + e;
+        const bool real = act && k < sg.k;
+        float x = real ? v[e >> 2][e & 3] * sg.t_scale : (k == sg.k ? sg.tc : (k == sg.k + 1 ? sg.tc * (1.0f / 2048.0f) : 0.0f));
+        asm volatile("" : "+v"(x));
+        _Float16 h = (_Float16)x;
+        asm volatile("" : "+v"(h));
+        hi[e] = h;
+        hf32[e] = real ? (float)h : 0.0f;
+        lo[e] = real ? x - (float)h : 0.0f;
+        amax_h = fmaxf(amax_h, fabsf(hf32[e]));
+        amax_l = fmaxf(amax_l, fabsf(lo[e]));
+    }
+    amax_h = fmaxf(amax_h, __shfl_xor(amax_h, 1));
+    amax_l = fmaxf(amax_l, __shfl_xor(amax_l, 1));
+    if (!act) return;
+    const int bh_ = mx6_block_byte(amax_h), bl_ = mx6_block_byte(amax_l);
+    unsigned ch[16], cl[16], ph[3], pl[3];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ch[e] = mx6_code(hf32[e], bh_); cl[e] = mx6_code(lo[e], bl_); }
+    mx6_pack16(ch, ph);
+    mx6_pack16(cl, pl);
+    const int j = gs >> 1, half = gs & 1;
+    *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half, r)) = *reinterpret_cast<const f32x4 *>(hi);
+    *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half + 1, r)) = *reinterpret_cast<const f32x4 *>(hi + 8);
+    // plane in slot sl (lo6: 0, hi6: 1): dwords 0-3 in granule 4 + 2 sl, dwords 4-5 in granule 5 at byte 8 sl; this lane holds dwords 3 half .. 3 half + 2
+    unsigned char *g4 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 4, r), *g5 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 5, r);
+    unsigned char *g6 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 6, r);
+    if (half == 0) {
+        *reinterpret_cast<unsigned *>(g4 + 0) = pl[0]; *reinterpret_cast<unsigned *>(g4 + 4) = pl[1]; *reinterpret_cast<unsigned *>(g4 + 8) = pl[2];
+        *reinterpret_cast<unsigned *>(g6 + 0) = ph[0]; *reinterpret_cast<unsigned *>(g6 + 4) = ph[1]; *reinterpret_cast<unsigned *>(g6 + 8) = ph[2];
+        unsigned char *g7 = oblk + mx_tm_granule(sg.tm_off, 7, r);
+        g7[j] = (unsigned char)bl_;
+        g7[8 + j] = (unsigned char)bh_;
+    } else {
+        *reinterpret_cast<unsigned *>(g4 + 12) = pl[0]; *reinterpret_cast<unsigned *>(g5 + 0) = pl[1]; *reinterpret_cast<unsigned *>(g5 + 4) = pl[2];
+        *reinterpret_cast<unsigned *>(g6 + 12) = ph[0]; *reinterpret_cast<unsigned *>(g5 + 8) = ph[1]; *reinterpret_cast<unsigned *>(g5 + 12) = ph[2];
+    }
+}
+
 #ifdef JLM_WGTIME
 // -DJLM_WGTIME: per workgroup [start, end] on the constant 100 MHz clock, the segment of its last sub-range, shader-clock cycles
 // in between (tools/probes/mixed_clock.py: workgroup durations and the shader clock the kernel actually ran at)
@@ -262,6 +393,7 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mixed_kernel(MxArgs a, const
 // external-bias form of the other contractions that fill their last block (k = 64, 128, 192), out-of-line
 #define MX_KERNEL_GENERIC_XB vocab_lse_mixed_kernel<false, true, 2, 4, 4, 8, 6, 12, 8, 16>
 
+
 #ifdef JLM_MX_RESOURCES
 // one kernel per instantiation: hipcc -S -DJLM_MX_RESOURCES shows each form's own register count (the shipped kernel hosts all)
 #define MX_RES(NB_, NS_) __global__ __launch_bounds__(512, 1) void mx_res_##NB_##_##NS_(MxSeg sg, const float *T, int ldt, const int *rows, float2 *part) { \
@@ -278,9 +410,16 @@ extern "C" int jlm_pack_mixed(const float *src, int rows, int k, int ld, const f
     if (rows <= 0) return 0;
     // ld_dst = 32 ceil((k + 2) / 32): the bias rides in columns k, k + 1; = 32 ceil(k / 32) < that (k a multiple of 32): no bias columns
     // (bias ignored; jlm_vocab_lse_mixed takes the biases separately)
-    if (k <= 0 || k % 4 || ld < k || ld_dst % 32 || (ld_dst / 32 != (k + 2 + 31) / 32 && ld_dst / 32 != (k + 31) / 32) || !(s8 > 0.0f)) return -1;
+    if (k <= 0 || k % 4 || ld < k || ld_dst % 32 || (ld_dst / 32 != (k + 2 + 31) / 32 && ld_dst / 32 != (k + 31) / 32) || !(s8 >= 0.0f)) return -1;
     const int nb = ld_dst / 32;
     const long n = (long)rows * nb;
+    if (s8 == 0.0f) {                                    // ABI 11: mx6 rows (FP6 cross-term planes with block scales; at most 8 blocks per row)
+        if (nb > 8) return -1;
+        hipLaunchKernelGGL(pack_mx6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k, ld, bias,
+                           scale, bias_scale, reinterpret_cast<unsigned char *>(dst), nb);
+        JLM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(pack_mixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, k, ld, bias,
                        scale, bias_scale, 1.0f / s8, reinterpret_cast<unsigned char *>(dst), nb);
     JLM_LAUNCH_CHECK();
@@ -316,8 +455,8 @@ extern "C" int jlm_mixed_t_stride(const jlm_segment *segs_host, int n_segs) {
 
 // T [G, ldt] f32 -> Tm [G, ld_tm] packed rows, for the rows listed (rows[0 .. min(*n_dev, n_rows_max)), or 0 .. n_rows_max).
 // t_scale[i] = 2^eT_i (a power of two: x = T 2^eT log2 e).
-extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
-                                int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream) {
+static int pack_t_mixed_impl(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                             int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream, int fmt6) {
     if (n_segs < 1 || n_segs > JLM_MAX_SEGMENTS || ldt % 4) return -1;
     {
         const int want = jlm_mixed_t_stride(segs_host, n_segs);
@@ -335,12 +474,32 @@ extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_sca
         a.seg[i] = MxTSeg{sg.k, sg.t_off, nb, off, t_scale[i] * 1.4426950408889634f, sg.k + 2 <= 32 * nb ? t_scale[i] : 0.0f};
         off += nb * 128;
     }
-    hipLaunchKernelGGL(pack_t_mixed_kernel, dim3((n_rows_max + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, T, ldt, rows, n_rows_max, n_dev,
-                       reinterpret_cast<unsigned char *>(Tm), ld_tm);
+    if (fmt6) {
+        for (int i = 0; i < n_segs; ++i) if (a.seg[i].nb > 8) return -2;      // (a row's scale bytes: eight per half)
+        hipLaunchKernelGGL(pack_t_mx6_kernel, dim3((n_rows_max + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, T, ldt, rows, n_rows_max, n_dev,
+                           reinterpret_cast<unsigned char *>(Tm), ld_tm);
+    } else {
+        hipLaunchKernelGGL(pack_t_mixed_kernel, dim3((n_rows_max + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, T, ldt, rows, n_rows_max, n_dev,
+                           reinterpret_cast<unsigned char *>(Tm), ld_tm);
+    }
     JLM_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int jlm_pack_t_mixed(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                                int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream) {
+    return pack_t_mixed_impl(segs_host, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream, 0);
+}
+
+// ABI 11: the same rows in the mx6 form (FP6 planes, halves swapped against the vocabulary rows: jlm_mx6_body.h); same stride and buffer
+extern "C" int jlm_pack_t_mixed6(const jlm_segment *segs_host, const float *t_scale, int n_segs, const float *T, int ldt, const int *rows,
+                                 int n_rows_max, const int *n_dev, void *Tm, int ld_tm, void *stream) {
+    return pack_t_mixed_impl(segs_host, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream, 1);
+}
+
+// the mx6 form (jlm_mx6.hip: FP6 cross terms on the block-scaled matrix instruction)
+int jlm_mx6_launch(const MxArgs &a, bool xbias, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
+                   int lds, hipStream_t st);
 // the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
                        int n_ptiles, int lds, hipStream_t st);
@@ -468,6 +627,15 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     a.n_sub = n_sub;
     if (n_sub > max_parts) return -1;
     const int lds = lds_max;
+    // ABI 11: s8[i] == 0 for every segment = mx6 rows (jlm_mx6_body.h); one format per launch
+    int n6 = 0;
+    for (int i = 0; i < n_segs; ++i) n6 += s8[i] == 0.0f;
+    if (n6 && n6 != n_segs) return -2;
+    if (n6) {
+        if (rows_wg != 256) return -2;
+        if (int rc = jlm_mx6_launch(a, xbias, Tm, ld_tm, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles, lds, (hipStream_t)stream)) return rc;
+        return n_sub;
+    }
     // which kernel: 0 the D-softmax* shapes (inlined), 1 any other bias-column shape, 2 tied k = 256 (inlined), 3 other external-bias shapes
     int which = xbias ? 2 : 0;
     for (int i = 0; i < n_segs; ++i) {

@@ -1079,6 +1079,7 @@ extern "C" int jlm_vocab_lse_hybrid(const jlm_segment *segs_host_in, const float
             m.n_vocab = sg.v_end - sg.v_start; m.k = sg.k; m.t_off = sg.t_off; m.nb = nb;
             m.tm_off = tmoff_of[i]; m.seg = slot_of[i]; m.bias2 = nullptr;
             m.descale = mx_descale[i];
+            if (!(mx_s8[i] > 0.0f)) return -2;          // (ABI 11: mx6 rows -- s8 = 0 -- have no body in this launch)
             m.cs = mx_s8[i] * (1.0f / 2048.0f);
             const int mtt = jlm_mx::mx_blocks_per_tile(nb);
             ntiles[i] = (m.n_vocab + 32 * mtt - 1) / (32 * mtt);

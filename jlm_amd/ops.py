@@ -32,7 +32,7 @@ class HipOps:
         self._ops = torch.ops.jlm
         self.Model = torch.classes.jlm.Model
         self.Plan = torch.classes.jlm.Plan
-        if int(self._ops.abi_version()) != 10:
+        if int(self._ops.abi_version()) != 11:
             raise _lib.JlmHipError("libjlm_hip.so ABI version mismatch")
 
     def __getattr__(self, name):

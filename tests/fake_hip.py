@@ -43,7 +43,20 @@ def _rows(rows, n):
 
 class FakeLib:
     def jlm_abi_version(self):
-        return 10
+        return 11
+
+    @staticmethod
+    def _mx6_model(m):
+        """ABI 11: the model's mixed segments are mx6 rows (s8 = 0): csrc/jlm_decode.hip jlm_model_mx6"""
+        if not m.mixed_segs or not m.mixed_s8:
+            return False
+        for i in range(m.n_segs):
+            if m.mixed_segs[i].B:
+                return float(m.mixed_s8[i]) == 0.0
+        return False
+
+    def _pack_t_for(self, m):
+        return self.jlm_pack_t_mixed6 if self._mx6_model(m) else self.jlm_pack_t_mixed
 
     def jlm_lse_probe(self, m, rowlist, prev, word, steps, rows, h, c, T, Tm, ld_tm, form, part, max_parts, stream):
         """ABI 8 (csrc/jlm_decode.hip): `steps` LSTM steps from the zero state, T of the last block, its normaliser slices"""
@@ -70,7 +83,7 @@ class FakeLib:
         only = (_lib.Segment * len(idx))(*[m.mixed_segs[i] for i in idx])
         if self.jlm_mixed_t_stride(only, len(idx)) != ld_tm:
             return -1
-        rc = self.jlm_pack_t_mixed(only, [m.mixed_t_scale[i] for i in idx], len(idx), T, m.ldt, rl, rows, None, Tm, ld_tm, stream)
+        rc = self._pack_t_for(m)(only, [m.mixed_t_scale[i] for i in idx], len(idx), T, m.ldt, rl, rows, None, Tm, ld_tm, stream)
         if rc:
             return rc
         cut = bool(m.mixed_head_split) and any(m.mixed_head_split[i] > 0 for i in idx)
@@ -162,8 +175,8 @@ class FakeLib:
                     only = (type(m.mixed_segs[0]) * len(idx))(*[m.mixed_segs[i] for i in idx])
                     if self.jlm_mixed_t_stride(only, len(idx)) != p.ld_tm:
                         return -1
-                    r = self.jlm_pack_t_mixed(only, [m.mixed_t_scale[i] for i in idx], len(idx), p.T, m.ldt, rows, B if f == 0 else rmax,
-                                              ndev, p.Tm, p.ld_tm, stream)
+                    r = self._pack_t_for(m)(only, [m.mixed_t_scale[i] for i in idx], len(idx), p.T, m.ldt, rows, B if f == 0 else rmax,
+                                            ndev, p.Tm, p.ld_tm, stream)
                     if r:
                         return r
                     hybrid = True
@@ -518,18 +531,108 @@ class FakeLib:
         flat = view(src, (rows - 1) * ld + k, np.float32)
         x = np.zeros((rows, 32 * nb), dtype=np.float32)
         x[:, :k] = np.lib.stride_tricks.as_strided(flat, shape=(rows, k), strides=(4 * ld, 4)) * np.float32(scale)
-        hi, h8, l8 = self._quant(x, np.float32(s8))
+        mx6 = float(s8) == 0.0
+        if float(s8) < 0.0 or (mx6 and nb > 8):
+            return -1
+        hi, h8, l8 = self._quant(x, np.float32(s8 if not mx6 else 1.0))
         if cols:
             xb = (view(bias, rows, np.float32) * np.float32(bias_scale)) if _p(bias) else np.zeros(rows, dtype=np.float32)
             bh = xb.astype(np.float16)
             hi[:, k] = bh
             hi[:, k + 1] = ((xb - bh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        if mx6:
+            self._mx6_store(dst, rows, nb, nb * 128, x, hi, k, swap=False)
+            return 0
         h8[:, k:] = 0
         l8[:, k:] = 0
         vh, v8, vl = self._mixed_view(dst, rows, nb)
         vh[:] = hi.reshape(rows, nb, 32).view(np.uint8).reshape(rows, nb, 64)
         v8[:] = h8.reshape(rows, nb, 32).view(np.uint8)
         vl[:] = l8.reshape(rows, nb, 32).view(np.uint8)
+        return 0
+
+    # ------------------------------------------------------------------ ABI 11: mx6 rows (FP6 cross-term planes with E8M0 block scales)
+    @staticmethod
+    def _mx6_block_byte(amax):
+        """csrc/jlm_mx6_body.h mx6_block_byte: the smallest power of two s = 2^(byte - 127) with amax <= 7.5 s; 0 for an all-zero block"""
+        m, ex = np.frexp(amax.astype(np.float32))               # amax = m 2^ex, m in [0.5, 1)
+        e = np.where(m <= 0.9375, ex - 3, ex - 2)
+        return np.where(amax > 0, np.clip(e + 127, 0, 254), 0).astype(np.int64)
+
+    def _mx6_store(self, ptr, rows, nb, ld_bytes, x, hi, k, swap):
+        """x [rows, 32 nb] f32 (scaled), hi f16 (with the bias columns filled in) -> rows of 128-byte mx6 blocks: granules 0-3 f16 hi;
+        the FP6 planes of the REAL k-values (hi6 of the f16 hi, lo6 of the residual): vocabulary rows half 0 = hi6, half 1 = lo6;
+        hypothesis rows (swap) the other way round; granule 7 of block 0: the halves' scale bytes"""
+        from tests import mx6_emu as E
+        raw = np.frombuffer((ctypes.c_uint8 * (rows * ld_bytes)).from_address(_p(ptr)), dtype=np.uint8).reshape(rows, ld_bytes)
+        blk = raw[:, :nb * 128].reshape(rows, nb, 128)
+        blk[:, :, :64] = hi.reshape(rows, nb, 32).view(np.uint8).reshape(rows, nb, 64)
+        real = (np.arange(32 * nb) < k)[None, :]
+        h32 = np.where(real, x.astype(np.float16).astype(np.float32), np.float32(0.0))
+        lo = np.where(real, x - x.astype(np.float16).astype(np.float32), np.float32(0.0))
+        planes = []
+        for v in (h32, lo):
+            vb = v.reshape(rows, nb, 32).astype(np.float64)
+            byte = self._mx6_block_byte(np.abs(vb).max(axis=2))
+            q = E.e2m3_round(vb * np.exp2(127.0 - byte)[:, :, None])
+            code = E.e2m3_code(q)
+            bits = ((code[..., None] >> np.arange(6)) & 1).astype(np.uint8).reshape(rows, nb, 192)
+            planes.append((np.packbits(bits, axis=2, bitorder="little"), byte.astype(np.uint8)))
+        (ph, bh), (pl, bl) = planes
+        half0, half1, b0, b1 = (pl, ph, bl, bh) if swap else (ph, pl, bh, bl)
+        blk[:, :, 64:80] = half0[:, :, :16]
+        blk[:, :, 80:88] = half0[:, :, 16:24]
+        blk[:, :, 88:96] = half1[:, :, 16:24]
+        blk[:, :, 96:112] = half1[:, :, :16]
+        blk[:, :, 112:128] = 0
+        blk[:, 0, 112:112 + nb] = b0
+        blk[:, 0, 120:120 + nb] = b1
+
+    @staticmethod
+    def _mx6_load(ptr, rows, nb, ld_bytes, swap):
+        """-> (hi f64 [rows, 32 nb] from the f16 part, hi6 f64, lo6 f64: the FP6 planes with their block scales applied)"""
+        from tests import mx6_emu as E
+        raw = np.frombuffer((ctypes.c_uint8 * (rows * ld_bytes)).from_address(_p(ptr)), dtype=np.uint8).reshape(rows, ld_bytes)
+        blk = raw[:, :nb * 128].reshape(rows, nb, 128)
+        hi = np.ascontiguousarray(blk[:, :, :64]).view(np.float16).reshape(rows, 32 * nb).astype(np.float64)
+        half0 = np.concatenate([blk[:, :, 64:80], blk[:, :, 80:88]], axis=2)
+        half1 = np.concatenate([blk[:, :, 96:112], blk[:, :, 88:96]], axis=2)
+        out = []
+        for plane, sc in ((half0, blk[:, 0, 112:112 + nb]), (half1, blk[:, 0, 120:120 + nb])):
+            bits = np.unpackbits(np.ascontiguousarray(plane), axis=2, bitorder="little").reshape(rows, nb, 32, 6)
+            code = (bits * (1 << np.arange(6))).sum(axis=3)
+            out.append((E.e2m3_value(code) * np.exp2(sc.astype(np.float64) - 127.0)[:, :, None]).reshape(rows, 32 * nb))
+        h6, l6 = (out[1], out[0]) if swap else (out[0], out[1])
+        return hi, h6, l6
+
+    def jlm_pack_t_mixed6(self, segs, t_scale, n_segs, T, ldt, rows, n_rows_max, n_dev, Tm, ld_tm, stream):
+        """jlm_pack_t_mixed's rows in the mx6 form (halves swapped against the vocabulary rows)"""
+        if n_segs < 1 or n_segs > 8 or ldt % 4:
+            return -1
+        want = self.jlm_mixed_t_stride(segs, n_segs)
+        if want == -2:
+            return -2
+        if ld_tm != want:
+            return -1
+        if any(segs[i].ldb // 32 > 8 for i in range(n_segs)):
+            return -2
+        n = _n(n_rows_max, n_dev)
+        if n <= 0:
+            return 0
+        g = _rows(rows, n)
+        off = 0
+        for i in range(n_segs):
+            sg = segs[i]
+            nb = sg.ldb // 32
+            Tv = np.stack([view(_p(T) + 4 * (int(r) * ldt + sg.t_off), sg.k, np.float32) for r in g])
+            x = np.zeros((n, 32 * nb), dtype=np.float32)
+            x[:, :sg.k] = Tv * np.float32(float(t_scale[i]) * 1.4426950408889634)
+            hi = x.astype(np.float16)
+            if sg.k + 2 <= 32 * nb:
+                hi[:, sg.k] = np.float16(t_scale[i])
+                hi[:, sg.k + 1] = np.float16(float(t_scale[i]) / 2048.0)
+            self._mx6_store(_p(Tm) + off, n, nb, ld_tm * 4, x, hi, sg.k, swap=True)
+            off += nb * 128
         return 0
 
     def jlm_mixed_t_stride(self, segs, n_segs):
@@ -585,6 +688,13 @@ class FakeLib:
     def _mixed_logits(self, sg, Tm, ld_tm, tm_off, slot, n, descale, s8, bias2=None):
         """base-e logits [n, words] of a mixed segment: (hi.hi in f16 products + int8 cross terms x s_t s8 / 2048) descale ln 2"""
         nb, nv = sg.ldb // 32, sg.v_end - sg.v_start
+        if float(s8) == 0.0:                             # ABI 11: mx6 rows -- hi.hi + hi6.lo6 + lo6.hi6 into one f32 accumulator
+            bh, b6h, b6l = self._mx6_load(sg.B, nv, nb, nb * 128, swap=False)
+            th, t6h, t6l = self._mx6_load(_p(Tm) + tm_off, n, nb, ld_tm * 4, swap=True)
+            y2 = (th @ bh.T + t6h @ b6l.T + t6l @ b6h.T).astype(np.float32) * np.float32(descale)
+            if sg.k + 2 > 32 * nb:
+                y2 = y2 + view(_p(bias2) + 4 * sg.v_start, nv, np.float32)[None, :]
+            return y2.astype(np.float64) * 0.6931471805599453
         f = lambda v, dt: np.ascontiguousarray(v).view(dt).reshape(v.shape[0], -1).astype(np.float64)
         bh, b8, bl = self._mixed_view(sg.B, nv, nb)
         th, t8, tl = self._mixed_view(_p(Tm) + tm_off, n, nb, ld_tm * 4)
@@ -605,6 +715,9 @@ class FakeLib:
             return -1
         xb = [segs[i].k + 2 > segs[i].ldb for i in range(n_segs)]
         if any(xb) and (not all(xb) or not _p(bias2) or any((segs[i].ldb // 32) % 2 for i in range(n_segs))):
+            return -2
+        n6 = sum(float(s8[i]) == 0.0 for i in range(n_segs))
+        if n6 and (n6 != n_segs or any(segs[i].ldb // 32 > 8 for i in range(n_segs))):       # one format per launch; mx6: <= 8 blocks
             return -2
         n = _n(n_rows_max, n_dev)
         pv = view(part, n_segs * ld_part * 2, np.float32).reshape(n_segs, ld_part, 2)
@@ -635,6 +748,8 @@ class FakeLib:
                 return -1
             if is_mixed[i]:
                 if ((k + 2 + 31) // 32, (k + 2 + 15) // 16) not in ((7, 13), (4, 7), (2, 4)) or mixed[i].ldb != 32 * ((k + 2 + 31) // 32):
+                    return -2
+                if not (float(mx_s8[i]) > 0.0):          # (ABI 11: mx6 rows have no body in this launch)
                     return -2
             if not is_mixed[i] or cut[i]:
                 ns = (k + 15) // 16

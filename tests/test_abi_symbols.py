@@ -22,7 +22,7 @@ def test_hip_library_exports_header():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.EXPORTS) == names
-    assert lib.jlm_abi_version() == 10
+    assert lib.jlm_abi_version() == 11
 
 
 def test_host_library_exports_header():

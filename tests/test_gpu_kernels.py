@@ -720,8 +720,14 @@ def test_softmax_rows(L, R, C, sn):
     np.testing.assert_allclose(pg.cpu().numpy()[:, :C], p.numpy()[:, :C], rtol=3e-5, atol=1e-9)
 
 
-def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
-    """mixed rows of every segment (jlm_pack_mixed) + the scale arrays jlm_vocab_lse_mixed takes"""
+def _pack_t(L, fmt):
+    """the packer of the hypothesis rows for a row format: int8 planes (jlm_pack_t_mixed) or FP6 planes with block scales (ABI 11)"""
+    return L.jlm_pack_t_mixed6 if fmt == "mx6" else L.jlm_pack_t_mixed
+
+
+def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10, fmt="int8"):
+    """mixed rows of every segment (jlm_pack_mixed) + the scale arrays jlm_vocab_lse_mixed takes; fmt "mx6": s8 = 0 selects the
+    FP6 cross-term planes (csrc/jlm_mx6_body.h)"""
     import ctypes
     n = len(widths)
     segs = (_lib.Segment * n)()
@@ -736,7 +742,7 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
         bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427 if k % 32 else 0.0)
         eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
         hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
-        s_b = 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
+        s_b = 0.0 if fmt == "mx6" else 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
         nb = k // 32 if k % 32 == 0 else (k + 2 + 31) // 32          # a contraction that fills its last block: no bias columns
         dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device="cuda")
         assert L.jlm_pack_mixed(Bg.data_ptr(), nv, k, k, b2.data_ptr() + 4 * bounds[i], 2.0 ** eB, 2.0 ** eB * 1.4426950408889634,
@@ -750,16 +756,19 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10):
 
 @pytest.mark.parametrize("V,widths,bounds,R,maxp", [(2000, [200, 100, 52], [0, 700, 1300, 2000], 48, 16), (2000, [200, 100, 52], [0, 700, 1300, 2000], 300, 96),
                                                     (3000, [256], [0, 3000], 200, 24), (1500, [512], [0, 1500], 130, 12)])
-def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp):
+@pytest.mark.parametrize("fmt", ["int8", "mx6"])
+def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp, fmt):
     """Round 5: IDENTICAL hypothesis rows (frame 0 of every decode: all sentences leave the <eos> state) must get bit-identical slices
     whichever wave, row set or lane of the kernel they land in -- the order of a frame's live rows is not deterministic, so a
     kernel that rounds one row set differently from the other (the wide kernel did: one set's `s * scale + sum` was contracted
     into an fma, the other's was not) makes scores differ from run to run in their last bits.  Covers the eight-wave kernel, the
     wide kernel's two-row-set form (tied k = 256 by default; every shape under JLM_MX_WIDE=1) and its one-row-set form (k = 512)."""
     import ctypes
+    if fmt == "mx6" and max(widths) > 256:
+        pytest.skip("mx6 rows hold at most eight 32-k blocks")
     rng = np.random.default_rng(V + R)
     b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
-    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np, fmt=fmt)
     b2l = (b2 * 1.4426950408889634).contiguous()
     bias2 = b2l.data_ptr() if widths[0] % 32 == 0 else None
     T = torch.as_tensor(np.tile((np.tanh(rng.standard_normal((1, ldt))) * 0.7).astype(np.float32), (R, 1))).cuda()
@@ -767,7 +776,7 @@ def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp):
     ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
-    assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, None, R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
+    assert _pack_t(L, fmt)(segs, ts, len(widths), T.data_ptr(), ldt, None, R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
     lses = []
     for entry in (L.jlm_vocab_lse_mixed, L.jlm_vocab_lse_mixed_fr):       # (_fr: without a running maximum where the kernel has such a form)
         part.zero_()
@@ -789,13 +798,16 @@ def test_vocab_lse_mixed_identical_rows(L, V, widths, bounds, R, maxp):
                                                (50000, [256], [0, 50000], 2560), (4001, [256], [0, 4001], 300), (3000, [128, 64], [0, 1700, 3000], 70),
                                                # k = 512 (an untied model's vocabulary matrix at H = 512): the wide kernel's one-row-set form, 128 rows per workgroup
                                                (4001, [512], [0, 4001], 300), (50000, [512], [0, 50000], 2560), (777, [512], [0, 777], 129)])
-def test_vocab_lse_mixed(L, V, widths, bounds, R):
+@pytest.mark.parametrize("fmt", ["int8", "mx6"])
+def test_vocab_lse_mixed(L, V, widths, bounds, R, fmt):
     """jlm_vocab_lse_mixed (f16 hi.hi + int8 cross terms, csrc/jlm_mixed.hip): log-sum-exp of T.B^T + b2 over the vocabulary
     against the f64 evaluation of the f32 operands; the logits behind it are good to ~1e-5 of the row's logit scale (a one-word
     vocabulary range makes the kernel return a logit), the normaliser itself far better (the words' errors are independent)"""
+    if fmt == "mx6" and max(widths) > 256:
+        pytest.skip("mx6 rows hold at most eight 32-k blocks")
     rng = np.random.default_rng(V + R)
     b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
-    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np)
+    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np, fmt=fmt)
     b2l = (b2 * 1.4426950408889634).contiguous()
     bias2 = b2l.data_ptr() if widths[0] % 32 == 0 else None
     G = R + 9
@@ -807,7 +819,7 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
     ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
-    assert L.jlm_pack_t_mixed(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
+    assert _pack_t(L, fmt)(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
     n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
     assert n >= len(widths), n
     torch.cuda.synchronize()
@@ -831,8 +843,8 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
             import ctypes
             ld1 = L.jlm_mixed_t_stride(one, 1)
             Tm1 = torch.zeros(((R + 31) // 32 * 32, ld1), dtype=torch.float32, device="cuda")
-            assert L.jlm_pack_t_mixed(one, (ctypes.c_float * 1)(ts[i]), 1, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
-                                      Tm1.data_ptr(), ld1, _st()) == 0
+            assert _pack_t(L, fmt)(one, (ctypes.c_float * 1)(ts[i]), 1, T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(),
+                                   Tm1.data_ptr(), ld1, _st()) == 0
             n1 = L.jlm_vocab_lse_mixed(one, (ctypes.c_float * 1)(ds[i]), (ctypes.c_float * 1)(s8[i]), bias2, 1,
                                        Tm1.data_ptr(), ld1, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
             assert n1 == 1
@@ -843,8 +855,9 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R):
     assert worst <= 3e-5, worst
 
 
+@pytest.mark.parametrize("fmt", ["int8", "mx6"])
 @pytest.mark.parametrize("tails", ["gauss", "outliers", "student-t3"])
-def test_vocab_lse_mixed_spread(L, tails):
+def test_vocab_lse_mixed_spread(L, tails, fmt):
     """What the ONE int8 scale per segment costs on heavy-tailed vocabulary blocks: the error of the mixed-row normaliser grows with
     max|B| / rms B (the hi8 quantisation step is max|B| / 254 for every word) -- up to ~7e-7 x spread on the log-sum-exp; DeviceModel keeps
     blocks with a spread above JLM_MIXED_MAX_SPREAD (8) on split rows (jlm_amd/model.py, _build_mixed)."""
@@ -860,7 +873,7 @@ def test_vocab_lse_mixed_spread(L, tails):
     bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np).max()) * 1.4427)
     eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
     hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
-    s_b = 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
+    s_b = 0.0 if fmt == "mx6" else 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
     nb = (k + 2 + 31) // 32
     Bg = torch.as_tensor(B_np).cuda()
     dst = torch.zeros((V, 32 * nb), dtype=torch.float32, device="cuda")
@@ -872,7 +885,7 @@ def test_vocab_lse_mixed_spread(L, tails):
     ld_tm = L.jlm_mixed_t_stride(seg, 1)
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
     eT = 10
-    assert L.jlm_pack_t_mixed(seg, (ctypes.c_float * 1)(2.0 ** eT), 1, T.data_ptr(), k, None, R, None, Tm.data_ptr(), ld_tm, _st()) == 0
+    assert _pack_t(L, fmt)(seg, (ctypes.c_float * 1)(2.0 ** eT), 1, T.data_ptr(), k, None, R, None, Tm.data_ptr(), ld_tm, _st()) == 0
     part = torch.zeros((96, R, 2), dtype=torch.float32, device="cuda")
     n = L.jlm_vocab_lse_mixed(seg, (ctypes.c_float * 1)(2.0 ** -(eT + eB)), (ctypes.c_float * 1)(s_b), None, 1, Tm.data_ptr(), ld_tm, part.data_ptr(),
                               R, 96, R, None, _st())
@@ -886,6 +899,13 @@ def test_vocab_lse_mixed_spread(L, tails):
     ymax = y.max(axis=1)
     ref = ymax + np.log(np.exp(y - ymax[:, None]).sum(axis=1))
     err = float(np.abs(lse - ref).max())
+    if fmt == "mx6":
+        # FP6 planes carry a scale per 32 k-values of every word: an outlier sets the scale of ITS block of 32 only, and the other 31 values
+        # lose their low bits (outliers: 3e-5 at a spread of 80, student-t3: 1.1e-4 at a spread of several hundred -- inside what the int8
+        # planes are allowed, 1e-6 x spread) -- the loader's calibration, not a spread gate, decides for this format
+        print("mx6 spread", tails, spread, err)
+        assert err <= (2e-6 if tails == "gauss" else 1e-6 * spread), (tails, spread, err)
+        return
     assert err <= 1e-6 * spread, (tails, spread, err)
     if tails == "gauss":
         assert spread < 8 and err <= 2e-6, (spread, err)

@@ -284,17 +284,23 @@ def test_beams_above_one_wave(fx, fake, name, kind, kw):
         np.testing.assert_allclose([x for x, _ in g], [x for x, _ in w], rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("fmt", ["mx6", "int8"])
 @pytest.mark.parametrize("name", ["wide-vtable", "wide-dsoftmax", "wideh-vtable", "wide128-tied"])
-def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
+def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name, fmt):
     """Segments of width 200 / 100 / 50 get mixed rows at load (DeviceModel._build_mixed), the plan its packed-row buffer, and the
     frame loop packs the live rows and calls the hybrid normaliser (include/jlm_hip.h ABI 7); results as the oracle's, and as
-    the split rows' (JLM_LSE_MIXED=0)."""
+    the split rows' (JLM_LSE_MIXED=0).  Round 6: in both formats of the cross-term planes -- mx6 (FP6 with block scales, ABI 11: the
+    default where every segment has a hosted shape) and int8 (JLM_LSE_MX6=0; also what a model with a split-row segment gets)."""
     f = fx(name)
     calls = {"hybrid": 0, "pack_t": 0}
     lib = fake
+    if fmt == "int8":
+        monkeypatch.setenv("JLM_LSE_MX6", "0")
+    want_fmt = "int8" if name.startswith("wideh") else fmt          # (the two-format launch hosts int8 planes only)
     # wide-*: all three widths are hosted mixed shapes, the all-mixed launch; wideh-*: the last one stays on split rows, the hybrid
     launch = "jlm_vocab_lse_hybrid" if name.startswith("wideh") else "jlm_vocab_lse_mixed"
-    hy, pk = getattr(lib, launch), lib.jlm_pack_t_mixed
+    packer = "jlm_pack_t_mixed6" if want_fmt == "mx6" else "jlm_pack_t_mixed"
+    hy, pk = getattr(lib, launch), getattr(lib, packer)
 
     def hybrid(*a):
         calls["hybrid"] += 1
@@ -304,11 +310,17 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
         calls["pack_t"] += 1
         return pk(*a)
     monkeypatch.setattr(lib, launch, hybrid, raising=False)
-    monkeypatch.setattr(lib, "jlm_pack_t_mixed", pack_t, raising=False)
+    monkeypatch.setattr(lib, packer, pack_t, raising=False)
     dec = _decoder(f, "static")
     m = dec.model.dev
-    # the load-time calibration (DeviceModel._calibrate_mixed) has run the normaliser once in each form on its probe rows
-    assert calls["hybrid"] == calls["pack_t"] == 1 and m.mixed_calib["kept"] and m.mixed_calib["lse_rms_diff"] < 1e-6, m.mixed_calib
+    # the load-time calibration (DeviceModel._calibrate_mixed) has run the normaliser once in each form on its probe rows -- and once
+    # more in the fixed-reference form where the model's range allows it (round 6: the form itself is probed before it is enabled)
+    n_probe = len(m.CALIB_PROBES) * (1 + int("fixed_ref_lse_rms_diff" in m.mixed_calib))
+    assert len(m.mixed_calib["probes"]) == len(m.CALIB_PROBES) and m.mixed_calib["lse_rms_diff"] == max(x["rms"] for x in m.mixed_calib["probes"])
+    assert calls["hybrid"] == calls["pack_t"] == n_probe and m.mixed_calib["kept"] and m.mixed_calib["lse_rms_diff"] < 1e-6, m.mixed_calib
+    assert m.mixed_fmt == want_fmt == m.mixed_calib["fmt"] and all((x == 0.0) == (want_fmt == "mx6") for x in m.mixed_s8), (m.mixed_fmt, m.mixed_s8)
+    if m.lse_fixed_ref:
+        assert m.mixed_calib["fixed_ref_lse_rms_diff"] < 1e-6
     calls["hybrid"] = calls["pack_t"] = 0
     if name.startswith("wideh"):
         assert m.mixed_idx == [0, 1] and m.ld_tm == (7 * 128 + 4 * 128 + 32) // 4
@@ -343,7 +355,10 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name):
     monkeypatch.delenv("JLM_LSE_MIXED")
     monkeypatch.setenv("JLM_MIXED_MAX_SPREAD", "2")
     dec2 = _decoder(f, "static")
-    assert dec2.model.dev.mixed_idx == [] and dec2.model.dev.ld_tm == 0 and dec2.model.dev.mixed_spread
+    if want_fmt == "mx6":        # a scale per 32 k-values of every word: the spread gate does not apply to this format
+        assert dec2.model.dev.mixed_fmt == "mx6" and dec2.model.dev.mixed_idx == m.mixed_idx
+    else:
+        assert dec2.model.dev.mixed_idx == [] and dec2.model.dev.ld_tm == 0 and dec2.model.dev.mixed_spread
 
 
 def test_lattice_blocks_return_to_the_pool(fx, fake):

@@ -126,8 +126,10 @@ def bench_lse_split(V, widths, R, tag, bias_col=False):
     report("vocab_lse_split%s %s V=%d k=%s R=%d" % ("+bcol " if bias_col else "      ", tag, V, widths, R), flops, timeit(f))
 
 
-def bench_lse_mixed(V, widths, R, tag):
-    """jlm_vocab_lse_mixed: f16 hi.hi + int8 cross terms"""
+def bench_lse_mixed(V, widths, R, tag, fmt="int8", reps=1):
+    """jlm_vocab_lse_mixed: f16 hi.hi + the cross terms on int8 planes, or (fmt "mx6", ABI 11) on FP6 planes with block scales"""
+    if fmt == "mx6" and max(widths) > 256:
+        return
     if flt and flt not in "lse":
         return
     if os.environ.get("KBENCH_ONLY") and os.environ["KBENCH_ONLY"] not in "mixed split " + tag:
@@ -145,11 +147,12 @@ def bench_lse_mixed(V, widths, R, tag):
         nv = bounds[i + 1] - bounds[i]
         Bm = rnd(nv, kp, scale=0.05)
         dst = torch.zeros((nv, 32 * nb), device=dev)
-        assert L.jlm_pack_mixed(Bm.data_ptr(), nv, kp, kp, b2.data_ptr() + 4 * bounds[i], 2.0 ** 15, 2.0 ** 15 * 1.4427, 2.0 ** 7,
+        sb = 0.0 if fmt == "mx6" else 2.0 ** 7
+        assert L.jlm_pack_mixed(Bm.data_ptr(), nv, kp, kp, b2.data_ptr() + 4 * bounds[i], 2.0 ** 15, 2.0 ** 15 * 1.4427, sb,
                                 dst.data_ptr(), 32 * nb, st) == 0
         keep += [Bm, dst]
         segs[i] = _lib.Segment(bounds[i], bounds[i + 1], kp, off, dst.data_ptr(), 32 * nb)
-        ts[i], ds[i], s8[i] = 2.0 ** 10, 2.0 ** -25, 2.0 ** 7
+        ts[i], ds[i], s8[i] = 2.0 ** 10, 2.0 ** -25, sb
         off += kp
         flops += 2.0 * k * nv * R
     b2l = b2 * 1.4426950408889634
@@ -160,7 +163,8 @@ def bench_lse_mixed(V, widths, R, tag):
     rows = torch.arange(R, device=dev, dtype=torch.int32)
     ld_tm = L.jlm_mixed_t_stride(segs, n)
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), device=dev)
-    g = lambda: L.jlm_pack_t_mixed(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
+    pack_t = L.jlm_pack_t_mixed6 if fmt == "mx6" else L.jlm_pack_t_mixed
+    g = lambda: pack_t(segs, ts, n, T.data_ptr(), off, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, st)
     assert g() == 0
     f = lambda: L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, n, Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), st)
     np_ = f()
@@ -168,8 +172,9 @@ def bench_lse_mixed(V, widths, R, tag):
     if os.environ.get("KBENCH_DUMP"):        # bit comparison of two builds: same seed, the partial (max, sum) pairs to a file
         torch.cuda.synchronize()
         np.save("%s.%s.k%s.npy" % (os.environ["KBENCH_DUMP"], tag, "_".join(map(str, widths))), part[:np_].cpu().numpy())
-    report("vocab_lse_mixed      %s V=%d k=%s R=%d" % (tag, V, widths, R), flops, timeit(f))
-    report("pack_t_mixed         %s R=%d" % (tag, R), 1.0, timeit(g))
+    for _ in range(reps):
+        report("vocab_lse_mixed %-5s %s V=%d k=%s R=%d" % (fmt, tag, V, widths, R), flops, timeit(f))
+    report("pack_t_mixed    %-5s %s R=%d" % (fmt, tag, R), 1.0, timeit(g))
 
 
 def bench_lse_hybrid(V, widths, R, tag, mixed_set=(0, 1), heads=None):
@@ -298,6 +303,16 @@ def bench_gemm(M, N, K, tag):
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
+    if os.environ.get("KBENCH_MX6"):          # round 6: the two formats of the cross-term planes side by side, interleaved
+        for rep in range(int(os.environ["KBENCH_MX6"])):
+            for fmt in ("int8", "mx6"):
+                bench_lse_mixed(50000, [200, 100, 50], 2560, "dsoftmax*", fmt)
+                for V1, k1 in ((12000, 200), (18000, 100), (20000, 50)):
+                    bench_lse_mixed(V1, [k1], 2560, "seg-k%d" % k1, fmt)
+                bench_lse_mixed(50000, [256], 2560, "tied50k", fmt)
+        for fmt in ("int8", "mx6"):
+            bench_lse_mixed(100000, [256], 20480, "tied100k-b20", fmt)
+        sys.exit(0)
     for R in (2560,):
         bench_gate(512, 200, R)
         bench_gate_xg(512, R)
