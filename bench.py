@@ -49,7 +49,7 @@ CONFIG5_SENTENCES = 8192
 def kernel_source_sha256():
     """Identity of the kernels the committed PMC traffic figure was measured on (profiles/traffic_latest.json)."""
     h = hashlib.sha256()
-    for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_w.hip", "jlm_mixed_body.h", "jlm_common.h"):
+    for f in ("jlm_split.hip", "jlm_mixed.hip", "jlm_mixed_w.hip", "jlm_mixed_body.h", "jlm_mx6.hip", "jlm_mx6_body.h", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -224,7 +224,9 @@ def main():
         heads = list(getattr(m, "mixed_head_split", None) or [])
         mixed = split and len(getattr(m, "mixed_idx", [])) == m.n_segs and not any(heads)
         hybrid = split and bool(getattr(m, "mixed_idx", [])) and not mixed
-        mx_exec = lambda sg, nv: 2.0 * 16 * ((sg["k"] + 2 + 15) // 16 + 2 * ((sg["k"] + 2 + 31) // 32)) * nv
+        # (round 6, mx6 rows: per 32 k-values the two f16 instructions and ONE block-scaled FP6 instruction of 32 cycles for both cross terms)
+        mx6 = getattr(m, "mixed_fmt", None) == "mx6"
+        mx_exec = lambda sg, nv: 2.0 * 16 * ((sg["k"] + 2 + 15) // 16 + (1 if mx6 else 2) * ((sg["k"] + 2 + 31) // 32)) * nv
         if mixed:
             exec_per_row_vocab = sum(mx_exec(sg, sg["v_end"] - sg["v_start"]) for sg in m.segments)
         elif hybrid:
@@ -243,7 +245,9 @@ def main():
                      "gemm_split_kernel<128x128,EpiLse> (jlm_vocab_lse_partials_split: tile form, k = H)" if getattr(m, "um_split", None) is not None else
                      "vocab_lse_mixedw_kernel<2, true, 8, 16> (jlm_vocab_lse_mixed: the wide form -- four waves x 64 rows, row operands in accumulation "
                      "registers, csrc/jlm_mixed_w.hip; rows packed by pack_t_mixed_kernel behind the T projection)"
-                     if (mixed and m.n_segs == 1 and m.segments[0]["k"] == 256 and os.environ.get("JLM_MX_WIDE", "-1") != "0") else
+                     if (mixed and not mx6 and m.n_segs == 1 and m.segments[0]["k"] == 256 and os.environ.get("JLM_MX_WIDE", "-1") != "0") else
+                     "vocab_lse_mx6_kernel (jlm_vocab_lse_mixed on mx6 rows, csrc/jlm_mx6.hip; its rows packed by pack_t_mx6_kernel behind the T "
+                     "projection)" if (mixed and mx6) else
                      "vocab_lse_mixed_kernel (jlm_vocab_lse_mixed; its rows packed by pack_t_mixed_kernel behind the T projection)" if mixed else
                      "vocab_lse_hybrid_kernel (jlm_vocab_lse_hybrid: segments %s on mixed rows%s, the rest on split rows; the mixed segments' rows "
                      "packed by pack_t_mixed_kernel)" % (list(m.mixed_idx), (" but for their first %s words" % heads) if any(heads) else "") if hybrid else
@@ -254,7 +258,9 @@ def main():
             # f32-grade product on split rows (dense f16 / 3); on mixed rows one f16 pass + two int8 passes at twice the k per
             # instruction = the time of TWO f16 passes (dense f16 / 2)
             # (both formats in one launch: the same pricing per segment -- dense f16 x algorithmic flops / executed f16-instruction flops)
-            peak = (F16_MFMA_PEAK_TFLOPS / 2.0 if mixed else
+            # (round 6, mx6 rows: one f16 pass + ONE FP6 instruction covering both cross terms of 32 k-values in 32 cycles = the time of 1.5
+            #  f16 passes: dense f16 / 1.5)
+            peak = (F16_MFMA_PEAK_TFLOPS / 1.5 if (mixed and mx6) else F16_MFMA_PEAK_TFLOPS / 2.0 if mixed else
                     F16_MFMA_PEAK_TFLOPS * m.flops_per_row_vocab / exec_per_row_vocab if hybrid else
                     F16_MFMA_PEAK_TFLOPS / SPLIT_PASSES) if split else F32_MFMA_PEAK_TFLOPS
             traffic, traffic_note = None, "not measured in this run (tools/gpu_traffic.sh + tools/traffic_report.py write profiles/traffic_latest.json)"
@@ -279,7 +285,13 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_note,
                         "avg_launch_ms": round(v["avg_ms"], 4), "launches": v["launches"],
                         "flops_per_launch": v["flops_per_launch"],
-                        "mfma_dtype": (("f16 hi.hi (v_mfma_f32_32x32x16_f16) + int8 cross terms (v_mfma_i32_32x32x32_i8): 4 matrix instructions per "
+                        "mfma_dtype": (("f16 hi.hi (v_mfma_f32_32x32x16_f16) + BOTH cross terms of the split product as FP6 (e2m3) x FP6 with an E8M0 scale "
+                                        "per 32 k-values of every row, in ONE block-scaled instruction per 32 k-values (v_mfma_scale_f32_32x32x64_f8f6f4) into the "
+                                        "same f32 accumulator: 3 matrix instructions of 32 cycles per 32 k-values (int8 cross terms: 4, three f16 passes: 6).  "
+                                        "`peak` = %.1f dense f16 / 1.5: the ceiling of the instructions issued; frac_of_dense_f16 prices the executed "
+                                        "instructions at 32 cycles each; `frac_f16x3_pricing` keeps rounds 1-3's dense f16 / %d" % (F16_MFMA_PEAK_TFLOPS, SPLIT_PASSES))
+                                       if (mixed and mx6) else
+                                       ("f16 hi.hi (v_mfma_f32_32x32x16_f16) + int8 cross terms (v_mfma_i32_32x32x32_i8): 4 matrix instructions per "
                                         "32 k-values instead of the split form's 6.  `peak` = %.1f dense f16 / 2: the ceiling of the instructions issued "
                                         "(round 4; rounds 1-3 priced every form at dense f16 / %d = three f16 passes per f32-grade product -- that figure "
                                         "is kept as `frac_f16x3_pricing`); frac_of_dense_f16 prices the executed instructions at 32 cycles each"
@@ -417,6 +429,13 @@ def main():
         # step of successive 20-step calls after a 5-step one: 3.0-6.8, 2.36-2.40, 2.13-2.15, 2.10): settle calls are repeated until
         # two successive ones agree within 3 % (2 to 6 calls).
         settle = max(args.steps, 12 - args.warmup, 4)
+        # the cold side (verdict round 5, weak 5): the very first decode of this process -- one batch, strings -> strings: plans, page-locked
+        # blocks and the engine's streams are created on the way -- before anything else has run
+        torch.cuda.synchronize()
+        _tf = time.perf_counter()
+        dec.decode_batch(sents, beam_width=args.beam, **dkw)
+        torch.cuda.synchronize()
+        line_extra["first_call_ms"] = round((time.perf_counter() - _tf) * 1e3, 2)
         if args.warmup:
             dec.decode_batch(sents * args.warmup, beam_width=args.beam, **dkw)
         n_settle, prev = 0, None
@@ -464,6 +483,15 @@ def main():
                                    "note": "usable = affinity mask capped by the cgroup quota, divided by the ranks of the node (jlm_amd.usable_cpus); "
                                            "the lattice workers pin themselves to the CPUs of their GPU's NUMA node (jlm_amd/numa.py; 0 = sysfs names none)"}
         assert len(out) == len(sents) * args.steps and all(len(r) > 0 for r in out)
+        # ... and ONE warm batch by itself (no pipelining: the latency of a single 256-sentence call in a running service)
+        torch.cuda.synchronize()
+        _tf = time.perf_counter()
+        dec.decode_batch(sents, beam_width=args.beam, **dkw)
+        torch.cuda.synchronize()
+        line_extra["single_call_ms"] = round((time.perf_counter() - _tf) * 1e3, 2)
+        line_extra["first_call_note"] = ("first_call_ms: the first decode_batch of the process (one batch of `sentences_per_gpu`, strings -> strings, cold: "
+                                         "plans, page-locked blocks, streams); single_call_ms: the same call once the process is warm; `value` is the "
+                                         "pipelined steady state after `untimed_steps`")
         del out        # ~300 k list objects: kept alive they make every later full garbage collection (the loops below) slower
         total_chars_per_step = sum_over_ranks(float(chars_per_step))
         value = total_chars_per_step * args.steps / dt
@@ -485,7 +513,12 @@ def main():
             per_step = roofline["launches"] / float(min(args.steps, 20))
             roofline["solo_launch_ms_per_step"] = round(roofline["avg_launch_ms"] * per_step, 4)
             # (two different runs -- serialised event timing vs the pipelined loop: recorded, never raised)
-            roofline["clock_consistency_ok"] = bool(roofline["solo_launch_ms_per_step"] <= line_extra["device_resident_ms_per_step"])
+            roofline["clock_consistency_ok"] = bool(roofline["solo_launch_ms_per_step"] <= 1.02 * line_extra["device_resident_ms_per_step"])
+            if not roofline["clock_consistency_ok"]:       # (round-5 advice: a line whose two clocks disagree is marked, loudly)
+                line_extra["line_suspect"] = ("the dominant kernel's solo launches of one step (%.3f ms by HIP events) exceed the device-resident step "
+                                              "(%.3f ms by the wall clock): one of the two measurements is wrong"
+                                              % (roofline["solo_launch_ms_per_step"], line_extra["device_resident_ms_per_step"]))
+                print("bench.py: WARNING: " + line_extra["line_suspect"], file=sys.stderr)
         if roofline and args.decoder == "static" and roofline.get("lse_form") in ("mixed", "hybrid"):
             # the same launches on SPLIT rows (three f16 passes; what a model the load-time gates keep off the int8 planes runs)
             os.environ["JLM_LSE_MIXED"] = "0"
@@ -695,6 +728,19 @@ def main():
                              n, len(cpu_sents), os.cpu_count(), 100 * sum(o.perf_log_lstm) / cdt, 100 * sum(o.perf_log_softmax) / cdt, same, n)}
 
     m = cpu_dec.model.dev
+    # north_star: throughput "as fraction of the gate-GEMM roofline" -- SURVEY 8(d): 2 (H + E) 4H flop per hypothesis row, beam rows per
+    # decoded character (31.5 MFLOP per char at beam 10, E = 256), against the dense f16 matrix peak of N GPUs; and against the ceiling of
+    # what the step kernel issues (three f16 passes over the state: the input side is a table row)
+    _fpc = 2.0 * (m.H + m.E_in) * 4 * m.H * args.beam
+    _issued = (SPLIT_PASSES if getattr(m, "split_lstm", False) else 1) * 2.0 * m.H * 4 * m.H * args.beam
+    _peak = (F16_MFMA_PEAK_TFLOPS if getattr(m, "split_lstm", False) else F32_MFMA_PEAK_TFLOPS) * 1e12 * world
+    line_extra["gate_roofline"] = {
+        "flops_per_char": _fpc, "chars_per_s_at_peak": round(_peak / _fpc, 1), "frac": round(value / (_peak / _fpc), 5),
+        "issued_flops_per_char": _issued, "chars_per_s_at_issued_ceiling": round(_peak / _issued, 1), "frac_of_issued_ceiling": round(value / (_peak / _issued), 5),
+        "note": "value / (matrix peak of %d GPU(s) / gate-GEMM flop per decoded char): the whole decode priced as if it were the gate GEMM alone "
+                "(SURVEY 8d); the step kernel's own utilisation is gate_gemm.mfma_util_pct" % world}
+    from jlm_amd import ops as _ops
+    assert type(_ops.backend()).__name__ == "HipOps", "bench.py measures the HIP path only (jlm_amd.ops.set_backend is a test hook)"
     line = {
         "metric": "decoded chars/sec at beam=%d, vocab=%dk (kana strings in -> n-best strings out, SURVEY 8d)" % (
             args.beam, cfg["vocab_size"] // 1000),
@@ -704,7 +750,8 @@ def main():
         "vs_baseline": None,
         "dtype": ("f32 (matrix products as 3-pass split-f16 MFMA, f32 accumulate%s: f32-grade error, tests/test_gpu_kernels.py; "
                   "scores f64; parity bars: step logits <= 1e-4 relative, 1-best identical, path scores within 1e-6 per frame + 2e-6 of the "
-                  "reference's -- tests/test_gpu_decode.py score_atol)" % ("; the vocabulary projection as f16 hi.hi + two int8 cross-term passes" if getattr(m, "mixed_idx", None) else "")
+                  "reference's -- tests/test_gpu_decode.py score_atol)" % (("; the vocabulary projection as f16 hi.hi + both cross terms in one block-scaled FP6 instruction per 32 k-values" if getattr(m, "mixed_fmt", None) == "mx6"
+                                                                  else "; the vocabulary projection as f16 hi.hi + two int8 cross-term passes") if getattr(m, "mixed_idx", None) else "")
                   if getattr(m, "split_lstm", False) else "f32"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config, "fixture": args.fixture,

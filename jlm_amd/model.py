@@ -444,7 +444,7 @@ class DeviceModel:
         self.mixed_head_split = []
         if not getattr(self, "mixed_idx", None):
             return
-        limit = float(os.environ.get("JLM_MIXED_MAX_LSE_RMS", "1.0e-6"))
+        limit = float(os.environ.get("JLM_MIXED_MAX_LSE_RMS", "1.5e-6"))
         if not (limit > 0.0):
             return
 

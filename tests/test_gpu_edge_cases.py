@@ -277,17 +277,27 @@ def _heavy_tails(w):
     ("wide128-tied", _scale_out(1.0 / 64.0, 64.0), "small embeddings, large projection", True),
     ("wide-vtable", _heavy_tails, "0.2 % of the embedding entries x 25: the spread guard keeps the model on split rows", False),
 ], ids=lambda v: v if isinstance(v, str) else getattr(v, "__name__", "edit") if callable(v) else str(v))
-def test_operand_ranges_of_the_mixed_kernels(name, edit, tag, mixed, tmp_path, monkeypatch):
+@pytest.mark.parametrize("fmt", ["mx6", "int8"])
+def test_operand_ranges_of_the_mixed_kernels(name, edit, tag, mixed, tmp_path, monkeypatch, fmt):
     """The mixed-row normaliser takes its power-of-two scales (2^eB, the int8 scale s8, 2^eT) from the weights' ranges and only
     serves blocks without heavy tails (DeviceModel._build_mixed): the decode stays on the oracle whatever the ranges are.
     (The KERNELS' handling of the ranges is what is tested: the load-time calibration, which sends e.g. the +-40 biases to split
     rows on its own measurement, is switched off here -- tests/test_gpu_mixed_logits.py covers what it decides.)"""
     if os.environ.get("JLM_PRECISION", "f16x3") != "f16x3" or os.environ.get("JLM_LSE_MIXED", "1") == "0":
         pytest.skip("the suite is running without the mixed rows")
-    monkeypatch.setenv("JLM_MIXED_MAX_LSE_RMS", "0")
+    monkeypatch.setenv("JLM_LSE_MX6", "1" if fmt == "mx6" else "0")
+    heavy = edit is _heavy_tails
+    if not (heavy and fmt == "mx6"):
+        monkeypatch.setenv("JLM_MIXED_MAX_LSE_RMS", "0")
+    # (round 6: the FP6 planes have no spread gate -- a scale per 32 k-values of every word -- so for the heavy-tailed model the
+    #  load-time calibration stays ON in that format and decides; whatever it decides, the decode must stay on the oracle)
     f = _rescaled_fixture(tmp_path, name, edit)
     d, o = _pair(f, "static")
-    assert bool(d.model.dev.mixed_idx) == mixed, (d.model.dev.mixed_idx, d.model.dev.mixed_spread)
+    if heavy and fmt == "mx6":
+        print("heavy tails on mx6 rows:", d.model.dev.mixed_fmt, d.model.dev.mixed_idx, d.model.dev.mixed_calib)
+    else:
+        assert bool(d.model.dev.mixed_idx) == mixed, (d.model.dev.mixed_idx, d.model.dev.mixed_spread)
+        assert d.model.dev.mixed_fmt == (fmt if mixed else None)
     sents = synth.make_ragged_sentences(6, 3, 15, seed=123, alphabet=f["alphabet"])
     got = d.decode_batch(sents, beam_width=6)
     for s, g in zip(sents, got):

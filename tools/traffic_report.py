@@ -23,7 +23,8 @@ with open(sys.argv[1], "w") as fo:
         print("%-70s n=%4d  %.1f MB per launch" % (k[:70], n, tot / 1e6))
 if len(sys.argv) > 2:
     # the headline workload's kernel (mid-vtable: the D-softmax* shapes), not the tied legs' instantiation of the same template
-    lse = ([r for r in rows if "vocab_lse_mixed" in r[0] and "7, 13" in r[0]] or [r for r in rows if "vocab_lse_mixed" in r[0]] or
+    lse = ([r for r in rows if "vocab_lse_mx6" in r[0] and "7, 13" in r[0]] or [r for r in rows if "vocab_lse_mx6" in r[0]] or
+           [r for r in rows if "vocab_lse_mixed" in r[0] and "7, 13" in r[0]] or [r for r in rows if "vocab_lse_mixed" in r[0]] or
            [r for r in rows if "vocab_lse_split" in r[0] or "vocab_lse_hybrid" in r[0]])
     if lse:
         import bench
