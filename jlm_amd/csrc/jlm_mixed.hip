@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) void pack_mx6_kernel(const float *__restrict__
     else *reinterpret_cast<i32x4 *>(o + 112) = i32x4{0, 0, 0, 0};
 }
 
-// hypothesis rows: pack_t_mixed_kernel's scheme (one wave per row, lane = 16-value group of the row's segments) with FP6 planes.  The
-// halves are SWAPPED against the vocabulary rows (half 0 = lo6, half 1 = hi6): the instruction pairs k-slot with k-slot.
+// hypothesis rows: one wave per row; a lane owns ONE PLANE of one 16-value group of the row's segments (lanes 0-31: the lo6 plane of groups
+// g0 .. g0 + 31, lanes 32-63: the hi6 plane of the same groups) -- the quantiser is ~20 VALU instructions per value, and with a lane
+// per group and BOTH planes (the int8 packer's assignment) the launch took 12-14 us where the int8 one takes 9.
+// The halves are SWAPPED against the vocabulary rows (half 0 = lo6, half 1 = hi6): the instruction pairs k-slot with k-slot.
 __global__ __launch_bounds__(256) void pack_t_mx6_kernel(MxTArgs a, const float *__restrict__ T, int ldt, const int *__restrict__ rows,
                                                          int n_rows_max, const int *__restrict__ n_dev, unsigned char *__restrict__ Tm, int ld_tm) {
     const int n = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
@@ -244,63 +246,58 @@ __global__ __launch_bounds__(256) void pack_t_mx6_kernel(MxTArgs a, const float 
     if (r >= n) return;
     const int g = rows ? rows[r] : r;
     const int lane = threadIdx.x & 63;
+    const int sl = lane >> 5;                         // plane: 0 = lo6 (half 0 of the row format), 1 = hi6
     const float *trow = T + (size_t)g * ldt;
     unsigned char *oblk = Tm + mx_tm_block(r, ld_tm);
     int total = 0;
     for (int si = 0; si < a.n_segs; ++si) total += 2 * a.seg[si].nb;
-    const int grp = lane;
-    int si = 0, base = 0;
-    while (si + 1 < a.n_segs && grp >= base + 2 * a.seg[si].nb) { base += 2 * a.seg[si].nb; ++si; }
-    const bool act = grp < total;
-    const MxTSeg sg = a.seg[si];
-    const int gs = grp - base;                        // group inside the segment: block gs >> 1, half gs & 1 (partner lane ^ 1: base is even)
-    f32x4 v[4];
+    for (int g0 = 0; g0 < total; g0 += 32) {
+        const int grp = g0 + (lane & 31);
+        int si = 0, base = 0;
+        while (si + 1 < a.n_segs && grp >= base + 2 * a.seg[si].nb) { base += 2 * a.seg[si].nb; ++si; }
+        const bool act = grp < total;
+        const MxTSeg sg = a.seg[si];
+        const int gs = grp - base;                    // group inside the segment: block gs >> 1, half gs & 1 (partner lane ^ 1: base is even)
+        f32x4 v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k0 = 16 * gs + 4 * q;
-        v[q] = *reinterpret_cast<const f32x4 *>(trow + sg.t_off + ((act && k0 < sg.k) ? k0 : 0));
-    }
-    _Float16 hi[16];
-    float hf32[16], lo[16];
-    float amax_h = 0.0f, amax_l = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const int k0 = 16 * gs + 4 * q;
+            v[q] = *reinterpret_cast<const f32x4 *>(trow + sg.t_off + ((act && k0 < sg.k) ? k0 : 0));
+        }
+        _Float16 hi[16];
+        float val[16];
+        float amax = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int k = 16 * gs + e;
-        const bool real = act && k < sg.k;
-        float x = real ? v[e >> 2][e & 3] * sg.t_scale : (k == sg.k ? sg.tc : (k == sg.k + 1 ? sg.tc * (1.0f / 2048.0f) : 0.0f));
-        asm volatile("" : "+v"(x));
-        _Float16 h = (_Float16)x;
-        asm volatile("" : "+v"(h));
-        hi[e] = h;
-        hf32[e] = real ? (float)h : 0.0f;
-        lo[e] = real ? x - (float)h : 0.0f;
-        amax_h = fmaxf(amax_h, fabsf(hf32[e]));
-        amax_l = fmaxf(amax_l, fabsf(lo[e]));
-    }
-    amax_h = fmaxf(amax_h, __shfl_xor(amax_h, 1));
-    amax_l = fmaxf(amax_l, __shfl_xor(amax_l, 1));
-    if (!act) return;
-    const int bh_ = mx6_block_byte(amax_h), bl_ = mx6_block_byte(amax_l);
-    unsigned ch[16], cl[16], ph[3], pl[3];
+        for (int e = 0; e < 16; ++e) {
+            const int k = 16 * gs + e;
+            const bool real = act && k < sg.k;
+            float x = real ? v[e >> 2][e & 3] * sg.t_scale : (k == sg.k ? sg.tc : (k == sg.k + 1 ? sg.tc * (1.0f / 2048.0f) : 0.0f));
+            asm volatile("" : "+v"(x));               // (the scaled value is used twice: jlm_common.h jlm_split2)
+            _Float16 h = (_Float16)x;
+            asm volatile("" : "+v"(h));
+            hi[e] = h;
+            val[e] = real ? (sl ? (float)h : x - (float)h) : 0.0f;
+            amax = fmaxf(amax, fabsf(val[e]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        if (act) {
+            const int byte = mx6_block_byte(amax);
+            unsigned c[16], pw[3];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { ch[e] = mx6_code(hf32[e], bh_); cl[e] = mx6_code(lo[e], bl_); }
-    mx6_pack16(ch, ph);
-    mx6_pack16(cl, pl);
-    const int j = gs >> 1, half = gs & 1;
-    *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half, r)) = *reinterpret_cast<const f32x4 *>(hi);
-    *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half + 1, r)) = *reinterpret_cast<const f32x4 *>(hi + 8);
-    // plane in slot sl (lo6: 0, hi6: 1): dwords 0-3 in granule 4 + 2 sl, dwords 4-5 in granule 5 at byte 8 sl; this lane holds dwords 3 half .. 3 half + 2
-    unsigned char *g4 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 4, r), *g5 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 5, r);
-    unsigned char *g6 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 6, r);
-    if (half == 0) {
-        *reinterpret_cast<unsigned *>(g4 + 0) = pl[0]; *reinterpret_cast<unsigned *>(g4 + 4) = pl[1]; *reinterpret_cast<unsigned *>(g4 + 8) = pl[2];
-        *reinterpret_cast<unsigned *>(g6 + 0) = ph[0]; *reinterpret_cast<unsigned *>(g6 + 4) = ph[1]; *reinterpret_cast<unsigned *>(g6 + 8) = ph[2];
-        unsigned char *g7 = oblk + mx_tm_granule(sg.tm_off, 7, r);
-        g7[j] = (unsigned char)bl_;
-        g7[8 + j] = (unsigned char)bh_;
-    } else {
-        *reinterpret_cast<unsigned *>(g4 + 12) = pl[0]; *reinterpret_cast<unsigned *>(g5 + 0) = pl[1]; *reinterpret_cast<unsigned *>(g5 + 4) = pl[2];
-        *reinterpret_cast<unsigned *>(g6 + 12) = ph[0]; *reinterpret_cast<unsigned *>(g5 + 8) = ph[1]; *reinterpret_cast<unsigned *>(g5 + 12) = ph[2];
+            for (int e = 0; e < 16; ++e) c[e] = mx6_code(val[e], byte);
+            mx6_pack16(c, pw);
+            const int j = gs >> 1, half = gs & 1;
+            // the f16 part: granules 2 half, 2 half + 1 of the block -- one each from the group's two lanes
+            *reinterpret_cast<f32x4 *>(oblk + mx_tm_granule(sg.tm_off, j * 8 + 2 * half + sl, r)) = *reinterpret_cast<const f32x4 *>(hi + 8 * sl);
+            // plane sl: dwords 0-3 in granule 4 + 2 sl, dwords 4-5 in granule 5 at byte 8 sl; this lane holds dwords 3 half .. 3 half + 2
+            unsigned char *ga = oblk + mx_tm_granule(sg.tm_off, j * 8 + 4 + 2 * sl, r), *g5 = oblk + mx_tm_granule(sg.tm_off, j * 8 + 5, r) + 8 * sl;
+            if (half == 0) {
+                *reinterpret_cast<unsigned *>(ga + 0) = pw[0]; *reinterpret_cast<unsigned *>(ga + 4) = pw[1]; *reinterpret_cast<unsigned *>(ga + 8) = pw[2];
+                (oblk + mx_tm_granule(sg.tm_off, 7, r))[8 * sl + j] = (unsigned char)byte;
+            } else {
+                *reinterpret_cast<unsigned *>(ga + 12) = pw[0]; *reinterpret_cast<unsigned *>(g5 + 0) = pw[1]; *reinterpret_cast<unsigned *>(g5 + 4) = pw[2];
+            }
+        }
     }
 }
 
@@ -498,7 +495,7 @@ extern "C" int jlm_pack_t_mixed6(const jlm_segment *segs_host, const float *t_sc
 }
 
 // the mx6 form (jlm_mx6.hip: FP6 cross terms on the block-scaled matrix instruction)
-int jlm_mx6_launch(const MxArgs &a, bool xbias, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
+int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
                    int lds, hipStream_t st);
 // the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
@@ -633,7 +630,7 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     if (n6 && n6 != n_segs) return -2;
     if (n6) {
         if (rows_wg != 256) return -2;
-        if (int rc = jlm_mx6_launch(a, xbias, Tm, ld_tm, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles, lds, (hipStream_t)stream)) return rc;
+        if (int rc = jlm_mx6_launch(a, xbias, fixed_ref, Tm, ld_tm, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles, lds, (hipStream_t)stream)) return rc;
         return n_sub;
     }
     // which kernel: 0 the D-softmax* shapes (inlined), 1 any other bias-column shape, 2 tied k = 256 (inlined), 3 other external-bias shapes

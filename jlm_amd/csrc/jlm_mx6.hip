@@ -7,6 +7,7 @@
 // instruction's accumulator, and with IEEE semantics hipcc canonicalises every such value first (v_max_f32 x, x, x: one more VALU
 // instruction per logit -- 742 instead of 266 v_max in the D-softmax* kernel).  A NaN logit is garbage either way.
 #include "jlm_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -76,10 +77,26 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mx6_kernel(MxArgs a, const u
 
 }  // namespace
 
+// the wide form (jlm_mx6w.hip: four waves of 64 rows): the shapes it hosts, its launch
+bool jlm_mx6w_hosts(const MxArgs &a, bool xbias);
+int jlm_mx6w_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
+                    int n_ptiles, int lds, hipStream_t st);
+
+#ifndef JLM_MX6_WIDE_DEFAULT
+#define JLM_MX6_WIDE_DEFAULT -1
+#endif
+
 // which kernel: the D-softmax* shapes (inlined), any other bias-column shape, tied k = 256 (inlined), other external-bias shapes.
+// JLM_MX6_WIDE: 1 the wide kernel for every shape it hosts, 0 the eight-wave kernel, -1 (default) where it measures faster -- the tied
+// k = 256 shapes: 98-100 vs 107 us at V = 50 k / 2 560 rows, 1 384 vs 1 500 us at V = 100 k / 20 480 rows; the D-softmax* launch measures
+// the same on both (60.5-60.9 vs 59.6-59.9 us) and stays on the eight-wave kernel (profiles/r06_g_mx6_wide.txt) -- as for the int8 planes.
 // Returns 0, -3 (LDS grant) or a negative HIP error like its caller.
-int jlm_mx6_launch(const MxArgs &a, bool xbias, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
-                   int lds, hipStream_t st) {
+int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
+                   int n_ptiles, int lds, hipStream_t st) {
+    static int wide = -1;
+    if (wide < 0) { const char *e = getenv("JLM_MX6_WIDE"); wide = e ? atoi(e) : JLM_MX6_WIDE_DEFAULT; }
+    if ((wide > 0 || (wide < 0 && xbias)) && jlm_mx6w_hosts(a, xbias))
+        return jlm_mx6w_launch(a, xbias, fixed_ref, Tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles, lds, st);
     int which = xbias ? 2 : 0;
     for (int i = 0; i < a.n_segs; ++i) {
         const int nb = a.seg[i].nb, ns16 = (a.seg[i].k + 2 + 15) / 16;

@@ -39,12 +39,14 @@ __device__ __forceinline__ int mx6_block_byte(float amax) {
     return min(max(e + 127, 0), 254);
 }
 // code of x / 2^(byte - 127): round to nearest even on the e2m3 grid (steps 0.125 below 2, 0.25 below 4, 0.5 up to 7.5), saturating
+// (below 2 the code IS 8 x the value -- the subnormal codes 0 .. 7 and the first binade 8 .. 15 share the step 0.125; in [2, 4): 8 + 4 a; in
+//  [4, 7.5]: 16 + 2 a; a value that rounds up to the next binade's first grid point gets that point's code from the same formula)
 __device__ __forceinline__ unsigned mx6_code(float x, int byte) {
     const float a = fminf(fabsf(__builtin_ldexpf(x, 127 - byte)), 7.5f);
-    const float inv_step = a < 2.0f ? 8.0f : (a < 4.0f ? 4.0f : 2.0f);
-    const unsigned qi = (unsigned)(rintf(a * inv_step) * (8.0f / inv_step));        // 8 x the rounded magnitude: 0 .. 60
-    const unsigned mag = qi < 16u ? qi : (qi < 32u ? 8u + (qi >> 1) : 16u + (qi >> 2));
-    return mag | (x < 0.0f ? 32u : 0u);
+    const float mul = a < 2.0f ? 8.0f : (a < 4.0f ? 4.0f : 2.0f);
+    const float off = a < 2.0f ? 0.0f : (a < 4.0f ? 8.0f : 16.0f);
+    const unsigned mag = (unsigned)(rintf(a * mul) + off);
+    return mag | ((__float_as_uint(x) >> 26) & 32u);
 }
 // 16 codes -> 96 bits
 __device__ __forceinline__ void mx6_pack16(const unsigned *c, unsigned w[3]) {

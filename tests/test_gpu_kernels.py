@@ -754,6 +754,58 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10, fmt="int8"):
     return segs, ts, ds, s8, Bs, keep, off, b2
 
 
+@pytest.mark.parametrize("widths,R", [([200, 100, 52], 75), ([256], 40), ([36, 128], 33)])
+def test_mx6_packers_match_the_numpy_double(L, widths, R):
+    """ABI 11: the device packers of the mx6 rows (csrc/jlm_mixed.hip pack_mx6_kernel / pack_t_mx6_kernel: f16 hi, FP6 planes of hi and of the
+    residual with an E8M0 scale per 32 k-values, scale bytes in granule 7 of a row's first block) against tests/fake_hip.py's numpy
+    restatement of the format -- byte for byte (round to nearest even on the e2m3 grid, the block exponent rule, the bit packing)."""
+    import ctypes
+    rng = np.random.default_rng(sum(widths) + R)
+    V = 40 * len(widths) + 7
+    bounds = [0] + [(i + 1) * (V // len(widths)) for i in range(len(widths) - 1)] + [V]
+    b2_np = (rng.standard_normal(V) * 0.3).astype(np.float32)
+    b2_np[::5] = 0.0
+    segs, ts, ds, s8, Bs, keep, ldt, b2 = _mixed_segments(L, rng, V, widths, bounds, b2_np, fmt="mx6")
+    T_np = (np.tanh(rng.standard_normal((R, ldt))) * rng.uniform(1e-3, 1.0, size=(R, 1))).astype(np.float32)
+    T_np[3] = 0.0                                        # an all-zero row: scale bytes 0, codes 0
+    T_np[5, ::2] = 0.0
+    T_np[7] *= np.float32(2.0 ** -30)
+    T = torch.as_tensor(T_np).cuda()
+    n = len(widths)
+    ld_tm = L.jlm_mixed_t_stride(segs, n)
+    Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")
+    assert L.jlm_pack_t_mixed6(segs, ts, n, T.data_ptr(), ldt, None, R, None, Tm.data_ptr(), ld_tm, _st()) == 0
+    torch.cuda.synchronize()
+    # --- vocabulary rows: repack on the host from the same matrices
+    off = 0
+    for i, k in enumerate(widths):
+        nv, nb = bounds[i + 1] - bounds[i], segs[i].ldb // 32
+        dev_rows = keep[2 * i + 1].cpu().numpy().view(np.uint8).reshape(nv, nb * 128)
+        host = np.zeros((nv, nb * 128), dtype=np.uint8)
+        bmax = max(float(np.abs(Bs[i]).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427 if k % 32 else 0.0)
+        eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
+        src = np.ascontiguousarray(Bs[i])
+        bias = np.ascontiguousarray(b2_np[bounds[i]:bounds[i + 1]])
+        assert FK.jlm_pack_mixed(src.ctypes.data, nv, k, k, bias.ctypes.data, 2.0 ** eB, 2.0 ** eB * 1.4426950408889634, 0.0,
+                                 host.ctypes.data, 32 * nb, 0) == 0
+        bad = np.argwhere(dev_rows != host)
+        assert len(bad) == 0, ("vocabulary rows differ (row, byte):", i, bad[:8].tolist())
+        off += nb * 128
+    # --- hypothesis rows: the device image is granule-major in blocks of 32 rows (csrc/jlm_mixed_body.h); back to row-major
+    host_tm = np.zeros((R, ld_tm * 4), dtype=np.uint8)
+    tsc = [float(ts[i]) for i in range(n)]
+    assert FK.jlm_pack_t_mixed6(segs, tsc, n, T_np.ctypes.data, ldt, None, R, None, host_tm.ctypes.data, ld_tm, 0) == 0
+    raw = Tm.cpu().numpy().view(np.uint8).reshape(-1)
+    dev_tm = np.zeros_like(host_tm)
+    ngr = sum(segs[i].ldb // 32 for i in range(n)) * 8
+    for r in range(R):
+        blk = (r // 32) * 32 * ld_tm * 4
+        for g in range(ngr):
+            dev_tm[r, 16 * g:16 * g + 16] = raw[blk + g * 512 + (r % 32) * 16: blk + g * 512 + (r % 32) * 16 + 16]
+    bad = np.argwhere(dev_tm[:, :16 * ngr] != host_tm[:, :16 * ngr])
+    assert len(bad) == 0, ("hypothesis rows differ (row, byte):", bad[:8].tolist())
+
+
 @pytest.mark.parametrize("V,widths,bounds,R,maxp", [(2000, [200, 100, 52], [0, 700, 1300, 2000], 48, 16), (2000, [200, 100, 52], [0, 700, 1300, 2000], 300, 96),
                                                     (3000, [256], [0, 3000], 200, 24), (1500, [512], [0, 1500], 130, 12)])
 @pytest.mark.parametrize("fmt", ["int8", "mx6"])

@@ -304,14 +304,16 @@ def bench_gemm(M, N, K, tag):
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     if os.environ.get("KBENCH_MX6"):          # round 6: the two formats of the cross-term planes side by side, interleaved
+        fmts = tuple(os.environ.get("KBENCH_FMTS", "int8,mx6").split(","))
         for rep in range(int(os.environ["KBENCH_MX6"])):
-            for fmt in ("int8", "mx6"):
+            for fmt in fmts:
                 bench_lse_mixed(50000, [200, 100, 50], 2560, "dsoftmax*", fmt)
                 for V1, k1 in ((12000, 200), (18000, 100), (20000, 50)):
                     bench_lse_mixed(V1, [k1], 2560, "seg-k%d" % k1, fmt)
                 bench_lse_mixed(50000, [256], 2560, "tied50k", fmt)
-        for fmt in ("int8", "mx6"):
-            bench_lse_mixed(100000, [256], 20480, "tied100k-b20", fmt)
+        if not os.environ.get("KBENCH_NO_BIG"):
+            for fmt in fmts:
+                bench_lse_mixed(100000, [256], 20480, "tied100k-b20", fmt)
         sys.exit(0)
     for R in (2560,):
         bench_gate(512, 200, R)
