@@ -50,6 +50,11 @@ DECODE_CASES = [
     ("small-tied/dynamic-top", "small-tied", "dynamic",
      dict(beam_width=10, vocab_select=True, samples=20, top_sampling=True), ("ragged", 6, 2, 14, 5)),
     ("small-tied-sn/dynamic", "small-tied-sn", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 7)),
+    # round 6: random ids appended to the frame-0 list (decoder_dynamic.py:38-41: NOT de-duplicated there), np.random seeded per sentence as
+    # for static-vs-rand; and the unpruned incremental search (decoder_dynamic.py:89-91: no sort, no cut) on inputs short enough for it
+    ("small-tied/dynamic-rand", "small-tied", "dynamic",
+     dict(beam_width=10, vocab_select=True, samples=30, random_sampling=True), ("ragged", 6, 2, 14, 6)),
+    ("small-tied/dynamic-unpruned", "small-tied", "dynamic", dict(beam_width=None, vocab_select=True, topN=50), ("ragged", 6, 1, 3, 11)),
     # the incremental decoder on SEGMENTED models: the reference pairs weight rows and biases of different words there
     # (SURVEY 8 a16); jlm_amd reproduces it with DynamicDecoder.compat_quirks = True (the "-quirk" cases set it)
     ("small-vtable/dynamic-quirk", "small-vtable", "dynamic", dict(beam_width=10, vocab_select=True), ("ragged", 8, 1, 16, 10)),
