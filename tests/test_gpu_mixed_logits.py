@@ -135,7 +135,7 @@ def test_mixed_kernel_step_logits_within_1e4_of_reference(name, fx, golden_lm, m
 # the int8 planes and their two-format launches as in round 5 (peaked20-vtable: second and third segment on int8 mixed rows, the first --
 # which carries the mass and the error -- on split rows), then split rows.  Heavy-tailed blocks, which one int8 scale per segment kept on
 # split rows, pass on mx6 (a scale per 32 k-values of every word).
-GATES = [("mid-vtable", True, "mx6"), ("mid-tied", True, "mx6"), ("peaked-vtable", True, "mx6"), ("peaked-tied", False, None),
+GATES = [("mid-vtable", True, "mx6"), ("mid-tied", True, "mx6"), ("peaked-vtable", True, "mx6"), ("peaked-tied", True, "mx6"),
          ("peaked20-vtable", "first-split", "int8"), ("peaked20-tied", False, None), ("heavy-vtable", True, "mx6")]
 
 
@@ -159,9 +159,9 @@ def test_mixed_row_gates_follow_the_models_logit_range(name, kept, fmt, fx, monk
         assert m.mixed_fmt == fmt, (name, m.mixed_fmt, cal)
         assert cal is not None and cal["kept"] == bool(kept) and np.isfinite(cal["lse_rms_diff"]) and len(cal["probes"]) == len(DeviceModel.CALIB_PROBES)
         # no decision within 30 % of the limit (verdict round 5, item 3): the form kept is well inside, every form refused well outside
-        assert cal["margin"] >= 1.2 or cal["margin"] <= 1.0 / 1.2, (name, cal)
+        assert cal["margin"] >= 1.3 or cal["margin"] <= 1.0 / 1.3, (name, cal)
         if "mx6" in cal:
-            assert not cal["mx6"]["kept"] and cal["mx6"]["lse_rms_diff"] >= 1.2 * cal["limit"], cal
+            assert not cal["mx6"]["kept"] and cal["mx6"]["lse_rms_diff"] >= 1.3 * cal["limit"], cal
         if kept == "first-split":
             assert m.mixed_idx == [1, 2] and cal["split_segments"] == [0] and cal["lse_rms_diff"] < 2e-7 < 1e-6 < cal["lse_rms_diff_all_mixed"], cal
         if name == "mid-vtable":
