@@ -10,7 +10,7 @@ OBJS=""
 for s in jlm_gemm jlm_beam jlm_split jlm_gate jlm_mixed jlm_decode jlm_gate_ws jlm_mixed_w jlm_mx6 jlm_mx6w; do
   if [[ " $* " == *" $s.hip "* ]]; then
     X=""; { [ $s = jlm_gate_ws ] || [ $s = jlm_mixed_w ]; } && X="-mllvm -amdgpu-mfma-vgpr-form"
-    [ $s = jlm_mx6 ] && X="-fno-honor-nans -mno-amdgpu-ieee"
+    [ $s = jlm_mx6 ] && X="-fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize"
     [ $s = jlm_mx6w ] && X="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans -mno-amdgpu-ieee"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS $X -c -o ../../build_prof/$TAG/$s.o $s.hip &
     OBJS="$OBJS ../../build_prof/$TAG/$s.o"
