@@ -496,8 +496,7 @@ extern "C" int jlm_pack_t_mixed6(const jlm_segment *segs_host, const float *t_sc
 
 // the mx6 form (jlm_mx6.hip: FP6 cross terms on the block-scaled matrix instruction)
 int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev, int n_ptiles,
-                   int lds, int rows_wg, hipStream_t st);
-bool jlm_mx6_pair_hosts(const jlm_segment *segs, int n_segs);
+                   int lds, hipStream_t st);
 // the wide form of the D-softmax* kernel (jlm_mixed_w.hip: four waves of 64 rows, row operands in accumulation registers)
 int jlm_mx_wide_launch(int which, const MxArgs &a, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
                        int n_ptiles, int lds, hipStream_t st);
@@ -524,11 +523,9 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     int n6 = 0;
     for (int i = 0; i < n_segs; ++i) n6 += s8[i] == 0.0f;
     if (n6 && n6 != n_segs) return -2;
-    // ... in 512-row workgroups where the launch hosts them (round 6: two row sets per wave for the segments of up to four 32-k blocks)
-    const bool pair6 = n6 && n_rows_max > 256 && jlm_mx6_pair_hosts(segs_host, n_segs);
-    static double c2 = -1.0;
-    if (c2 < 0) { const char *e = getenv("JLM_MX6_C2"); c2 = e ? atof(e) : 1.7; }
-    if (pair6) rows_wg = 512;
+    // (Round 6 also built 512-row workgroups -- two row sets per wave for the segments of up to four 32-k blocks, the 200-wide one walking
+    //  its two 256-row halves in turn: half the fragment reads and LDS-DMA per row for 60 % of the launch.  Correct, and no faster:
+    //  61-62 us against 59.8; LDS instructions -29 %, wave cycles +6 % (profiles/r06_k_pair512.txt, r06_l_pmc_mx6_forms.txt).  Removed.)
     double ctile[JLM_MAX_SEGMENTS], total = 0.0;
     long n_tiles_all = 0;
     int lds_max = 0, tm_off = 0;
@@ -562,8 +559,6 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
         // measured (kbench, single-segment launches): a 32-word block costs 0.055 us x (its matrix instructions + ~6: combine,
         // fold, block start); here in the split kernel's units (a k-step of a 128-word tile = 12 instructions ~ 2 units)
         ctile[i] = mtt * (ns16 + 2 * nb + 3.0 * c0x2) / 6.0;
-        // (512-row workgroups: a tile of the 200-wide segment is walked twice, one of the others once with two row sets -- ~c2 x the work)
-        if (pair6) ctile[i] *= nb > 4 ? 2.0 : c2;
         // (per-shape block costs fitted to single-segment launches -- 2.15 : 1.28 : 1 for k = 200 / 100 / 50 -- cut the three-segment
         //  launch WORSE than this formula's 1.95 : 1.35 : 1 (72.6 vs 70.5 us); what is left between the columns is the XCDs' clocks:
         //  equal cycles per workgroup within 2 %, 1.81-1.92 GHz from XCD to XCD on one chip -- tools/probes/mixed_wg_timeline.py)
@@ -638,7 +633,10 @@ static int vocab_lse_mixed_impl(const jlm_segment *segs_host, const float *desca
     const int lds = lds_max;
     if (n6) {
         if (rows_wg == 128) return -2;
-        if (int rc = jlm_mx6_launch(a, xbias, fixed_ref, Tm, ld_tm, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles, lds, rows_wg,
+        // (the mx6 forms without a running maximum take the accumulators as base-2 logits: only for launches whose descale is 1)
+        int fr6 = fixed_ref;
+        for (int i = 0; i < n_segs; ++i) fr6 &= descale[i] == 1.0f;
+        if (int rc = jlm_mx6_launch(a, xbias, fr6, Tm, ld_tm, reinterpret_cast<float2 *>(part), ld_part, n_rows_max, n_dev, n_ptiles, lds,
                                     (hipStream_t)stream)) return rc;
         return n_sub;
     }

@@ -16,40 +16,40 @@ using namespace jlm_mx;
 
 namespace {
 
-template <bool INLINE, bool XB, int NB, int NS16>
+template <bool INLINE, bool XB, bool FR, int NB, int NS16>
 struct Mx6Call {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                                float2 *prow, unsigned char *smem) {
-        mx6_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+        mx6_body<NB, NS16, mx_blocks_per_tile(NB), XB, FR>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
     }
 };
-template <bool XB, int NB, int NS16>
+template <bool XB, bool FR, int NB, int NS16>
 __device__ __noinline__ void mx6_body_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                               float2 *prow, unsigned char *smem) {
-    mx6_body<NB, NS16, mx_blocks_per_tile(NB), XB>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+    mx6_body<NB, NS16, mx_blocks_per_tile(NB), XB, FR>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
 }
-template <bool XB, int NB, int NS16>
-struct Mx6Call<false, XB, NB, NS16> {
+template <bool XB, bool FR, int NB, int NS16>
+struct Mx6Call<false, XB, FR, NB, NS16> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                                float2 *prow, unsigned char *smem) {
-        mx6_body_outline<XB, NB, NS16>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+        mx6_body_outline<XB, FR, NB, NS16>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
     }
 };
-template <bool INLINE, bool XB, int... SH>
+template <bool INLINE, bool XB, bool FR, int... SH>
 struct Mx6Dispatch;
-template <bool INLINE, bool XB>
-struct Mx6Dispatch<INLINE, XB> {
+template <bool INLINE, bool XB, bool FR>
+struct Mx6Dispatch<INLINE, XB, FR> {
     static __device__ __forceinline__ void run(const MxSeg &, int, int, int, int, int, const unsigned char *, int, float2 *, unsigned char *) {}
 };
-template <bool INLINE, bool XB, int NB, int NS16, int... REST>
-struct Mx6Dispatch<INLINE, XB, NB, NS16, REST...> {
+template <bool INLINE, bool XB, bool FR, int NB, int NS16, int... REST>
+struct Mx6Dispatch<INLINE, XB, FR, NB, NS16, REST...> {
     static __device__ __forceinline__ void run(const MxSeg &sg, int ns16, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm,
                                                float2 *prow, unsigned char *smem) {
-        if (sg.nb == NB && ns16 == NS16) Mx6Call<INLINE, XB, NB, NS16>::run(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
-        else Mx6Dispatch<INLINE, XB, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+        if (sg.nb == NB && ns16 == NS16) Mx6Call<INLINE, XB, FR, NB, NS16>::run(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
+        else Mx6Dispatch<INLINE, XB, FR, REST...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, smem);
     }
 };
-template <bool INLINE, bool XB, int... SH>
+template <bool INLINE, bool XB, bool FR, int... SH>
 __global__ __launch_bounds__(512, 1) void vocab_lse_mx6_kernel(MxArgs a, const unsigned char *__restrict__ Tm, int ld_tm, float2 *__restrict__ part,
                                                                int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mx6_smem[];
@@ -66,101 +66,18 @@ __global__ __launch_bounds__(512, 1) void vocab_lse_mx6_kernel(MxArgs a, const u
         float2 *prow = part + (size_t)r * ld_part;
         if (r != a.col_first[p]) __syncthreads();
         const int ns16 = XB ? 2 * sg.nb : (sg.k + 2 + 15) >> 4;
-        Mx6Dispatch<INLINE, XB, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mx6_smem);
+        Mx6Dispatch<INLINE, XB, FR, SH...>::run(sg, ns16, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mx6_smem);
     }
 }
-template <int NB, int NS16>
-__device__ __noinline__ void mx6_body2_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm, float2 *prow,
-                                               unsigned char *smem) {
-    // (arguments of a real call arrive in vector registers: the wave-uniform ones made provably uniform again -- jlm_mixed_w.hip mxw_body)
-    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto unip = [&](const void *q) {
-        const unsigned long long u = reinterpret_cast<unsigned long long>(q);
-        return reinterpret_cast<const void *>(((unsigned long long)(unsigned)uni((int)(u >> 32)) << 32) | (unsigned)uni((int)u));
-    };
-    MxSeg u;
-    u.B = static_cast<const unsigned char *>(unip(sg.B));
-    u.n_vocab = uni(sg.n_vocab); u.k = uni(sg.k); u.t_off = uni(sg.t_off); u.nb = uni(sg.nb); u.tm_off = uni(sg.tm_off); u.seg = uni(sg.seg);
-    u.descale = __int_as_float(uni(__float_as_int(sg.descale)));
-    u.cs = 0.0f;
-    u.bias2 = nullptr;
-    mx6_body2<NB, NS16, mx_blocks_per_tile(NB), false>(u, uni(vt0), uni(vt1), uni(pt), uni(n_paths), static_cast<const unsigned char *>(unip(Tm)), uni(ld_tm),
-                                                        static_cast<float2 *>(const_cast<void *>(unip(prow))), static_cast<unsigned char *>(const_cast<void *>(unip(smem))));
-}
-template <int NB, int NS16>
-__device__ __noinline__ void mx6_body1_outline(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *Tm, int ld_tm, float2 *prow,
-                                               unsigned char *smem) {
-    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto unip = [&](const void *q) {
-        const unsigned long long u = reinterpret_cast<unsigned long long>(q);
-        return reinterpret_cast<const void *>(((unsigned long long)(unsigned)uni((int)(u >> 32)) << 32) | (unsigned)uni((int)u));
-    };
-    MxSeg u;
-    u.B = static_cast<const unsigned char *>(unip(sg.B));
-    u.n_vocab = uni(sg.n_vocab); u.k = uni(sg.k); u.t_off = uni(sg.t_off); u.nb = uni(sg.nb); u.tm_off = uni(sg.tm_off); u.seg = uni(sg.seg);
-    u.descale = __int_as_float(uni(__float_as_int(sg.descale)));
-    u.cs = 0.0f;
-    u.bias2 = nullptr;
-    mx6_body<NB, NS16, mx_blocks_per_tile(NB), false>(u, uni(vt0), uni(vt1), uni(pt), uni(n_paths), static_cast<const unsigned char *>(unip(Tm)), uni(ld_tm),
-                                                       static_cast<float2 *>(const_cast<void *>(unip(prow))), static_cast<unsigned char *>(const_cast<void *>(unip(smem))));
-}
-
-// The D-softmax* model with 512 hypothesis rows per workgroup: its 100- and 50-wide segments run two row sets per wave (mx6_body2: half the
-// fragment reads and half the LDS-DMA per row), the 200-wide one -- whose operands fill a wave's registers with one set -- its two 256-row
-// halves one after the other (jlm_mx6_body.h).  Columns own whole 512-row tiles: p on XCD p % 8 as before.
-__global__ __launch_bounds__(512, 1) void vocab_lse_mx6p_kernel(MxArgs a, const unsigned char *__restrict__ Tm, int ld_tm, float2 *__restrict__ part,
-                                                                int ld_part, int n_rows_max, const int *n_dev, int n_ptiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mx6p_smem[];
-    const int n_paths = n_dev ? min(*n_dev, n_rows_max) : n_rows_max;
-    const int b = blockIdx.x;
-    int p, pt;
-    const int nb8 = (a.n_cols & ~7) * n_ptiles;
-    if (b < nb8) { const int x = b & 7, jb = b >> 3; p = (jb / n_ptiles) * 8 + x; pt = jb % n_ptiles; }
-    else { const int bb = b - nb8; p = (a.n_cols & ~7) + bb / n_ptiles; pt = bb % n_ptiles; }
-    if (p >= a.n_cols || pt * 512 >= n_paths) return;
-    for (int r = a.col_first[p]; r < a.col_first[p + 1]; ++r) {
-        const MxSeg sg = a.seg[a.sub_seg[r]];
-        const int vt0 = a.sub_t0[r], vt1 = a.sub_t1[r];
-        float2 *prow = part + (size_t)r * ld_part;
-        if (r != a.col_first[p]) __syncthreads();
-        const int ns16 = (sg.k + 2 + 15) >> 4;
-        if (sg.nb == 7 && ns16 == 13) {
-            // (out of line: hosted inline the three bodies cost each other a kilobyte of scratch per lane)
-            for (int half = 0; half < 2 && (2 * pt + half) * 256 < n_paths; ++half) {
-                if (half) __syncthreads();
-                mx6_body1_outline<7, 13>(sg, vt0, vt1, 2 * pt + half, n_paths, Tm, ld_tm, prow, mx6p_smem);
-            }
-        } else if (sg.nb == 4 && ns16 == 7) {
-            mx6_body2_outline<4, 7>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mx6p_smem);
-        } else if (sg.nb == 2 && ns16 == 4) {
-            mx6_body2_outline<2, 4>(sg, vt0, vt1, pt, n_paths, Tm, ld_tm, prow, mx6p_smem);
-        }
-    }
-}
-
-#define MX6_KERNEL_DSOFTMAX vocab_lse_mx6_kernel<true, false, 7, 13, 4, 7, 2, 4>
-#define MX6_KERNEL_GENERIC vocab_lse_mx6_kernel<false, false, 1, 1, 1, 2, 2, 3, 2, 4, 3, 5, 3, 6, 4, 7, 4, 8, 5, 9, 5, 10, 6, 11, 6, 12, 7, 13, 7, 14, 8, 15, 8, 16>
-#define MX6_KERNEL_TIED vocab_lse_mx6_kernel<true, true, 8, 16>
-#define MX6_KERNEL_GENERIC_XB vocab_lse_mx6_kernel<false, true, 2, 4, 4, 8, 6, 12, 8, 16>
+#define MX6_KERNEL_DSOFTMAX vocab_lse_mx6_kernel<true, false, false, 7, 13, 4, 7, 2, 4>
+#define MX6_KERNEL_DSOFTMAX_FR vocab_lse_mx6_kernel<true, false, true, 7, 13, 4, 7, 2, 4>
+#define MX6_KERNEL_GENERIC vocab_lse_mx6_kernel<false, false, false, 1, 1, 1, 2, 2, 3, 2, 4, 3, 5, 3, 6, 4, 7, 4, 8, 5, 9, 5, 10, 6, 11, 6, 12, 7, 13, 7, 14, 8, 15, 8, 16>
+#define MX6_KERNEL_TIED vocab_lse_mx6_kernel<true, true, false, 8, 16>
+#define MX6_KERNEL_TIED_FR vocab_lse_mx6_kernel<true, true, true, 8, 16>
+#define MX6_KERNEL_GENERIC_XB vocab_lse_mx6_kernel<false, true, false, 2, 4, 4, 8, 6, 12, 8, 16>
 
 
 }  // namespace
-
-// 512-row workgroups (vocab_lse_mx6p_kernel): the D-softmax* model's three shapes, every segment with bias columns.  JLM_MX6_PAIR=0: off
-bool jlm_mx6_pair_hosts(const jlm_segment *segs, int n_segs) {
-    static int pair = -1;
-    if (pair < 0) { const char *e = getenv("JLM_MX6_PAIR"); pair = e ? atoi(e) : 1; }
-    if (!pair || n_segs < 1) return false;
-    bool small = false;
-    for (int i = 0; i < n_segs; ++i) {
-        if (segs[i].k <= 0 || segs[i].ldb % 32) return false;
-        const int nb = segs[i].ldb / 32, ns16 = (segs[i].k + 2 + 15) / 16;
-        if (nb != (segs[i].k + 2 + 31) / 32) return false;                       // (bias columns)
-        if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4))) return false;
-        small |= nb <= 4;
-    }
-    return small;
-}
 
 // the wide form (jlm_mx6w.hip: four waves of 64 rows): the shapes it hosts, its launch
 bool jlm_mx6w_hosts(const MxArgs &a, bool xbias);
@@ -177,15 +94,7 @@ int jlm_mx6w_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, 
 // the same on both (60.5-60.9 vs 59.6-59.9 us) and stays on the eight-wave kernel (profiles/r06_g_mx6_wide.txt) -- as for the int8 planes.
 // Returns 0, -3 (LDS grant) or a negative HIP error like its caller.
 int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, int ld_tm, float2 *part, int ld_part, int n_rows_max, const int *n_dev,
-                   int n_ptiles, int lds, int rows_wg, hipStream_t st) {
-    if (rows_wg == 512) {       // the caller cut its columns for 512-row workgroups (jlm_mx6_pair_hosts said yes)
-        static JlmLdsGrant grant_p;
-        if (int rc = jlm_grant_lds(grant_p, reinterpret_cast<const void *>(vocab_lse_mx6p_kernel), lds)) return rc;
-        hipLaunchKernelGGL(vocab_lse_mx6p_kernel, dim3(a.n_cols * n_ptiles), dim3(512), lds, st, a, reinterpret_cast<const unsigned char *>(Tm), ld_tm, part,
-                           ld_part, n_rows_max, n_dev, n_ptiles);
-        hipError_t e = hipGetLastError();
-        return e != hipSuccess ? -(int)e - 100 : 0;
-    }
+                   int n_ptiles, int lds, hipStream_t st) {
     static int wide = -1;
     if (wide < 0) { const char *e = getenv("JLM_MX6_WIDE"); wide = e ? atoi(e) : JLM_MX6_WIDE_DEFAULT; }
     if ((wide > 0 || (wide < 0 && xbias)) && jlm_mx6w_hosts(a, xbias))
@@ -196,9 +105,14 @@ int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, i
         if (xbias) { if (nb != 8) which = 3; }
         else if (!((nb == 7 && ns16 == 13) || (nb == 4 && ns16 == 7) || (nb == 2 && ns16 == 4))) which = 1;
     }
-    static JlmLdsGrant grant[4];
-    const void *fns[4] = {reinterpret_cast<const void *>(MX6_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MX6_KERNEL_GENERIC),
-                          reinterpret_cast<const void *>(MX6_KERNEL_TIED), reinterpret_cast<const void *>(MX6_KERNEL_GENERIC_XB)};
+    // fixed_ref: the forms without a running maximum exist for the inlined shapes (4: D-softmax*, 5: tied k = 256); the caller passes it
+    // only for launches whose descale is 1 (the accumulators are base-2 logits)
+    if (fixed_ref && which == 0) which = 4;
+    if (fixed_ref && which == 2) which = 5;
+    static JlmLdsGrant grant[6];
+    const void *fns[6] = {reinterpret_cast<const void *>(MX6_KERNEL_DSOFTMAX), reinterpret_cast<const void *>(MX6_KERNEL_GENERIC),
+                          reinterpret_cast<const void *>(MX6_KERNEL_TIED), reinterpret_cast<const void *>(MX6_KERNEL_GENERIC_XB),
+                          reinterpret_cast<const void *>(MX6_KERNEL_DSOFTMAX_FR), reinterpret_cast<const void *>(MX6_KERNEL_TIED_FR)};
     if (int rc = jlm_grant_lds(grant[which], fns[which], lds)) return rc;
     const dim3 grid(a.n_cols * n_ptiles), block(512);
     const unsigned char *tm = reinterpret_cast<const unsigned char *>(Tm);
@@ -206,7 +120,9 @@ int jlm_mx6_launch(const MxArgs &a, bool xbias, int fixed_ref, const void *Tm, i
     case 0: hipLaunchKernelGGL(MX6_KERNEL_DSOFTMAX, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
     case 1: hipLaunchKernelGGL(MX6_KERNEL_GENERIC, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
     case 2: hipLaunchKernelGGL(MX6_KERNEL_TIED, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
-    default: hipLaunchKernelGGL(MX6_KERNEL_GENERIC_XB, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    case 3: hipLaunchKernelGGL(MX6_KERNEL_GENERIC_XB, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    case 4: hipLaunchKernelGGL(MX6_KERNEL_DSOFTMAX_FR, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
+    default: hipLaunchKernelGGL(MX6_KERNEL_TIED_FR, grid, block, lds, st, a, tm, ld_tm, part, ld_part, n_rows_max, n_dev, n_ptiles); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return -(int)e - 100;

@@ -63,7 +63,10 @@ __device__ __forceinline__ void mx6_pack16(const unsigned *c, unsigned w[3]) {
 // one sub-range (tiles [vt0, vt1) of one segment) for this workgroup's 256 rows; NB 32-k blocks, NS16 f16 steps (2 NB or 2 NB - 1),
 // MTT 32-word blocks per tile (even), XBIAS as mx_body.  TWO accumulators: block n + 1 multiplies into one while block n's logits
 // are folded straight out of the other -- there is nothing left to combine (no integer accumulator), so no v[] and no copy.
-template <int NB, int NS16, int MTT, bool XBIAS = false>
+// FR (fixed reference, jlm_vocab_lse_mixed_fr): no running maximum -- s = sum 2^y against the reference 0, slices (0, s) -- for launches whose
+// accumulators ARE base-2 logits (descale = 1: the loader scales mx6 operands so, DeviceModel._build_mixed): the fold is exp2 + add per
+// logit, 20 of the max form's 26 VALU cycles (the VALU's share of this kernel is 40 % of its time: profiles/r06_l_pmc_mx6_forms.txt).
+template <int NB, int NS16, int MTT, bool XBIAS = false, bool FR = false>
 __device__ __forceinline__ void mx6_body(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *__restrict__ Tm, int ld_tm,
                                          float2 *__restrict__ part_row, unsigned char *smem) {
     static_assert(MTT % 2 == 0, "the accumulators alternate by 32-word block: an even number per tile");
@@ -160,7 +163,7 @@ __device__ __forceinline__ void mx6_body(const MxSeg &sg, int vt0, int vt1, int 
     const int g_6a = fbase + ((4 + 2 * hf) ^ x) * 16, g_6b = fbase + (5 ^ x) * 16 + 8 * hf;   // this half's FP6 codes: 16 + 8 bytes
     const int g_sc = fbase + (7 ^ x) * 16 + 8 * hf;                                     // ... and its scales (32-k block 0 of the row)
 
-    float m = JLM_NEG_BIG, s = 0.0f;
+    float m = FR ? 0.0f : JLM_NEG_BIG, s = 0.0f;
     // the accumulator that is "finished" before the first block: sixteen -1e30 logits -- their fold leaves (m, s) = (very negative, 16),
     // which the first real fold scales to 0 (as mx_body's v[])
     f32x16 acc[2];
@@ -168,11 +171,20 @@ __device__ __forceinline__ void mx6_body(const MxSeg &sg, int vt0, int vt1, int 
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = -1.0e30f; }
     float tmax, nmn, sc_old, add0, add1;
     constexpr int NMF = NS16 + NB;                       // matrix instructions of a block
-    constexpr int NPIECE = 8 + 1 + 16 + 1;               // 8 x max3, 1, 16 x exp, 1
+    constexpr int NPIECE = FR ? 16 + 1 : 8 + 1 + 16 + 1;   // 8 x max3, 1, 16 x exp, 1   (FR: 16 x exp, 1)
     constexpr int PP = (NPIECE + NMF - 1) / NMF;
     // (XBIAS: the finished accumulator holds base-2 logits after the bias burst; else raw accumulator units, descaled inside the fold)
     auto fold_piece = [&](const f32x16 &pf, int pc) {
         if (MX_ABL & 1) { if (pc == 0) asm volatile("" :: "v"(pf)); return; }
+        if (FR) {
+            if (pc < 16) {
+                const float e = __builtin_amdgcn_exp2f(pf[pc]);
+                if (pc == 0) { add0 = e; add1 = 0.0f; } else if (pc & 1) add1 += e; else add0 += e;
+            } else if (pc == 16) {
+                s += add0 + add1;
+            }
+            return;
+        }
         if (pc < 8) {
             tmax = pc == 0 ? fmaxf(pf[0], pf[1]) : fmaxf(fmaxf(tmax, pf[2 * pc]), pf[2 * pc + 1]);      // (v_max3_f32)
         } else if (pc == 8) {
@@ -208,7 +220,7 @@ __device__ __forceinline__ void mx6_body(const MxSeg &sg, int vt0, int vt1, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float y = pf[r];
-            if (XBIAS) y = fmaf(y, descale, bq[r >> 2][r & 3]);
+            if (XBIAS) y = FR ? y + bq[r >> 2][r & 3] : fmaf(y, descale, bq[r >> 2][r & 3]);
             pf[r] = (MASKED && mt_acc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim_acc) ? JLM_NEG_BIG : y;
         }
     };
@@ -306,255 +318,14 @@ __device__ __forceinline__ void mx6_body(const MxSeg &sg, int vt0, int vt1, int 
 #pragma unroll
     for (int pc = 0; pc < NPIECE; ++pc) fold_piece(acc[1], pc);
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(s, 32);
-    {
+    if (FR) {
+        s += s2;
+    } else {
         const float mm = fmaxf(m, m2);
         s = s * __builtin_amdgcn_exp2f(m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
         m = mm * LN2;
     }
     if (hf == 0 && row_ok) part_row[prow] = make_float2(m, s);
-}
-
-// ------------------------------------------------------------------------------------------------ two row sets per wave
-// mx6_body with RS = 2 row sets of 32 hypotheses per wave (512 rows per workgroup): EVERY fragment read from LDS feeds two matrix
-// instructions and every tile brought in by LDS-DMA serves twice the rows -- the eight-wave kernel's measured costs are additive
-// (profiles/r06_f_mx6_ablate.txt: of 60 us, 18 are exposed fragment reads and 7 LDS-DMA issue) and both halve per row this way, with two
-// waves per SIMD still covering each other.  The operands of two sets fit a wave's 256 registers for contractions of up to four 32-k
-// blocks (k + 2 <= 128: the D-softmax* model's 100- and 50-wide segments; 104 + 64 accumulator registers at k = 100); the 200-wide
-// segment keeps one set per wave and runs its workgroup's two 256-row halves one after the other (vocab_lse_mx6_kernel).
-// Same LDS image, tiles and LDS-DMA as mx6_body; the fold's pieces alternate between the sets.
-template <int NB, int NS16, int MTT, bool XBIAS = false>
-__device__ __forceinline__ void mx6_body2(const MxSeg &sg, int vt0, int vt1, int pt, int n_paths, const unsigned char *__restrict__ Tm, int ld_tm,
-                                          float2 *__restrict__ part_row, unsigned char *smem) {
-    static_assert(MTT % 2 == 0, "the accumulators alternate by 32-word block: an even number per tile");
-    constexpr int RS = 2;
-    constexpr float LN2 = 0.6931471805599453f;
-    constexpr int ROWB = NB * 128;
-    constexpr int TW = 32 * MTT;
-    constexpr int BUFB = TW * ROWB;
-    constexpr int BIAS_OFF = 2 * BUFB;
-    int tid_ = threadIdx.x;
-    asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hf = lane >> 5, li = lane & 31;
-    // ---- 1. row operands of both sets
-    int prow[RS];
-    bool row_ok[RS];
-    f16x8 thi[RS][NS16];
-    i32x8 t6[RS][NB];
-    i32x2 tsc[RS];
-#pragma unroll
-    for (int S = 0; S < RS; ++S) {
-        prow[S] = pt * (256 * RS) + wave * (32 * RS) + S * 32 + li;
-        row_ok[S] = prow[S] < n_paths;
-        const unsigned char *tb0 = Tm + (row_ok[S] ? mx_tm_block(prow[S], ld_tm) : 0) + mx_tm_granule(sg.tm_off, 0, prow[S]);
-        const i32x4 z = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < NS16; ++q) {
-            const i32x4 raw = *reinterpret_cast<const i32x4 *>(tb0 + ((q >> 1) * 8 + 2 * (q & 1) + hf) * 512);
-            thi[S][q] = __builtin_bit_cast(f16x8, row_ok[S] ? raw : z);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const i32x4 ra = *reinterpret_cast<const i32x4 *>(tb0 + (j * 8 + 4 + 2 * hf) * 512);
-            const i32x2 rb = *reinterpret_cast<const i32x2 *>(tb0 + (j * 8 + 5) * 512 + 8 * hf);
-            const i32x4 a = row_ok[S] ? ra : z;
-            t6[S][j] = i32x8{a[0], a[1], a[2], a[3], row_ok[S] ? rb[0] : 0, row_ok[S] ? rb[1] : 0, 0, 0};
-        }
-        tsc[S] = *reinterpret_cast<const i32x2 *>(tb0 + 7 * 512 + 8 * hf);
-    }
-    const float descale = sg.descale;
-
-    // ---- 2. LDS-DMA of a tile (as mx6_body)
-    const unsigned long long bptr = reinterpret_cast<unsigned long long>(sg.B);
-    const unsigned long long bptr_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bptr >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)bptr);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(bptr_u), 0,
-                                                                          __builtin_amdgcn_readfirstlane(sg.n_vocab) * ROWB, 0x00020000);
-    const int r8 = lane >> 3, dslot = lane & 7;
-    const int drow = 8 * wave + r8;
-    const int dvoff = drow * ROWB + ((dslot ^ ((drow >> 1) & 7)) * 16);
-    constexpr int NRG = MTT / 2;
-    __amdgpu_buffer_rsrc_t rs_bias = rs_b;
-    if (XBIAS) {
-        const unsigned long long p2 = reinterpret_cast<unsigned long long>(sg.bias2);
-        const unsigned long long p2u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(p2 >> 32)) << 32) |
-                                       (unsigned)__builtin_amdgcn_readfirstlane((int)p2);
-        rs_bias = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p2u), 0, __builtin_amdgcn_readfirstlane(sg.n_vocab) * 4, 0x00020000);
-    }
-    auto issue = [&](int t, int buf) {
-        if (XBIAS && wave == 0) {
-#pragma unroll
-            for (int i = 0; i < (TW + 63) / 64; ++i)
-                if (i * 64 + 64 <= TW || lane < TW - i * 64)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_bias, (__attribute__((address_space(3))) void *)(smem + BIAS_OFF + (t % 3) * (TW * 4) + i * 256),
-                                                             4, (t * TW + i * 64 + lane) * 4, 0, 0, 0);
-        }
-        const int voff = dvoff + t * (TW * ROWB);
-#pragma unroll
-        for (int i = 0; i < NRG; ++i) {
-            unsigned char *dst = smem + buf * BUFB + ((wave + 8 * i) * NB) * 1024;
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
-                                                         voff + i * (64 * ROWB), j * 128, 0, 0);
-        }
-    };
-    const int x = (li >> 1) & 7;
-    const int fbase = (li >> 3) * (NB * 1024) + (li & 7) * 128;
-    const int g_f0 = fbase + ((0 + hf) ^ x) * 16, g_f1 = fbase + ((2 + hf) ^ x) * 16;
-    const int g_6a = fbase + ((4 + 2 * hf) ^ x) * 16, g_6b = fbase + (5 ^ x) * 16 + 8 * hf;
-    const int g_sc = fbase + (7 ^ x) * 16 + 8 * hf;
-
-    float m[RS], s[RS], tmax[RS], nmn[RS], sc_old[RS], add0[RS], add1[RS];
-    f32x16 acc[2][RS];
-#pragma unroll
-    for (int S = 0; S < RS; ++S) {
-        m[S] = JLM_NEG_BIG; s[S] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][S][r] = 0.0f; acc[1][S][r] = -1.0e30f; }
-    }
-    constexpr int NMF = RS * (NS16 + NB);
-    constexpr int NPIECE = RS * (8 + 1 + 16 + 1);
-    constexpr int PP = (NPIECE + NMF - 1) / NMF;
-    auto fold_piece = [&](f32x16 (&pfs)[RS], int pc2) {
-#pragma clang fp contract(off)          // (the two sets must round alike: jlm_mixed_w.hip)
-        const int S = pc2 % RS, pc = pc2 / RS;
-        const f32x16 &pf = pfs[S];
-        if (MX_ABL & 1) { if (pc == 0) asm volatile("" :: "v"(pf)); return; }
-        if (pc < 8) {
-            tmax[S] = pc == 0 ? fmaxf(pf[0], pf[1]) : fmaxf(fmaxf(tmax[S], pf[2 * pc]), pf[2 * pc + 1]);
-        } else if (pc == 8) {
-            const float mn = fmaxf(m[S], XBIAS ? tmax[S] : tmax[S] * descale);
-            nmn[S] = -mn;
-            sc_old[S] = __builtin_amdgcn_exp2f(m[S] - mn);
-            m[S] = mn;
-            add0[S] = 0.0f; add1[S] = 0.0f;
-        } else if (pc < 25) {
-            const int r = pc - 9;
-            const float e = __builtin_amdgcn_exp2f(XBIAS ? pf[r] + nmn[S] : fmaf(pf[r], descale, nmn[S]));
-            if (r & 1) add1[S] += e; else add0[S] += e;
-        } else if (pc == 25) {
-            s[S] = fmaf(s[S], sc_old[S], add0[S] + add1[S]);
-        }
-    };
-    issue(vt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    int lim_acc = 1 << 30, mt_acc = 0, t_acc = vt0;
-    auto finish = [&](auto masked_c, f32x16 (&pfs)[RS]) {
-        constexpr bool MASKED = decltype(masked_c)::value != 0;
-        if (!XBIAS && !MASKED) return;
-        f32x4 bq[4];
-        if (XBIAS) {
-            const unsigned char *bp = smem + BIAS_OFF + (t_acc % 3) * (TW * 4) + (mt_acc * 32 + 4 * hf) * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4 *>(bp + q * 32);
-        }
-#pragma unroll
-        for (int S = 0; S < RS; ++S)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float y = pfs[S][r];
-                if (XBIAS) y = fmaf(y, descale, bq[r >> 2][r & 3]);
-                pfs[S][r] = (MASKED && mt_acc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim_acc) ? JLM_NEG_BIG : y;
-            }
-    };
-    auto tile = [&](auto masked_c, int t) {
-        if (!(MX_ABL & 4) && t + 1 < vt1) issue(t + 1, buf ^ 1);
-        const int lim = sg.n_vocab - t * TW;
-        i32x4 F0, F1;
-        i32x8 F6;
-        i32x2 fsc;
-        {
-            const unsigned char *bs0 = smem + buf * BUFB;
-            F0 = *reinterpret_cast<const i32x4 *>(bs0 + g_f0);
-            const i32x4 a = *reinterpret_cast<const i32x4 *>(bs0 + g_6a);
-            const i32x2 b = *reinterpret_cast<const i32x2 *>(bs0 + g_6b);
-            fsc = *reinterpret_cast<const i32x2 *>(bs0 + g_sc);
-            F1 = *reinterpret_cast<const i32x4 *>(bs0 + g_f1);
-            F6 = i32x8{a[0], a[1], a[2], a[3], b[0], b[1], 0, 0};
-        }
-#pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-            const unsigned char *bs = smem + buf * BUFB + mt * (4 * NB * 1024);
-            f32x16 (&wf)[RS] = acc[mt & 1];
-            f32x16 (&pf)[RS] = acc[(mt & 1) ^ 1];
-            finish(masked_c, pf);
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            i32x2 fsc_next = fsc;
-            mx_for_each_ic([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                constexpr bool second = 2 * J + 1 < NS16;
-                constexpr bool rdm = (J + 1 < NB);
-                const bool more = (rdm || mt + 1 < MTT) && !(MX_ABL & 32);
-                const unsigned char *nx = rdm ? bs + (J + 1) * 1024 : bs + (4 * NB * 1024);
-                auto pieces = [&](int q) {
-#pragma unroll
-                    for (int pc = q * PP; pc < (q + 1) * PP && pc < NPIECE; ++pc) fold_piece(pf, pc);
-                };
-                constexpr int Q0 = 3 * RS * J;
-                // (a fragment is refilled in place behind the SECOND set's instruction: the last one that reads it)
-                mx_for_each_ic([&](auto sc) {
-                    constexpr int S = decltype(sc)::value;
-                    wf[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F0), thi[S][2 * J], J == 0 ? zf : wf[S], 0, 0, 0);
-                    if (S == RS - 1 && more) F0 = *reinterpret_cast<const i32x4 *>(nx + g_f0);
-                    pieces(Q0 + S);
-                }, std::make_integer_sequence<int, RS>{});
-                mx_for_each_ic([&](auto sc) {
-                    constexpr int S = decltype(sc)::value;
-                    wf[S] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F6, t6[S][J], wf[S], 2, 2, J & 3, fsc[J >> 2], J & 3, tsc[S][J >> 2]);
-                    if (S == RS - 1 && more) {
-                        const i32x4 a = *reinterpret_cast<const i32x4 *>(nx + g_6a);
-                        const i32x2 b = *reinterpret_cast<const i32x2 *>(nx + g_6b);
-                        F6 = i32x8{a[0], a[1], a[2], a[3], b[0], b[1], 0, 0};
-                        if (!rdm) fsc_next = *reinterpret_cast<const i32x2 *>(nx + g_sc);
-                    }
-                    pieces(Q0 + RS + S);
-                }, std::make_integer_sequence<int, RS>{});
-                mx_for_each_ic([&](auto sc) {
-                    constexpr int S = decltype(sc)::value;
-                    if constexpr (second) wf[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, F1), thi[S][second ? 2 * J + 1 : 0], wf[S], 0, 0, 0);
-                    if (S == RS - 1 && more) F1 = *reinterpret_cast<const i32x4 *>(nx + g_f1);
-                    pieces(Q0 + 2 * RS + S);
-                }, std::make_integer_sequence<int, RS>{});
-#pragma unroll
-                for (int i = 0; i < 3 * RS; ++i) {
-                    const bool has_m = second || (i / RS != 2);
-                    if (has_m) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if ((i % RS) == RS - 1 && (rdm || mt + 1 < MTT) && !(MX_ABL & 32)) {
-                        if (i / RS != 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        else if (rdm) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    }
-                    if (!(MX_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 3 * PP, 0);
-                }
-            }, std::make_integer_sequence<int, NB>{});
-            __builtin_amdgcn_sched_barrier(0);
-            fsc = fsc_next;
-#pragma unroll
-            for (int pc = 3 * RS * NB * PP; pc < NPIECE; ++pc) fold_piece(pf, pc);
-            lim_acc = lim; mt_acc = mt; t_acc = t;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(MX_ABL & 8)) __builtin_amdgcn_s_barrier();
-        buf ^= 1;
-    };
-    const int t_full = min(vt1, sg.n_vocab / TW);
-    for (int t = vt0; t < t_full; ++t) tile(IC<0>{}, t);
-    for (int t = max(vt0, t_full); t < vt1; ++t) tile(IC<1>{}, t);
-    finish(IC<1>{}, acc[1]);
-#pragma unroll
-    for (int pc = 0; pc < NPIECE; ++pc) fold_piece(acc[1], pc);
-#pragma unroll
-    for (int S = 0; S < RS; ++S) {
-        const float m2 = __shfl_xor(m[S], 32), s2 = __shfl_xor(s[S], 32);
-        const float mm = fmaxf(m[S], m2);
-        const float ss = fmaf(s[S], __builtin_amdgcn_exp2f(m[S] - mm), s2 * __builtin_amdgcn_exp2f(m2 - mm));
-        if (hf == 0 && row_ok[S]) part_row[prow[S]] = make_float2(mm * LN2, ss);
-    }
 }
 
 }  // namespace jlm_mx

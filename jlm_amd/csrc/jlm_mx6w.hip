@@ -29,7 +29,7 @@ using namespace jlm_mx;
 namespace {
 
 // NB 32-k blocks per row, NS16 f16 steps, MTT 32-word blocks per tile (even), XB: external biases (k a multiple of 32), FR: fixed
-// reference -- s = sum 2^y against 0, no running maximum (jlm_vocab_lse_mixed_fr: the loader's decision)
+// reference -- s = sum 2^y against 0, no running maximum (jlm_vocab_lse_mixed_fr: the loader's decision), for launches with descale = 1
 template <int NB, int NS16, int MTT, bool XB, bool FR>
 struct Mx6Wide {
     static_assert(MTT % 2 == 0, "the accumulators alternate by 32-word block");
@@ -68,7 +68,7 @@ struct Mx6Wide {
             if (pc < 16) {
                 const int r = pc;
                 float y = pf[r];
-                if (XB) y = fmaf(y, descale, bq[r >> 2][r & 3]);
+                if (XB) y = FR ? y + bq[r >> 2][r & 3] : fmaf(y, descale, bq[r >> 2][r & 3]);
                 pf[r] = (MASKED && mtp * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf >= lim) ? JLM_NEG_BIG : y;
                 return;
             }
@@ -76,7 +76,7 @@ struct Mx6Wide {
         }
         if (FR) {
             if (pc < 16) {
-                const float e = __builtin_amdgcn_exp2f(XB ? pf[pc] : pf[pc] * descale);
+                const float e = __builtin_amdgcn_exp2f(pf[pc]);             // (FR launches have descale = 1: the accumulators are base-2 logits)
                 if (pc == 0) { add0[S] = e; add1[S] = 0.0f; } else if (pc & 1) add1[S] += e; else add0[S] += e;
             } else if (pc == 16) {
                 s[S] += add0[S] + add1[S];

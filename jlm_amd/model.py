@@ -667,6 +667,18 @@ class DeviceModel:
             s8 = 0.0 if fmt == "mx6" else 2.0 ** int(np.ceil(np.log2(max(hmax, 2.0 ** -100) / 127.0)))      # (ABI 11: s8 = 0 selects the FP6 planes)
             tb = 1.0 if t_bound is None else max(float(t_bound[sg["t_off"]:sg["t_off"] + k].max()), 1.0)
             eT = pow2_below(2.0 ** 15, tb * LOG2E)
+            if fmt == "mx6":
+                # mx6 operands want eT + eB = 0: the accumulators are then base-2 logits themselves (descale = 1) and the fold needs no
+                # multiply -- and no running maximum where the loader allows the fixed reference (exp2 + add per logit).  The FP6 planes
+                # carry their own block scales, so only the f16 hi planes feel the choice: any exponent that keeps an operand's largest
+                # value between 2^-3 and the top of the f16 range leaves its typical values normal (what falls into the subnormals is
+                # good to 2^-25 absolute, below the FP6 planes' own step).  Balanced: largest |B| 2^e = largest |T| log2 e 2^-e.
+                lo = max(eB - 17, -eT)
+                hi = min(eB, 17 - eT, 13)                        # (new eT = -e >= -13: the bias constant 2^(eT - 11) must stay representable)
+                if lo <= hi:
+                    bal = int(round(0.5 * (np.log2(max(tb * LOG2E, 1e-30)) - np.log2(max(bmax, 1e-30)))))
+                    eB = int(min(max(bal, lo), hi))
+                    eT = -eB
             dst = torch.zeros((nv, 32 * nb), dtype=torch.float32, device=self.device)
             O.pack_mixed(self.seg_B[i], 0, nv, k, sg["ldb"], self.b2, sg["v_start"], float(2.0 ** eB), float(2.0 ** eB * LOG2E), float(s8),
                          dst, 32 * nb)
