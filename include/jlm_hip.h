@@ -299,6 +299,11 @@ typedef struct {
     int *live_base;               /* [n_frames*n_sent] */
     const float *lse_part;
     int ld_part, n_parts;
+    /* ABI 11: one device int (NULL: none) that jlm_beam_step ORs 1 into when a folded log-normaliser is not finite -- a row whose
+     * logits left the range of the fixed-reference normaliser (jlm_vocab_lse_mixed_fr: sum 2^y overflowed to inf or vanished to 0).
+     * An overflowed row's hypotheses score -inf and are pruned silently otherwise; the caller zeroes the int per batch and reads it
+     * back with the traces (jlm_amd/engine.py: DecodeEngine.collect raises). */
+    int *flags;
 } jlm_beam_state;
 
 /* K7+K8: candidate scoring and stable per-sentence top-k for frame `frame`.

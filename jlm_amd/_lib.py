@@ -32,7 +32,7 @@ class BeamState(Structure):
                 ("bp", c_void_p), ("node", c_void_p), ("word", c_void_p),
                 ("cnt", c_void_p), ("live", c_void_p), ("n_live", c_void_p),
                 ("edge", c_void_p),
-                ("live_base", c_void_p), ("lse_part", c_void_p), ("ld_part", c_int), ("n_parts", c_int)]
+                ("live_base", c_void_p), ("lse_part", c_void_p), ("ld_part", c_int), ("n_parts", c_int), ("flags", c_void_p)]
 
 
 class DecodeModel(Structure):

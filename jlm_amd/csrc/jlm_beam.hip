@@ -336,7 +336,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
                     m = mm;
                 }
                 if (sub == 0 && r < kprev) {
-                    const double l = (double)m + log(sm);
+                    double l = (double)m + log(sm);
+                    // inf / nan (jlm_beam_state.flags): the batch is flagged and the value replaced by a finite one -- a NaN key would leave
+                    // the selection rounds below without a winner and the next LSTM step with garbage row indices
+                    if (!(fabs(l) < 1.0e300)) { if (st.flags) atomicOr(st.flags, 1); l = 1.0e30; }
                     lse_new[r] = l;
                     st.lse[(size_t)(frame - 1) * rmax + s * beam + r] = l;
                 }

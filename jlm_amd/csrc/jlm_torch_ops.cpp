@@ -209,7 +209,7 @@ struct JlmPlan : torch::CustomClassHolder {
         st.bp = tptr<int>(tensors, "bp"); st.node = tptr<int>(tensors, "node"); st.word = tptr<int>(tensors, "word");
         st.cnt = tptr<int>(tensors, "cnt"); st.live = tptr<int>(tensors, "live"); st.n_live = tptr<int>(tensors, "n_live");
         st.edge = tptr<const float>(tensors, "edge"); st.live_base = tptr<int>(tensors, "live_base");
-        st.lse_part = nullptr; st.ld_part = 0; st.n_parts = 0;
+        st.lse_part = nullptr; st.ld_part = 0; st.n_parts = 0; st.flags = nullptr;
         p.kind = (int)geti(i, "kind"); p.max_cands = (int)geti(i, "max_cands");
         p.h = tptr<void>(tensors, "h"); p.c = tptr<float>(tensors, "c"); p.T = tptr<float>(tensors, "T");
         p.g0 = at_off("off_g0"); p.cidx = at_off("off_cidx"); p.sidx = at_off("off_sidx");
@@ -228,6 +228,8 @@ struct JlmPlan : torch::CustomClassHolder {
                     "jlm.Plan: Tm must hold n_sent * beam rows (rounded up to whole 32-row blocks) of ld_tm");
         p.out_nodes = tptr<int>(tensors, "out_nodes"); p.out_len = tptr<int>(tensors, "out_len");
         p.out_score = tptr<double>(tensors, "out_score"); p.stride = (int)geti(i, "stride");
+        // ABI 11: one spare element behind the trace lengths = the batch's flag word (jlm_beam_state.flags): it travels back with them
+        if (p.out_len && find(tensors, "out_len")->numel() > (int64_t)lat.n_sent * lat.beam) st.flags = p.out_len + (size_t)lat.n_sent * lat.beam;
         TORCH_CHECK(st.score && st.lse && st.bp && st.node && st.word && st.cnt && st.live && st.n_live && st.live_base && p.h && p.c &&
                         p.T && p.edge && p.out_nodes && p.out_len && p.out_score && lat.n_sent > 0 && lat.beam > 0 && frames_cap > 0,
                     "jlm.Plan: a required buffer is missing");
@@ -326,6 +328,7 @@ int64_t decode_batch(const c10::intrusive_ptr<JlmModel> &model, const c10::intru
     }
     jlm_check((int)hipMemsetAsync(cnt->data_ptr(), 0, (size_t)cnt->numel() * 4, st), "hipMemsetAsync (cnt)");
     jlm_check((int)hipMemsetAsync(n_live->data_ptr(), 0, (size_t)n_live->numel() * 4, st), "hipMemsetAsync (n_live)");
+    if (pl.st.flags) jlm_check((int)hipMemsetAsync(pl.st.flags, 0, 4, st), "hipMemsetAsync (flags)");
     const int64_t rc = decode_frames(model, plan, n_frames, vs_max, di_max, dd_max, use_side, timed, lse_cu_share_pct);
     if (rc != 0) return rc;
     jlm_check((int)hipMemcpyAsync(h_nodes.data_ptr(), o_nodes->data_ptr(), (size_t)o_nodes->numel() * 4, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (traces)");

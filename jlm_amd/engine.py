@@ -135,11 +135,11 @@ class _Plan:
             self.Tm = torch.zeros(((rmax + 31) // 32 * 32, m.ld_tm), device=dev, dtype=f32)      # whole 32-row blocks (granule-major, jlm_hip.h)
         self.stride = F + 1
         self.out_nodes = e((rmax, self.stride), i32)
-        self.out_len = e(rmax, i32)
+        self.out_len = torch.zeros(rmax + 1, device=dev, dtype=i32)       # [rmax]: the batch's flag word (jlm_beam_state.flags, ABI 11)
         self.out_score = e(rmax, f64)
         pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
         self.h_nodes = pin(torch.empty((rmax, self.stride), dtype=i32))
-        self.h_len = pin(torch.empty(rmax, dtype=i32))
+        self.h_len = pin(torch.zeros(rmax + 1, dtype=i32))
         self.h_score = pin(torch.empty(rmax, dtype=f64))
         self.h_nlive = pin(torch.empty(F, dtype=i32))
         self.busy = False
@@ -376,6 +376,7 @@ class DecodeEngine:
                     p.dev_ints[d:d + n].copy_(blk.tensor[o:o + n], non_blocking=True)
         p.cnt.zero_()
         p.n_live.zero_()
+        p.out_len[-1:].zero_()          # the flag word
         # (side stream for the edge logits -- `side` above: with one stream, and with two when the hardware queues are there (ROCm's default
         #  of four is not enough: jlm_amd/__init__.py); with three or more streams (the default is four) they run on the batch's own stream)
         # the whole launch sequence of the batch: ONE op, no host synchronisation inside (csrc/jlm_decode.hip)
@@ -417,15 +418,21 @@ class DecodeEngine:
                 if self.keep_n_live:
                     self.last_n_live = p.h_nlive.numpy()[:lat.n_frames].copy()
         self.last_state = p
+        if int(p.h_len[-1]) != 0:
+            # (ABI 11) the beam step met a log-normaliser that is not finite: a row's sum of 2^y overflowed (or vanished) in the fixed-reference
+            # normaliser -- an overflowed row's hypotheses would score -inf and be pruned, leaving a plausible but wrong n-best
+            p.busy = False
+            raise _lib.JlmHipError("a log-normaliser is not finite: this model's logits left the range the fixed-reference normaliser covers "
+                                   "(DeviceModel.mixed_calib); set JLM_MX_FIXREF=0")
         if getattr(self.m, "lse_fixed_ref", 0):
             # the normaliser ran without a running maximum (jlm_vocab_lse_mixed_fr): a row whose logits left the range the load-time probe
             # vouched for comes back as log 0 or log inf -- never a plausible score.  Loud, not silent:
-            sc, ln = p.h_score.numpy(), p.h_len.numpy()
+            sc, ln = p.h_score.numpy(), p.h_len.numpy()[:-1]
             if not np.isfinite(sc[ln > 0]).all():
                 p.busy = False
                 raise _lib.JlmHipError("a path score is not finite: this model's logits left the range the fixed-reference normaliser covers "
                                        "(DeviceModel.mixed_calib); set JLM_MX_FIXREF=0")
-        out = self._read_out(lat, p.h_nodes.numpy(), p.h_len.numpy(), p.h_score.numpy(), topN)
+        out = self._read_out(lat, p.h_nodes.numpy(), p.h_len.numpy()[:-1], p.h_score.numpy(), topN)
         p.busy = False
         return out
 

@@ -346,3 +346,26 @@ def test_oversized_lattice_cells_take_the_host_path(fx, monkeypatch):
     got = d.decode_batch(sents, beam_width=6)
     for s, g in zip(sents, got):
         _same(g, o.decode(s, beam_width=6), ("oversized", s))
+
+
+@pytest.mark.parametrize("name", ["wide-vtable"])          # (the D-softmax* shapes: a launch with a fixed-reference kernel form)
+def test_fixed_reference_normaliser_overflow_is_loud(name, tmp_path, monkeypatch):
+    """Round-5 advice / ABI 11: the normaliser without a running maximum (jlm_vocab_lse_mixed_fr: sum 2^y against the reference 0) on a
+    model whose logits leave the f32 range.  The loader never enables the form for such a model (its probe bounds |log Z| at 40 bits);
+    here it is FORCED on: an overflowed row's hypotheses score -inf and would be pruned silently -- the beam step raises the batch's
+    flag word (jlm_beam_state.flags) and DecodeEngine.collect turns it into an error instead of a plausible n-best."""
+    from jlm_amd import _lib
+    if os.environ.get("JLM_PRECISION", "f16x3") != "f16x3" or os.environ.get("JLM_LSE_MIXED", "1") == "0":
+        pytest.skip("the suite is running without the mixed rows")
+    monkeypatch.setenv("JLM_MIXED_MAX_LSE_RMS", "0")          # no calibration: the rows stay mixed whatever the model
+    f = _rescaled_fixture(tmp_path, name, _scale_out(600.0, 1.0))
+    d, _o = _pair(f, "static")
+    m = d.model.dev
+    assert m.mixed_idx and not m.lse_fixed_ref and m.mixed_fmt == "mx6" and all(x == 1.0 for x in m.mixed_descale), (m.mixed_fmt, m.mixed_descale)
+    sents = synth.make_ragged_sentences(4, 4, 9, seed=321, alphabet=f["alphabet"])
+    ok = d.decode_batch(sents, beam_width=4)                   # the running-maximum form copes with any range
+    assert all(np.isfinite(s) for r in ok for s, _ in r)
+    m.lse_fixed_ref, m._decode_model = 1, None
+    d._engine.m = m
+    with pytest.raises(_lib.JlmHipError, match="not finite"):
+        d.decode_batch(sents, beam_width=4)

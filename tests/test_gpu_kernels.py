@@ -741,6 +741,9 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10, fmt="int8"):
         Bg = torch.as_tensor(B_np).cuda()
         bmax = max(float(np.abs(B_np).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427 if k % 32 else 0.0)
         eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
+        eT_i = eT
+        if fmt == "mx6":        # as DeviceModel._build_mixed scales mx6 operands: eT + eB = 0 (descale = 1: the fixed-reference kernel forms run)
+            eB, eT_i = 4, -4
         hmax = float(np.abs((B_np * np.float32(2.0 ** eB)).astype(np.float16).astype(np.float32)).max())
         s_b = 0.0 if fmt == "mx6" else 2.0 ** int(np.ceil(np.log2(hmax / 127.0)))
         nb = k // 32 if k % 32 == 0 else (k + 2 + 31) // 32          # a contraction that fills its last block: no bias columns
@@ -749,7 +752,7 @@ def _mixed_segments(L, rng, V, widths, bounds, b2_np, eT=10, fmt="int8"):
                                 s_b, dst.data_ptr(), 32 * nb, _st()) == 0
         keep += [Bg, dst]
         segs[i] = _lib.Segment(bounds[i], bounds[i + 1], k, off, dst.data_ptr(), 32 * nb)
-        ts[i], ds[i], s8[i] = 2.0 ** eT, 2.0 ** -(eT + eB), s_b
+        ts[i], ds[i], s8[i] = 2.0 ** eT_i, 2.0 ** -(eT_i + eB), s_b
         off += k
     return segs, ts, ds, s8, Bs, keep, off, b2
 
@@ -782,8 +785,7 @@ def test_mx6_packers_match_the_numpy_double(L, widths, R):
         nv, nb = bounds[i + 1] - bounds[i], segs[i].ldb // 32
         dev_rows = keep[2 * i + 1].cpu().numpy().view(np.uint8).reshape(nv, nb * 128)
         host = np.zeros((nv, nb * 128), dtype=np.uint8)
-        bmax = max(float(np.abs(Bs[i]).max()), float(np.abs(b2_np[bounds[i]:bounds[i + 1]]).max()) * 1.4427 if k % 32 else 0.0)
-        eB = int(np.floor(np.log2(2.0 ** 14 / bmax)))
+        eB = 4                                           # (_mixed_segments' scale for mx6 rows)
         src = np.ascontiguousarray(Bs[i])
         bias = np.ascontiguousarray(b2_np[bounds[i]:bounds[i + 1]])
         assert FK.jlm_pack_mixed(src.ctypes.data, nv, k, k, bias.ctypes.data, 2.0 ** eB, 2.0 ** eB * 1.4426950408889634, 0.0,
@@ -872,19 +874,22 @@ def test_vocab_lse_mixed(L, V, widths, bounds, R, fmt):
     ld_tm = L.jlm_mixed_t_stride(segs, len(widths))
     Tm = torch.zeros(((R + 31) // 32 * 32, ld_tm), dtype=torch.float32, device="cuda")        # compact: packed row r = T row rows[r]
     assert _pack_t(L, fmt)(segs, ts, len(widths), T.data_ptr(), ldt, rows.data_ptr(), R, nd.data_ptr(), Tm.data_ptr(), ld_tm, _st()) == 0
-    n = L.jlm_vocab_lse_mixed(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
-    assert n >= len(widths), n
-    torch.cuda.synchronize()
-    p = part[:n, :R - 2].cpu().numpy().astype(np.float64)
-    with np.errstate(divide="ignore"):
-        v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
-    mx = v.max(axis=0)
-    lse = mx + np.log(np.exp(v - mx).sum(axis=0))
     Tsel = T_np[rows_np[:R - 2]].astype(np.float64)
     y = np.concatenate([Tsel[:, segs[i].t_off:segs[i].t_off + widths[i]] @ Bs[i].astype(np.float64).T for i in range(len(widths))], axis=1) + b2_np
     ymax = y.max(axis=1)
     ref = ymax + np.log(np.exp(y - ymax[:, None]).sum(axis=1))
-    assert np.abs(lse - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), np.abs(lse - ref).max()
+    # (the form without a running maximum too: on mx6 rows -- descale = 1 -- the D-softmax* and tied k = 256 shapes have kernel forms of their own)
+    for entry in (L.jlm_vocab_lse_mixed, L.jlm_vocab_lse_mixed_fr):
+        part.zero_()
+        n = entry(segs, ds, s8, bias2, len(widths), Tm.data_ptr(), ld_tm, part.data_ptr(), R, 96, R, nd.data_ptr(), _st())
+        assert n >= len(widths), n
+        torch.cuda.synchronize()
+        p = part[:n, :R - 2].cpu().numpy().astype(np.float64)
+        with np.errstate(divide="ignore"):
+            v = np.where(p[:, :, 1] > 0, p[:, :, 0] + np.log(p[:, :, 1]), -np.inf)
+        mx = v.max(axis=0)
+        lse = mx + np.log(np.exp(v - mx).sum(axis=0))
+        assert np.abs(lse - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (entry.__name__ if hasattr(entry, "__name__") else entry, np.abs(lse - ref).max())
     # logits through one-word ranges (sampled words of every segment)
     worst = 0.0
     for i in range(len(widths)):
