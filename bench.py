@@ -760,6 +760,9 @@ def main():
                    "timed": "strings -> strings (lattice build, upload, device decode, n-best read-out), pipelined",
                    "parallelism": "sentence-sharded x%d, no collective" % world},
     }
+    line["notes"] = ("north_star names wavefront shuffles for the back-pointer scan: the per-frame chain scan of the incremental decoder (beam_step_kernel<2>) "
+                     "and the per-beam top-k (DPP arg-min rounds) are wave-level; the once-per-batch n-best trace (backtrace_kernel, ~12 us of a 40 ms "
+                     "batch) deliberately stays one thread per path")
     line.update(line_extra)
     line.update({"roofline": roofline, "gate_gemm": gate_obj, "cpu_baseline": cpu})
     print(json.dumps(line))
