@@ -90,6 +90,7 @@ class Decoder():
         self._builder = LatticeBuilder(self.full_lexicon, self.full_reading_dict, self.w2i)
         self._engine = DecodeEngine(self.model.dev)
         self.pipeline_depth = self._engine.n_streams      # chunks in flight in decode_batch (see depth_for)
+        self._paths_calibrated = False
         self.lattice_vocab = None
         self.backward_lookup = None
         self.perf_sen = 0
@@ -121,6 +122,52 @@ class Decoder():
         if os.environ.get("JLM_NO_GC_FREEZE", "0") != "1":
             gc.collect()
             gc.freeze()
+        self._calibrate_on_decoded_paths()
+
+    CALIB_SENTENCES, CALIB_WORDS, CALIB_BEAM = 32, 6, 8
+
+    def _calibrate_on_decoded_paths(self):
+        """Round 6 (verdict item 3): the load-time calibration of the normaliser's row format once more on contexts the lattice search
+        really visits.  The model alone (DeviceModel._calibrate_mixed) probes seeded word draws; here a few synthetic sentences of
+        THIS lexicon -- readings of in-vocabulary words drawn ~ 1 / rank, concatenated -- are decoded, and the word sequences of the
+        hypotheses the beam kept become one more probe (DeviceModel.calibrate_on_paths: the worst probe decides).  Only for a model
+        that kept mixed rows (a model on split rows has nothing to re-decide); JLM_CALIB_PATHS=0: off."""
+        m = self.model.dev
+        if self._paths_calibrated or os.environ.get("JLM_CALIB_PATHS", "1") == "0" or not getattr(m, "mixed_idx", None) \
+                or float(os.environ.get("JLM_MIXED_MAX_LSE_RMS", "1")) <= 0.0:
+            return
+        self._paths_calibrated = True
+        import numpy as np
+        rng = np.random.RandomState(20240929)
+        V = len(self.w2i)
+        sents = []
+        for _ in range(self.CALIB_SENTENCES):
+            ids = np.minimum((np.exp(rng.random_sample(self.CALIB_WORDS) * np.log(V + 1.0)) - 1.0).astype(np.int64), V - 1)
+            reading = ""
+            for i in ids:
+                tok = self.i2w[int(i)].split("/")
+                if len(tok) >= 3:
+                    reading += tok[1] if tok[1] != "" else tok[0]
+            if reading:
+                sents.append(reading[:24])
+        if not sents:
+            return
+        timing, self.perf_timing = self.perf_timing, False
+        try:
+            nbest = Decoder.decode_batch(self, sents, topN=self.CALIB_BEAM, beam_width=self.CALIB_BEAM)
+        except Exception:                  # (a lexicon whose readings do not decode: the synthetic draws stand)
+            self.perf_timing = timing
+            return
+        self.perf_timing = timing
+        self.perf_sen = 0
+        unk = self.w2i.get("<unk>", 0)
+        paths = [[self.w2i.get(w, unk) for w in words] for res in nbest for _s, words in res if words]
+        before = (m.mixed_fmt, list(m.mixed_idx))
+        m.calibrate_on_paths(paths, first_word=self.w2i.get("<eos>", 0))
+        if (m.mixed_fmt, list(m.mixed_idx)) != before:
+            self._engine = DecodeEngine(m)     # (plans of the form the model had are of no use to the one it has now)
+            self.pipeline_depth = self._engine.n_streams
+        self.lattice_vocab, self.backward_lookup, self.last_lattice = None, None, None
 
     def _load_vocab(self):
         self.vocab = Vocab(self.config['vocab_size'])

@@ -379,12 +379,23 @@ class DeviceModel:
                 del wt8
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
-            # Round 6: the cross-term planes of the mixed rows come in two formats.  mx6 (FP6 with a scale per 32 k-values, one
-            # block-scaled matrix instruction per 32 k-values for both cross terms: csrc/jlm_mx6_body.h) is built and measured first;
-            # a model it does not pass on -- or a shape it does not host -- gets the int8 planes (and their two-format launches)
-            # exactly as before, then split rows.  JLM_LSE_MX6=0: int8 planes only.
-            self.mixed_fmt, mx6_calib = None, None
-            formats = (["mx6"] if os.environ.get("JLM_LSE_MX6", "1") != "0" else []) + ["int8"]
+            self._t_bound, self._pow2_below = t_bound, pow2_below
+            self._extra_probe_words = []
+            self._select_mixed_format()
+
+    def _select_mixed_format(self):
+        """Round 6: the cross-term planes of the mixed rows come in two formats.  mx6 (FP6 with a scale per 32 k-values, one
+        block-scaled matrix instruction per 32 k-values for both cross terms: csrc/jlm_mx6_body.h) is built and measured first;
+        a model it does not pass on -- or a shape it does not host -- gets the int8 planes (and their two-format launches)
+        exactly as before, then split rows.  JLM_LSE_MX6=0: int8 planes only.  Called at load and once more by the decoder with
+        probe rows taken from real decodes (``calibrate_on_paths``)."""
+        t_bound, pow2_below = self._t_bound, self._pow2_below
+        self._decode_model = None
+        self.lse_fixed_ref = 0
+        self.mixed_calib = None
+        self.mixed_fmt, mx6_calib = None, None
+        formats = (["mx6"] if os.environ.get("JLM_LSE_MX6", "1") != "0" else []) + ["int8"]
+        with self._ctx():
             for fmt in formats:
                 if self.stationary_ok:
                     self._build_mixed(t_bound, pow2_below, fmt)
@@ -398,11 +409,31 @@ class DeviceModel:
                     mx6_calib = self.mixed_calib
                 if self.mixed_idx:
                     break
-            self.mixed_fmt = self.mixed_fmt if self.mixed_idx else None
-            if self.mixed_calib is not None:
-                self.mixed_calib["fmt"] = self.mixed_fmt
-                if mx6_calib is not None and mx6_calib is not self.mixed_calib:
-                    self.mixed_calib["mx6"] = {k: v for k, v in mx6_calib.items() if k in ("lse_rms_diff", "lse_max_diff", "reason", "kept")}
+        self.mixed_fmt = self.mixed_fmt if self.mixed_idx else None
+        if self.mixed_calib is not None:
+            self.mixed_calib["fmt"] = self.mixed_fmt
+            if mx6_calib is not None and mx6_calib is not self.mixed_calib:
+                self.mixed_calib["mx6"] = {k: v for k, v in mx6_calib.items() if k in ("lse_rms_diff", "lse_max_diff", "reason", "kept")}
+
+    def calibrate_on_paths(self, paths, first_word=0, max_steps=12):
+        """Round 6 (verdict item 3): probe rows taken from REAL decodes.  ``paths``: word-id sequences of hypotheses a decode kept (the
+        decoder passes the n-best paths of a few synthetic sentences of its own lexicon); row r of the extra probe consumes
+        ``first_word`` (the <eos> every hypothesis starts from) and then the words of path r from the zero state -- the contexts the
+        lattice search actually visits, on top of the seeded word draws of ``CALIB_PROBES``.  The format cascade runs again with that
+        probe among the others (the worst probe decides); returns the new ``mixed_calib``."""
+        paths = [list(map(int, p)) for p in paths if len(p)]
+        if not paths or not getattr(self, "split_lstm", False) or not hasattr(self, "_pow2_below"):
+            return getattr(self, "mixed_calib", None)
+        R = self.CALIB_ROWS
+        S = int(min(max_steps, max(len(p) for p in paths) + 1))
+        w = np.zeros((S, R), dtype=np.int32)
+        for r in range(R):
+            seq = [int(first_word)] + paths[r % len(paths)]
+            for t in range(S):
+                w[t, r] = seq[t % len(seq)]
+        self._extra_probe_words = [w]
+        self._select_mixed_format()
+        return self.mixed_calib
 
     CALIB_ROWS, CALIB_STEPS, CALIB_SEED = 256, 3, 20240929
     # (kind, LSTM steps from the zero state, seed offset): uniform word ids / ids ~ 1 / rank over a longer chain, two seeds each
@@ -483,6 +514,12 @@ class DeviceModel:
             else:
                 w[R:] = rng.randint(0, self.V, size=S * R)
             probes.append(dict(kind=kind, steps=S, seed=seed, G=G, rowlist=i32(np.arange(G)), prev=i32(np.arange(G) - R), word=i32(w), lse0=None))
+        for j, pw in enumerate(getattr(self, "_extra_probe_words", None) or []):      # [steps, rows] word ids from real decodes (calibrate_on_paths)
+            S = int(pw.shape[0])
+            G = (S + 1) * R
+            w = np.zeros(G, dtype=np.int32)
+            w[R:] = np.asarray(pw, dtype=np.int32).reshape(-1)
+            probes.append(dict(kind="paths", steps=S, seed=j, G=G, rowlist=i32(np.arange(G)), prev=i32(np.arange(G) - R), word=i32(w), lse0=None))
 
         def probe(form, pr):
             """log-normalisers of a probe's rows in the given form (the model object as it stands), or a reason they cannot be had"""

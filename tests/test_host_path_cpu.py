@@ -297,6 +297,8 @@ def test_mixed_rows_normaliser_route(fx, fake, monkeypatch, name, fmt):
     f = fx(name)
     calls = {"hybrid": 0, "pack_t": 0}
     lib = fake
+    monkeypatch.setenv("JLM_CALIB_PATHS", "0")        # (the launch counts below are those of the model's own probes; the decoder's extra
+    #                                                    probe from decoded paths has a test of its own)
     if fmt == "int8":
         monkeypatch.setenv("JLM_LSE_MX6", "0")
     want_fmt = "int8" if name.startswith("wideh") else fmt          # (the two-format launch hosts int8 planes only)
@@ -475,3 +477,25 @@ def test_random_models_on_the_double(seed, tmp_path, fake):
     """A few of the GPU suite's random model draws (tests/random_models.py) through the host path on the numpy double."""
     from tests import random_models as rm
     rm.check(seed, str(tmp_path))
+
+
+@pytest.mark.parametrize("name", ["wide-vtable", "wide128-tied"])
+def test_calibration_on_decoded_paths(fx, fake, monkeypatch, name):
+    """Round 6: Decoder.__init__ decodes a few synthetic sentences of its own lexicon and hands the kept hypotheses' word sequences to
+    DeviceModel.calibrate_on_paths -- one more probe ("paths") beside the seeded word draws; the format decision stands on all of them."""
+    f = fx(name)
+    dec = _decoder(f, "static")
+    m = dec.model.dev
+    kinds = [p["kind"] for p in m.mixed_calib["probes"]]
+    assert kinds.count("paths") == 1 and len(kinds) == len(m.CALIB_PROBES) + 1, kinds
+    assert m.mixed_calib["kept"] and m.mixed_fmt == "mx6" and m.mixed_calib["lse_rms_diff"] == max(p["rms"] for p in m.mixed_calib["probes"])
+    assert dec.perf_sen == 0 and dec.last_lattice is None            # the calibration decode leaves no trace in the decoder's counters
+    # ... and the decode after it is the oracle's
+    sents = synth.make_ragged_sentences(4, 2, 9, seed=5, alphabet=f["alphabet"])
+    o = orc.OracleDecoder(f["root"], 1)
+    for s, g in zip(sents, dec.decode_batch(sents, beam_width=8)):
+        w = o.decode(s, beam_width=8)
+        assert [x for _, x in g] == [x for _, x in w]
+    monkeypatch.setenv("JLM_CALIB_PATHS", "0")
+    dec0 = _decoder(f, "static")
+    assert [p["kind"] for p in dec0.model.dev.mixed_calib["probes"]].count("paths") == 0
