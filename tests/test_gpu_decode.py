@@ -41,12 +41,17 @@ SCORE_ATOL_PER_FRAME = 1.5e-6 if os.environ.get("JLM_PRECISION", "f16x3") == "f3
 SCORE_ATOL_FLOOR = 2e-6
 
 
+SCORE_ATOL_FLAT = 2e-5            # rounds 1-4's flat bar: kept as a cap for inputs of up to 20 kana (round-5 advice: the per-frame formula
+                                  # gives 2.3e-5 at L = 20 -- looser than what those cases were held to before)
+
+
 def score_atol(n_kana):
     """The score bar scales with the path length: a path score is a sum over the L + 1 frames of (log-normaliser - edge logit)
     terms of size ~5..10, each good to ~1e-6 absolute on the f32-grade matrix products (north_star's own bars are 1e-4 relative
     on the step logits and identical 1-best strings).  1e-6 per frame + 2e-6: 2.3e-5 at the headline L = 20 (rounds 1-4 used a
     flat 2e-5), 1.3e-5 at L = 10, 4.3e-5 at L = 40 -- 2e-7 of the scores themselves (~50 / 100 / 230)."""
-    return SCORE_ATOL_PER_FRAME * (n_kana + 1) + SCORE_ATOL_FLOOR
+    bar = SCORE_ATOL_PER_FRAME * (n_kana + 1) + SCORE_ATOL_FLOOR
+    return min(bar, SCORE_ATOL_FLAT) if n_kana <= 20 else bar
 
 
 def _check_nbest(out, gold, tag, n_kana=20):
