@@ -1,7 +1,2 @@
-"""reference train/data.py (Vocab) -> jlm_amd.data"""
-from jlm_amd.data import Vocab  # noqa: F401
-
-
-class CharVocab(Vocab):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("CharVocab / char-RNN is outside the scope of this build (SURVEY.md 8f)")
+"""reference train/data.py (Vocab, CharVocab) -> jlm_amd.data"""
+from jlm_amd.data import Vocab, CharVocab  # noqa: F401

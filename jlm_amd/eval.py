@@ -58,9 +58,11 @@ class Evaluator:
     def __init__(self, args):
         self.args = args
         self.config = _config.load_config_dict(args.experiment_id)
-        if self.config['char_rnn']:
-            raise NotImplementedError("char-RNN models: the reference's CharRNNDecoder cannot run (DESIGN.md 8)")
-        self.vocab = Vocab(self.config['vocab_size'])
+        if self.config['char_rnn']:          # eval.py:35-36
+            from .data import CharVocab
+            self.vocab = CharVocab(self.config['vocab_size'])
+        else:
+            self.vocab = Vocab(self.config['vocab_size'])
         self.w2i = self.vocab.w2i
         self.decoder = self._make_decoder()
         if hasattr(self.decoder, "perf_timing"):
@@ -71,6 +73,9 @@ class Evaluator:
         if a.use_ngram:
             from .decoder_ngram import NGramDecoder
             return NGramDecoder(experiment_id=a.experiment_id, ngram_order=a.ngram_order)
+        if self.config['char_rnn']:
+            from .decoder_char import CharRNNDecoder
+            return CharRNNDecoder(experiment_id=a.experiment_id, comp=a.comp)
         if a.dynamic_decoding:
             from .decoder_dynamic import DynamicDecoder
             return DynamicDecoder(experiment_id=a.experiment_id, comp=a.comp)

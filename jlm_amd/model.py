@@ -944,6 +944,30 @@ class LSTM_Model():
         pred_np = pred[:, :n_cols].double().cpu().numpy()
         return pred_np, y_np, ev0.seconds_to(ev1), ev1.seconds_to(ev2)
 
+    def step_resident(self, h_pool, c_pool, prev, word, h_out, c_out, timing=False):
+        """predict() with the state staying in HBM: rows ``prev`` of the device tensors ``h_pool`` / ``c_pool`` step over ``word``
+        (device int32 tensors, one entry per row) into rows 0.. of ``h_out`` / ``c_out`` (device tensors, or row slices of the
+        pools past every row read), full-vocabulary softmax of the new rows -> (pred [n, ld] f32 on the device, number of
+        columns, (t_lstm, t_softmax) | None).  Same three launches as predict(): jlm_lstm_step, jlm_gemm_nt per segment,
+        jlm_softmax_rows (model.py:125-139, 141-193, 15-20 / 112-115)."""
+        torch = self.dev.torch
+        d = self.dev
+        n = int(prev.numel())
+        with d._ctx():
+            ev = [_Stamp(torch, self.device) for _ in range(3)] if timing else None
+            if ev:
+                ev[0].record()
+            d.lstm_step(h_pool, c_pool, h_out, c_out, prev, word, n)
+            if ev:
+                ev[1].record()
+            y, n_cols = self._project_dev(h_out, n, None)
+            pred = torch.empty_like(y)
+            _ops.backend().softmax_rows(y, pred, y.shape[1], n, n_cols, bool(self.config['self_norm']))
+            if ev:
+                ev[2].record()
+                _sync(torch, self.device)
+        return pred, n_cols, ((ev[0].seconds_to(ev[1]), ev[1].seconds_to(ev[2])) if ev else None)
+
     def project(self, hidden, vocab=None):
         hid = np.asarray(hidden, dtype=np.float64)
         if hid.ndim == 1:

@@ -32,19 +32,27 @@ READING_LEN_P = (0.05, 0.30, 0.40, 0.25)
 README_SEGS = [(200, 0, 12000), (100, 12000, 30000), (50, 30000, None)]
 
 
-def make_lexicon(vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
+def make_lexicon(vocab_size, seed=1234, oov_frac=0.1, alphabet=80, display_alphabet=0):
     """-> (lexicon, reading_dict).  ``<eos>`` is the most frequent entry; the
     first ``vocab_size-1`` entries are in-vocabulary, the ``oov_frac`` tail is
-    not (exercises the skip at reference decoder/decoder.py:99-103)."""
+    not (exercises the skip at reference decoder/decoder.py:99-103).
+    ``display_alphabet`` > 0 (the character-model fixtures): the display string of a word is 1-3 characters of that many CJK code
+    points (frequent ones more often), so that a character vocabulary (reference train/data.py:28-47) is worth a softmax and several
+    words of a reading share a display string (the ``word_set`` dedup at decoder.py:116-122); 0: ``w<i>`` as before."""
     rng = np.random.RandomState(seed)
     n_words = int(round(vocab_size * (1.0 + oov_frac)))
     lens = rng.choice([1, 2, 3, 4], size=n_words, p=READING_LEN_P)
     chars = rng.randint(0, alphabet, size=(n_words, 4))
     top = n_words + 10
     lexicon = [("<eos>", top + 1)]
+    if display_alphabet:
+        rng2 = np.random.RandomState(seed + 4321)          # a stream of its own: the readings stay those of the word fixtures
+        dlens = rng2.choice([1, 2, 3], size=n_words, p=(0.3, 0.45, 0.25))
+        dchars = np.minimum((rng2.rand(n_words, 3) ** 4 * display_alphabet).astype(int), display_alphabet - 1)
     for i in range(n_words):
         reading = "".join(KANA[c] for c in chars[i, : lens[i]])
-        lexicon.append(("w%d/%s/N" % (i, reading), top - i))
+        disp = "".join(chr(0x4E00 + c) for c in dchars[i, : dlens[i]]) if display_alphabet else "w%d" % i
+        lexicon.append(("%s/%s/N" % (disp, reading), top - i))
     reading_dict = {}
     for i, (word, _) in enumerate(lexicon):
         tokens = word.split("/")
@@ -55,8 +63,19 @@ def make_lexicon(vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
     return lexicon, reading_dict
 
 
-def write_lexicon(root, vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
-    lexicon, reading_dict = make_lexicon(vocab_size, seed, oov_frac, alphabet)
+def char_index(lexicon, vocab_size):
+    """character -> index over the in-vocabulary words' display strings, as the reference's CharVocab builds it (train/data.py:28-40):
+    ``<unk>`` 0, ``<eos>`` 1, then first occurrence order over Vocab.lexicon[2:]"""
+    c2i = {"<unk>": 0, "<eos>": 1}
+    for word, _f in ([("<unk>", 0)] + list(lexicon[: vocab_size - 1]))[2:]:
+        for c in word.split("/")[0]:
+            if c not in c2i:
+                c2i[c] = len(c2i)
+    return c2i
+
+
+def write_lexicon(root, vocab_size, seed=1234, oov_frac=0.1, alphabet=80, display_alphabet=0):
+    lexicon, reading_dict = make_lexicon(vocab_size, seed, oov_frac, alphabet, display_alphabet)
     d = os.path.join(root, "data")
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "lexicon.pkl"), "wb") as f:
@@ -66,8 +85,9 @@ def write_lexicon(root, vocab_size, seed=1234, oov_frac=0.1, alphabet=80):
     return lexicon, reading_dict
 
 
-def make_config(vocab_size, hidden, embed, mode="tied", segs=None, self_norm=False):
-    """config.json content.  ``mode``: tied | untied | dsoftmax | vtable."""
+def make_config(vocab_size, hidden, embed, mode="tied", segs=None, self_norm=False, char_rnn=False):
+    """config.json content.  ``mode``: tied | untied | dsoftmax | vtable.  ``char_rnn``: the model's softmax runs over characters
+    (``vocab_size`` stays the WORD vocabulary's size: reference train/model.py:95-96, decoder/eval.py:35-36)."""
     assert mode in ("tied", "untied", "dsoftmax", "vtable")
     cfg = {
         "vocab_size": int(vocab_size),
@@ -78,20 +98,21 @@ def make_config(vocab_size, hidden, embed, mode="tied", segs=None, self_norm=Fal
         "V_table": mode == "vtable",
         "embedding_seg": [list(s) for s in (segs if segs is not None else README_SEGS)],
         "self_norm": bool(self_norm),
-        "char_rnn": False,
+        "char_rnn": bool(char_rnn),
     }
     return cfg
 
 
-def make_weights(cfg, seed=7, scale=0.05):
+def make_weights(cfg, seed=7, scale=0.05, n_out=None):
     """Weight dict with the key names / shapes of reference train/weights.py:30-55
-    (shapes from reference train/model.py:137-150,188-193,57-60)."""
+    (shapes from reference train/model.py:137-150,188-193,57-60).  ``n_out``: rows of the softmax when it is not the word
+    vocabulary (character models: len(CharVocab))."""
     rng = np.random.RandomState(seed)
 
     def w(*shape):
         return rng.normal(0.0, scale, size=shape).astype(np.float32)
 
-    V, H = cfg["vocab_size"], cfg["hidden_size"]
+    V, H = (cfg["vocab_size"] if n_out is None else int(n_out)), cfg["hidden_size"]
     segs = cfg["embedding_seg"]
     if cfg["V_table"]:
         E = segs[0][0]                       # reference train/model.py:53
@@ -175,12 +196,12 @@ def shape_weights(weights, cfg, shape, seed=7):
     return weights
 
 
-def write_experiment(root, exp_id, cfg, seed=7, scale=0.05, shape=None):
+def write_experiment(root, exp_id, cfg, seed=7, scale=0.05, shape=None, n_out=None):
     d = os.path.join(root, "train", "experiments", str(exp_id))
     os.makedirs(os.path.join(d, "weights"), exist_ok=True)
     with open(os.path.join(d, "config.json"), "wt") as f:
         f.write(json.dumps(cfg))
-    weights = shape_weights(make_weights(cfg, seed, scale), cfg, shape, seed)
+    weights = shape_weights(make_weights(cfg, seed, scale, n_out), cfg, shape, seed)
     with open(os.path.join(d, "weights", "lstm_weights.pkl"), "wb") as f:
         pickle.dump(weights, f)
     return weights
@@ -281,6 +302,8 @@ def build_fixture(root, name, exp_id=1):
     that their 2 200-word lexicon still gives a dense lattice.  Names:
 
       small-{tied,untied,dsoftmax,vtable}[-sn]   V=2000 H=64 E=32 (unit tests)
+      small-char / mid-char                       character models (config char_rnn): tied softmax over the characters of the
+                                                  in-vocabulary words' display strings (300 / 3 000 CJK code points), same lexicon sizes
       wide-{vtable,dsoftmax}                      V=2000 H=64, segments 200 / 100 / 50 (the mixed-row shapes, small vocabulary)
       wideh-vtable                                 the same with 200 / 100 / 36: the hybrid launch (mixed + split rows)
       wide128-tied                                 tied, E = 128: mixed rows without bias columns (the form of the tied k = 256 models)
@@ -295,6 +318,9 @@ def build_fixture(root, name, exp_id=1):
     size, mode = parts[0], parts[1]
     self_norm = len(parts) > 2 and parts[2] == "sn"
     alphabet, scale, shape = 80, 0.05, None
+    display_alphabet = 0
+    if mode == "char":                    # a character model (tied softmax over CharVocab) decoded on the word lattice
+        mode, display_alphabet = "tied", {"small": 300, "mid": 3000}[size]
     if size in ("peaked", "peaked20", "heavy"):
         shape, size = size, "mid"
     elif size == "bigpeaked":             # config 3's model (V = 100 k) with the peaked statistics
@@ -317,9 +343,10 @@ def build_fixture(root, name, exp_id=1):
         V, H, E, segs = 100000, 512, 256, README_SEGS
     else:
         raise ValueError(name)
-    cfg = make_config(V, H, E, mode, segs, self_norm)
-    lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet)
-    write_experiment(root, exp_id, cfg, scale=scale, shape=shape)
+    cfg = make_config(V, H, E, mode, segs, self_norm, char_rnn=bool(display_alphabet))
+    lexicon, reading_dict = write_lexicon(root, V, alphabet=alphabet, display_alphabet=display_alphabet)
+    n_out = len(char_index(lexicon, V)) if display_alphabet else None
+    write_experiment(root, exp_id, cfg, scale=scale, shape=shape, n_out=n_out)
     if size == "small":
         write_arpa(root, lexicon, V)      # the n-gram baseline's model file (decoder/model_ngram.py reads data/lm3)
     return cfg, lexicon, reading_dict, alphabet

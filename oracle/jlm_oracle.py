@@ -27,8 +27,17 @@ Structure (array based, not the reference's Path/Node objects):
   dynamic_vocab        <- DynamicDecoder._build_lattice_vocab    (decoder_dynamic.py:30-46)
   dynamic_decode       <- DynamicDecoder.decode/_build_current_frame/
                           _incremental_decode/_fix_neg_log        (decoder_dynamic.py:49-194)
-  OracleDecoder / OracleDynamicDecoder : file-loading wrappers with the
+  build_char_lattice   <- Decoder._build_lattice, config['char_rnn'] branch (decoder.py:105-124)
+  char_decode          <- CharRNNDecoder.decode/_build_current_frame/_eval_frame (decoder.py:273-341)
+  OracleDecoder / OracleDynamicDecoder / OracleCharRNNDecoder : file-loading wrappers with the
                           reference's class signatures (decoder.py:54-77).
+
+PARITY UNPINNED for the character decoder: the reference's CharRNNDecoder cannot run as
+shipped (its _check_oov reads ``self.vocab.words``, decoder.py:263-264, which no Vocab defines, and
+Decoder._load_vocab gives it the WORD index where its character steps need CharVocab.c2i).  Its
+golden vectors come from the reference class with ONE method supplied at run time by a subclass
+inside tools/make_golden.py (``_load_vocab``: CharVocab, ``vocab.words`` = the word index,
+``w2i`` = ``c2i``) -- the evidently intended wiring, every other statement the reference's own.
 """
 import json
 import math
@@ -362,6 +371,100 @@ def dynamic_decode(lm, ends, lv, beam_width=10, topN=10, perf=None, trace=None):
     return out[:topN]
 
 
+# ------------------------------------------------------- character-model decode
+def build_char_lattice(text, lexicon, reading_dict, words, c2i):
+    """reference decoder.py:79-135 with config['char_rnn'] (:105-124): the word lattice, a node per distinct DISPLAY string of a
+    (start, reading) -- at most 201 of them, in sorted lexicon-id order -- indexed by its first character.
+    -> ends[f] = [(start, reading_len, first_char_idx, display)]"""
+    L = len(text)
+    ends = [[] for _ in range(L + 1)]
+    ends[0].append((-1, 1, c2i["<eos>"], "<eos>"))
+    for i in range(L):
+        for j in range(L - i):
+            sub = text[i:i + j + 1]
+            if sub in reading_dict:
+                seen = set()
+                for lex_id in sorted(reading_dict[sub]):
+                    word = lexicon[lex_id][0]
+                    if word not in words:
+                        continue                                   # decoder.py:99-103
+                    disp = word.split("/")[0]
+                    if sum(c not in c2i for c in disp):            # _char_check_oov, decoder.py:266-267
+                        continue
+                    if disp in seen or len(seen) > 200:            # decoder.py:116-120
+                        continue
+                    seen.add(disp)
+                    ends[i + j + 1].append((i, j + 1, c2i[disp[0]], disp))
+            if len(ends[i + 1]) == 0:                              # decoder.py:128-130
+                ends[i + 1].append((i, 1, c2i["<unk>"], text[i]))
+    return ends
+
+
+class _CharPath:
+    __slots__ = ("score", "words", "text", "h", "c", "prob", "idx", "step", "start")
+
+
+def _char_word_length(word):
+    """decoder.py:269-273"""
+    return 1 if word in ("<eos>", "<unk>") else len(word)
+
+
+def char_decode(lm, ends, c2i, beam_width=10, topN=10, perf=None, trace=None):
+    """reference decoder.py:276-341: a frame's candidates are (node, kept path of the node's start frame) pairs whose concatenated
+    display strings are new (FIRST occurrence wins, :289-294), scored with the first character from the path's stored distribution
+    (:285-287, Path.append_node :43-49); words of several characters then run one LSTM step + softmax per further character, all
+    candidates still short of their word's end batched together (_eval_frame, :300-320); stable sort, cut (:330-332); one more step
+    on the last character of the survivors (:334).  ``trace``: per frame (scores, (start, word_idx, #nodes))."""
+    L = len(ends) - 1
+    frames = []
+
+    def step(batch):
+        h = np.concatenate([p.h for p in batch], axis=0)
+        c = np.concatenate([p.c for p in batch], axis=0)
+        pred, _y, h, c, t1, t2 = lm.predict([p.idx for p in batch], h, c, None)      # _batch_predict, decoder.py:202-218
+        if perf is not None:
+            perf[0].append(t1)
+            perf[1].append(t2)
+        for k, p in enumerate(batch):
+            p.h, p.c, p.prob = h[k][None], c[k][None], pred[k]
+
+    for i in range(L + 1):
+        paths = []
+        if i == 0:
+            p = _CharPath()
+            p.score, p.words, p.text, p.prob, p.idx, p.step, p.start = 0.0, ["<eos>"], "<eos>", None, ends[0][0][2], 0, -1
+            p.h, p.c = lm.zero_state(1)
+            paths.append(p)
+        else:
+            seen = set()
+            for (start, _ln, idx, word) in ends[i]:
+                for pp in frames[start]:
+                    text = pp.text + word
+                    if text in seen:
+                        continue
+                    seen.add(text)
+                    p = _CharPath()
+                    p.score = pp.score + (-math.log(pp.prob[idx]))
+                    p.words, p.text, p.h, p.c, p.prob, p.idx, p.step, p.start = pp.words + [word], text, pp.h, pp.c, pp.prob, idx, 0, start
+                    paths.append(p)
+        batch = [p for p in paths if p.step + 1 < _char_word_length(p.words[-1])]
+        while batch:                                               # the recursion of _eval_frame, :300-320
+            step(batch)
+            for p in batch:
+                p.step += 1
+                p.idx = c2i[p.words[-1][p.step]]
+                p.score += -np.log(p.prob[p.idx])
+            batch = [p for p in batch if p.step + 1 < _char_word_length(p.words[-1])]
+        if beam_width is not None:
+            paths.sort(key=lambda p: p.score)
+            paths = paths[:beam_width]
+        step(paths)
+        frames.append(paths)
+        if trace is not None:
+            trace.append(([p.score for p in paths], [(p.start, p.idx, len(p.words)) for p in paths]))
+    return [(p.score, [w for w in p.words if w != "<eos>"]) for p in frames[L]][:topN]
+
+
 # ------------------------------------------------------------- file-level API
 class OracleDecoder:
     """File-loading wrapper with the reference's signatures (decoder.py:54-77,
@@ -415,3 +518,34 @@ class OracleDecoder:
 
 class OracleDynamicDecoder(OracleDecoder):
     dynamic = True
+
+
+class OracleCharRNNDecoder(OracleDecoder):
+    """reference decoder.py:244-341 as evidently intended (module docstring: parity unpinned): the word index decides what is in
+    the vocabulary, CharVocab's character index (train/data.py:28-47) what the model steps over."""
+
+    def __init__(self, root, experiment_id=0, comp=0):
+        super(OracleCharRNNDecoder, self).__init__(root, experiment_id, comp)
+        self.words = self.w2i
+        lex = [("<unk>", 0)] + self.full_lexicon[: self.config["vocab_size"] - 1]
+        c2i = {"<unk>": 0, "<eos>": 1}
+        for item in lex[2:]:
+            for ch in item[0].split("/")[0]:
+                if ch not in c2i:
+                    c2i[ch] = len(c2i)
+        self.w2i = c2i
+        self.i2w = {v: k for k, v in c2i.items()}
+
+    def _check_oov(self, word):
+        return word not in self.words
+
+    def decode(self, input, topN=10, beam_width=10, vocab_select=False, samples=0,
+               top_sampling=False, random_sampling=False):
+        ends = build_char_lattice(input, self.full_lexicon, self.full_reading_dict, self.words, self.w2i)
+        self.backward_lookup = ends
+        if vocab_select:                # decoder.py:132-133: the list is built and never read by this class
+            self.lattice_vocab = static_vocab(ends, samples, top_sampling, random_sampling, len(self.w2i))
+        self.last_trace = []
+        out = char_decode(self.model, ends, self.w2i, beam_width, topN, (self.perf_log_lstm, self.perf_log_softmax), self.last_trace)
+        self.perf_sen += 1
+        return out

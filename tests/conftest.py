@@ -63,3 +63,9 @@ def golden_lm():
 def golden_eval():
     with open(os.path.join(GOLD, "eval.json"), "r", encoding="utf-8") as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_char():
+    with open(os.path.join(GOLD, "char.json"), "r", encoding="utf-8") as f:
+        return json.load(f)

@@ -92,6 +92,22 @@ DECODE_CASES = [
     ("bigpeaked-tied/static-b20", "bigpeaked-tied", "static", dict(beam_width=20), ("fixed", 8, 20, 78)),
 ]
 
+# Character models on the word lattice (reference CharRNNDecoder, decoder.py:244-341, with the one run-time wiring of
+# tools/make_golden.py: parity unpinned): (case name, fixture, decode kwargs, sentence spec)
+CHAR_CASES = [
+    ("small-char/char", "small-char", dict(beam_width=10), ("ragged", 12, 1, 20, 3)),
+    ("small-char/char-b3", "small-char", dict(beam_width=3, topN=5), ("ragged", 8, 1, 16, 4)),
+    ("small-char/char-vs-top", "small-char", dict(beam_width=10, vocab_select=True, samples=20, top_sampling=True), ("ragged", 4, 2, 12, 5)),
+    ("small-char/char-unpruned", "small-char", dict(beam_width=None, topN=50), ("ragged", 6, 1, 3, 11)),
+    ("mid-char/char", "mid-char", dict(beam_width=10), ("fixed", 16, 20, 77)),
+]
+
+
+# ... and the reference's eval.py, unchanged, on the character fixture (decoder.CharRNNDecoder._load_vocab set at run time,
+# tools/make_golden.py): decoder selection by config['char_rnn'] (eval.py:43-44), CharVocab for the eval set (eval.py:35-36)
+CHAR_EVAL_CASE = ("small-char/eval-char", "small-char", ["-e", "1", "-es", "12", "-b", "10"])
+
+
 def is_quirk_case(name):
     """cases that need ``compat_quirks = True`` on the jlm_amd decoder"""
     return name.split("/")[1].startswith("dynamic-quirk")

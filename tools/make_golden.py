@@ -10,8 +10,10 @@ jlm_amd/synth.py), expected outputs go to tests/golden/:
                     frame beams, read from the reference's Path objects)
   eval.json         decoder/eval.py run unchanged via runpy: hit counts and log
   ngram.json        NGramDecoder.decode n-best lists, NGramModel.evaluate, eval.py -ng
+  char.json         CharRNNDecoder.decode n-best lists (+ per frame beams): the reference's class with ONE method supplied
+                    at run time (it cannot run as shipped; gen_char below)
 
-Usage:  python tools/make_golden.py [--only lm|decode|eval|ngram] [--filter substr]
+Usage:  python tools/make_golden.py [--only lm|decode|eval|ngram|char] [--filter substr]
 """
 import argparse
 import contextlib
@@ -247,6 +249,68 @@ def gen_ngram():
         json.dump(results, f, ensure_ascii=False, indent=0)
 
 
+def gen_char():
+    """The reference's CharRNNDecoder (decoder/decoder.py:244-341) dies on its first lattice look-up: ``_check_oov`` reads
+    ``self.vocab.words`` (:263-264), which no Vocab defines, and ``Decoder._load_vocab`` (:70-73) gives it the word index where its
+    character steps need ``CharVocab.c2i``.  Nothing of the reference is edited or copied: a subclass created HERE, at run time,
+    supplies ``_load_vocab`` -- ``vocab`` a CharVocab, ``vocab.words`` its word index, ``w2i`` / ``i2w`` its character index -- and
+    every other statement that runs is the reference's own."""
+    results = {}
+    for name, fx, kwargs, spec in gc.CHAR_CASES:
+        root = fixture_root(fx)
+        _model, decoder, _dd = import_reference(root)
+        from train.data import CharVocab
+
+        class Wired(decoder.CharRNNDecoder):
+            def _load_vocab(self):
+                self.vocab = CharVocab(self.config['vocab_size'])
+                self.vocab.words = self.vocab.w2i
+                self.w2i = self.vocab.c2i
+                self.i2w = self.vocab.i2c
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            dec = Wired(1)
+        store = {}
+        orig = dec._build_current_frame
+
+        def wrapped(nodes, frame, idx, _orig=orig, _store=store):
+            _store["frame"] = frame
+            return _orig(nodes, frame, idx)
+
+        dec._build_current_frame = wrapped
+        sents = gc.case_sentences(spec, _alpha[fx])
+        t0 = time.time()
+        case = []
+        for si, s in enumerate(sents):
+            res = dec.decode(s, **kwargs)
+            item = {"input": s, "nbest": [[float(sc), list(ws)] for sc, ws in res]}
+            if si < gc.TRACE_SENTENCES:
+                item["trace"] = [_snap(store["frame"][i]) for i in range(len(s) + 1)]
+            case.append(item)
+        results[name] = case
+        print("char", name, len(sents), "sentences %.1fs" % (time.time() - t0), "best", case[0]["nbest"][0][0])
+    # eval.py run unchanged; the class it imports (eval.py:7) carries the same ``_load_vocab``, set as an attribute at run time
+    name, fx, argv = gc.CHAR_EVAL_CASE
+    root = fixture_root(fx)
+    cfg, lexicon, _rd, _al = synth.build_fixture(root, fx)
+    synth.write_test_corpus(root, lexicon, cfg["vocab_size"], **gc.EVAL_CORPUS)
+    _model, decoder, _dd = import_reference(root)
+    from train.data import CharVocab
+
+    def _load_vocab(self):
+        self.vocab = CharVocab(self.config['vocab_size'])
+        self.vocab.words = self.vocab.w2i
+        self.w2i = self.vocab.c2i
+        self.i2w = self.vocab.i2c
+
+    # (a subclass under the module's name would recurse in the class's own super() call: the METHOD is set on the class instead)
+    decoder.CharRNNDecoder._load_vocab = _load_vocab
+    results[name] = _run_reference_eval(root, argv)
+    print("char eval", results[name]["stdout_hits"])
+    with open(os.path.join(GOLD, "char.json"), "w", encoding="utf-8") as f:
+        json.dump(results, f, ensure_ascii=False, indent=0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -261,3 +325,5 @@ if __name__ == "__main__":
         gen_eval()
     if a.only in (None, "ngram"):
         gen_ngram()
+    if a.only in (None, "char"):
+        gen_char()
