@@ -58,7 +58,7 @@ def kernel_source_sha256():
 def gate_source_sha256():
     """Identity of the LSTM-step kernel the committed PMC traffic figure was measured on"""
     h = hashlib.sha256()
-    for f in ("jlm_gate.hip", "jlm_gate_ws.hip", "jlm_gate.h", "jlm_common.h"):
+    for f in ("jlm_gate.hip", "jlm_gate_ws.hip", "jlm_gate_p2.hip", "jlm_gate.h", "jlm_common.h"):
         with open(os.path.join(REPO, "jlm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

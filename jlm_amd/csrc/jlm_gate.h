@@ -34,4 +34,6 @@ __device__ __forceinline__ void gate_for_each_ic(F &&f, std::integer_sequence<in
 namespace jlm_gate {
 // gate_ws_kernel<L, HF32> on tiles_n * Q workgroups (jlm_gate_ws.hip); L = ring stages ahead (3 or 7).  0, a hipError_t or -3.
 int ws_launch(const GateXgArgs &a, int L, int Q, hipStream_t stream);
+// gate_p2_kernel (jlm_gate_p2.hip): 128 x 256 tiles, a 2 x 2 register block per wave, persistent; H = 512 with a row list, no f32 copy of h'.
+int p2_launch(const GateXgArgs &a, hipStream_t stream);
 }

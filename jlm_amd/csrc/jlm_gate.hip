@@ -1112,7 +1112,10 @@ extern "C" int jlm_lstm_step_xg(const void *h_in, const float *c_in, int ld_stat
     static const int variant_env = getenv("JLM_GATE_V") ? atoi(getenv("JLM_GATE_V")) : -1;
     const int variant = variant_env >= 1 ? variant_env : (n_rows_max >= 16384 ? 2 : n_rows_max >= 4096 ? 3 : 1);
     static const int ws_l = getenv("JLM_GATE_WS_L") ? atoi(getenv("JLM_GATE_WS_L")) : 3;
-    if (variant == 3 && H == 512 && rows && (a.tiles_n & 7) == 0) {
+    if (variant == 4 && H == 512 && rows && !h_f32_out) {
+        // round 6: 128 x 256 tiles, a 2 x 2 register block per wave, persistent (csrc/jlm_gate_p2.hip)
+        if (int rc = jlm_gate::p2_launch(a, (hipStream_t)stream)) return rc;
+    } else if (variant == 3 && H == 512 && rows && (a.tiles_n & 7) == 0) {
         // the persistent form of the one-tile kernel (gate_pu_kernel): tiles_n column tiles x Q row-tile sequences
         const int per_col = 256 / a.tiles_n;
         const int Q = a.tiles_m < per_col ? a.tiles_m : per_col;

@@ -56,17 +56,27 @@ constexpr int WS_NK = 16;                                 // k-steps (H = 512)
 #define WS_ABL 0      // measurement builds (results wrong): 1 no LDS-DMA in the k-steps, 2 no fragment reads in the k-steps, 4 no MFMAs, 8 no barrier
 #endif
 constexpr int WS_ST = 3;                                  // stores per hypothesis block and lane that every launch issues (c, h hi, h lo)
+// Round 6: the cell update took 5.3-5.8 us of an 18-us tile with ~730 VALU instructions in it (profiles/r04_a_gate_ws_ablate.txt): the
+// operands of blocks 2..4 (table line, old cell state) are requested one block ahead, two in flight -- three exposed round trips to HBM /
+// the fabric.  The registers for five blocks in flight are not there (W 256 + 250 of 256), so the LINES are warmed instead: at k-step
+// WS_PF every lane touches one dword of each block's table line and cell-state line (10 loads into one dummy register, kept alive up to
+// the first counted wait behind them); the epilogue's own loads then hit the XCD's L2.  -DWS_PF=-1: off (A/B builds).
+#ifndef WS_PF
+#define WS_PF -1
+#endif
+constexpr int WS_NPF = 2 * WS_NB;                         // the warming loads of a tile
 
 // ---- the issue order of a tile's vector-memory operations, and the counted waits that follow from it ----
 // k-step j issues, in this order:  D  the 5 pieces of stage j + L (of the next tile from j = 16 - L on);
 //                                  X  the tile's extra loads: j = 0 row ids of the epilogue (5; first tile: in the prologue),
 //                                     j = 1 row ids of the next tile's pieces (5), j = 3 prev / word of the epilogue rows (10; first
-//                                     tile: prologue), j = 4 prev of the next tile's piece rows (5), j = 14 / 15 the epilogue operands
-//                                     of blocks 0 / 1 (5 each);
+//                                     tile: prologue), j = 4 prev of the next tile's piece rows (5), j = WS_PF the warming loads (10),
+//                                     j = 14 / 15 the epilogue operands of blocks 0 / 1 (5 each);
 //                                  W  first tile only: the 4 gate-matrix loads of k-step j + L + 1 (while there is one).
 constexpr int ws_x(bool first, int j) {
-    return j == 0 ? (first ? 0 : 5) : j == 1 ? 5 : j == 3 ? (first ? 0 : 10) : j == 4 ? 5 : (j == 14 || j == 15) ? 5 : 0;
+    return (j == 0 ? (first ? 0 : 5) : j == 1 ? 5 : j == 3 ? (first ? 0 : 10) : j == 4 ? 5 : (j == 14 || j == 15) ? 5 : 0) + (j == WS_PF ? WS_NPF : 0);
 }
+static_assert(WS_PF < 0 || (WS_PF > 4 && WS_PF < 14), "the warming loads need prev / word of the epilogue rows (X of k-step 3)");
 constexpr int ws_w(bool first, int L, int j) { return (first && j + L + 1 < WS_NK) ? 4 : 0; }
 constexpr int ws_issued(bool first, int L, int j) { return WS_NP + ws_x(first, j) + ws_w(first, L, j); }
 constexpr int ws_sum(bool first, int L, int j0, int j1) {      // operations issued by k-steps j0 .. j1 - 1
@@ -87,8 +97,9 @@ constexpr int ws_wait_eg(int L) { return ws_clamp(ws_w(false, L, 0) + ws_sum(fal
 constexpr int ws_wait_rn(bool first, int L) { return ws_clamp(ws_w(first, L, 1) + ws_sum(first, L, 2, 4) + WS_NP); }
 // in front of D of k-step 16 - L: prev of the next tile's piece rows (X of k-step 4)
 constexpr int ws_wait_ppn(bool first, int L) { return ws_clamp(ws_w(first, L, 4) + ws_sum(first, L, 5, WS_NK - L)); }
-// behind D of k-step 14: prev / word of the epilogue rows (X of k-step 3; first tile: prologue)
-constexpr int ws_wait_epew(int L) { return ws_clamp(ws_w(false, L, 3) + ws_sum(false, L, 4, 14) + WS_NP); }
+// behind D of k-step WS_PF (14 without the warming loads): prev / word of the epilogue rows (X of k-step 3; first tile: prologue)
+constexpr int WS_EPEW_AT = WS_PF >= 0 ? WS_PF : 14;
+constexpr int ws_wait_epew(int L) { return ws_clamp(ws_w(false, L, 3) + ws_sum(false, L, 4, WS_EPEW_AT) + WS_NP); }
 static_assert(ws_top(false, 7, 8) == 40 && ws_top(false, 7, 3) == 63 && ws_top(true, 7, 0) == 49 && ws_wait_eg(7) == 20, "issue-order bookkeeping");
 
 // (a struct with member templates, not lambdas: clang rejects inline-asm operands that name captured locals inside a GENERIC lambda)
@@ -114,6 +125,7 @@ struct GateWs {
     f32x16 acc[WS_NB];
     f16x8 B[WS_NB][2];                                    // fragments of ONE half step, refilled in place (plane 0 hi, 1 lo)
     f32x4 xg[2][4], cp[2];                                // epilogue operands, two blocks in flight
+    int warm;                                             // destination of the warming loads (never read)
 
     __device__ __forceinline__ GateWs(const GateXgArgs &a_, float *smem_) : a(a_), smem(smem_) {}
 
@@ -158,6 +170,9 @@ struct GateWs {
     }
     template <int N>
     __device__ __forceinline__ void wait_int(int &v) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+    // a warming load: one dword of a line into `warm`, read-write so that all of them live in ONE register that stays allocated until
+    // the counted wait of cell<0> (an output-only operand would be dead at once and its register handed out under the load in flight)
+    __device__ __forceinline__ void touch_line(const float *src) { asm volatile("global_load_dword %0, %1, off" : "+v"(warm) : "v"(src) : "memory"); }
     __device__ __forceinline__ void load_int(int &dst, const int *src) { asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(src) : "memory"); }
     template <bool FIRST, int KT>
     __device__ __forceinline__ void top() {               // stage KT + 1 landed (this wave's pieces), every wave through k-step KT - 1
@@ -252,13 +267,18 @@ struct GateWs {
 #pragma unroll
             for (int i = 0; i < WS_NP; ++i) load_int(rn[i], a.prev + rn[i]);
         }
-        if constexpr (KT == 14) {
-            if constexpr (!FIRST) {
+        if constexpr (KT == WS_EPEW_AT && !FIRST) {
 #pragma unroll
-                for (int nb = 0; nb < WS_NB; ++nb) { wait_int<ws_wait_epew(L)>(ep[nb]); wait_int<ws_wait_epew(L)>(ew[nb]); }
-            }
-            load_ops(0, 0);
+            for (int nb = 0; nb < WS_NB; ++nb) { wait_int<ws_wait_epew(L)>(ep[nb]); wait_int<ws_wait_epew(L)>(ew[nb]); }
         }
+        if constexpr (KT == WS_PF) {
+#pragma unroll
+            for (int nb = 0; nb < WS_NB; ++nb) {
+                touch_line(a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * wave + 4 * hf);
+                touch_line(a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0);
+            }
+        }
+        if constexpr (KT == 14) load_ops(0, 0);
         if constexpr (KT == 15) load_ops(1, 1);
         if constexpr (FIRST && KT + L + 1 < WS_NK) load_w<(KT + L + 1) & (WS_NK - 1)>();
         __builtin_amdgcn_sched_barrier(0);
@@ -273,6 +293,7 @@ struct GateWs {
         // younger than this block's operands: the next block's (5), and what was issued between them (stores, the block after)
         constexpr int younger = NBK == 0 ? 10 : NBK == 1 ? 5 + WS_ST : NBK == 4 ? 2 * WS_ST : 2 * WS_ST + 5;
         wait_ops<younger>(sl);
+        if constexpr (NBK == 0 && WS_PF >= 0) asm volatile("" : "+v"(warm));        // (in-order returns: the warming loads are older)
         f32x4 xq[4], cq;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[sl][g4];
@@ -318,6 +339,7 @@ struct GateWs {
 
     __device__ __forceinline__ void run() {
         JLM_WS_T(0);
+        warm = 0;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);            // = the wave's gate block
         li = lane & 31; hf = lane >> 5;

@@ -126,6 +126,20 @@ def _pack(L, src_g, k, scale, ld_dst=None, dst=None, col0=0, src_col0=0):
     return dst
 
 
+@pytest.mark.parametrize("variant", ["2", "3", "4"])
+def test_lstm_step_xg_forced_forms(variant):
+    """Every H = 512 form of the LSTM step on every row count of test_lstm_step_xg, whatever the launcher would pick by the row bound:
+    JLM_GATE_V = 2 (W-stationary), 3 (persistent 160 x 128), 4 (persistent 128 x 256, a 2 x 2 register block per wave: csrc/jlm_gate_p2.hip;
+    its tiles: first / middle / last of a sequence at 5 200 and 20 480 rows, a ragged last tile, a single row).  The variable is read once
+    per process, hence the child."""
+    import os, subprocess, sys
+    env = dict(os.environ, JLM_GATE_V=variant)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_lstm_step_xg and not forced"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
+
+
 @pytest.mark.parametrize("H,R,use_rows", [(64, 10, False), (64, 200, True), (512, 700, True), (512, 2560, True), (128, 161, True),
                                          (512, 159, False),
                                          # the W-stationary persistent kernel (H = 512 with a row list): one tile per workgroup at 2 560 rows; two

@@ -7,7 +7,7 @@ TAG=$1; FLAGS=$2; shift 2
 cd "$(dirname "$0")/../jlm_amd/csrc"
 mkdir -p ../../build_prof/$TAG
 OBJS=""
-for s in jlm_gemm jlm_beam jlm_split jlm_gate jlm_mixed jlm_decode jlm_gate_ws jlm_mixed_w jlm_mx6 jlm_mx6w; do
+for s in jlm_gemm jlm_beam jlm_split jlm_gate jlm_gate_p2 jlm_mixed jlm_decode jlm_gate_ws jlm_mixed_w jlm_mx6 jlm_mx6w; do
   if [[ " $* " == *" $s.hip "* ]]; then
     X=""; { [ $s = jlm_gate_ws ] || [ $s = jlm_mixed_w ]; } && X="-mllvm -amdgpu-mfma-vgpr-form"
     [ $s = jlm_mx6 ] && X="-fno-honor-nans -mno-amdgpu-ieee -fno-slp-vectorize"

@@ -269,6 +269,9 @@ def bench_gate_xg(H, R):
     rows = (torch.arange(R, device=dev, dtype=torch.int32) + 2 * R).contiguous()
     prev = torch.randint(0, 2 * R, (G,), device=dev, dtype=torch.int32)
     word = torch.randint(0, V, (G,), device=dev, dtype=torch.int32)
+    if os.environ.get("KBENCH_WORDS") == "zipf":      # word ids drawn ~ 1 / rank (a frequency-sorted lexicon): table lines repeat, as in a decode
+        w = 1.0 / torch.arange(1, V + 1, device=dev, dtype=torch.float64)
+        word = torch.multinomial(w / w.sum(), G, replacement=True).to(torch.int32)
     nd = torch.tensor([R], device=dev, dtype=torch.int32)
     f = lambda: L.jlm_lstm_step_xg(h.data_ptr(), c.data_ptr(), H, h.data_ptr(), c.data_ptr(), rows.data_ptr(), prev.data_ptr(),
                                    word.data_ptr(), wt.data_ptr(), xg.data_ptr(), H, 2.0 ** -20, 2.0 ** 14, None, R, nd.data_ptr(), st)
