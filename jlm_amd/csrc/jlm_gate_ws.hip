@@ -65,6 +65,20 @@ constexpr int WS_ST = 3;                                  // stores per hypothes
 #define WS_PF -1
 #endif
 constexpr int WS_NPF = 2 * WS_NB;                         // the warming loads of a tile
+// Round 6, the epilogue's operands FOUR blocks in flight instead of two (-DWS_OPS4=0: the round-4 form).  With every operand an L2 hit the
+// launch takes 123 instead of 149 us at 20 480 rows (profiles/r06_w_gate_ws_ops.txt): blocks 2..4 were requested one block ahead, a round
+// trip exposed per block.  The ten registers of two more operand sets are the wave's B fragments: the last half step of a tile no longer
+// refills them with the next tile's first fragments (those are read on top of its first k-step, behind the barrier, as in the first
+// tile), so behind the last matrix instruction they take the operands of blocks 2 and 3; block 4 goes into block 0's set behind its use.
+// WS_OPS4 = 1: sets 0 / 1 under k-steps 14 / 15, 2 and 3 behind the last k-step; 2: set 2 under k-step 15 as well; 3: sets 0 / 1 / 2 under k-steps
+// 13 / 14 / 15, 3 behind the last (the compiler finds the registers: no spills in any form -- scratch traffic would break the counted waits).
+#ifndef WS_OPS4
+#define WS_OPS4 1
+#endif
+constexpr int ws_kx(int b) {                              // k-step under which the operands of block b < 4 are requested (16: behind the k-steps)
+    return WS_OPS4 == 3 ? (b < 3 ? 13 + b : 16) : WS_OPS4 == 2 ? (b == 0 ? 14 : b < 3 ? 15 : 16) : WS_OPS4 == 1 ? (b < 2 ? 14 + b : 16) : (b < 2 ? 14 + b : -1);
+}
+constexpr int ws_nops(int j) { int n = 0; for (int b = 0; b < 4; ++b) n += ws_kx(b) == j ? 5 : 0; return n; }
 
 // ---- the issue order of a tile's vector-memory operations, and the counted waits that follow from it ----
 // k-step j issues, in this order:  D  the 5 pieces of stage j + L (of the next tile from j = 16 - L on);
@@ -74,7 +88,7 @@ constexpr int WS_NPF = 2 * WS_NB;                         // the warming loads o
 //                                     j = 14 / 15 the epilogue operands of blocks 0 / 1 (5 each);
 //                                  W  first tile only: the 4 gate-matrix loads of k-step j + L + 1 (while there is one).
 constexpr int ws_x(bool first, int j) {
-    return (j == 0 ? (first ? 0 : 5) : j == 1 ? 5 : j == 3 ? (first ? 0 : 10) : j == 4 ? 5 : (j == 14 || j == 15) ? 5 : 0) + (j == WS_PF ? WS_NPF : 0);
+    return (j == 0 ? (first ? 0 : 5) : j == 1 ? 5 : j == 3 ? (first ? 0 : 10) : j == 4 ? 5 : 0) + ws_nops(j) + (j == WS_PF ? WS_NPF : 0);
 }
 static_assert(WS_PF < 0 || (WS_PF > 4 && WS_PF < 14), "the warming loads need prev / word of the epilogue rows (X of k-step 3)");
 constexpr int ws_w(bool first, int L, int j) { return (first && j + L + 1 < WS_NK) ? 4 : 0; }
@@ -98,7 +112,7 @@ constexpr int ws_wait_rn(bool first, int L) { return ws_clamp(ws_w(first, L, 1) 
 // in front of D of k-step 16 - L: prev of the next tile's piece rows (X of k-step 4)
 constexpr int ws_wait_ppn(bool first, int L) { return ws_clamp(ws_w(first, L, 4) + ws_sum(first, L, 5, WS_NK - L)); }
 // behind D of k-step WS_PF (14 without the warming loads): prev / word of the epilogue rows (X of k-step 3; first tile: prologue)
-constexpr int WS_EPEW_AT = WS_PF >= 0 ? WS_PF : 14;
+constexpr int WS_EPEW_AT = WS_PF >= 0 ? WS_PF : ws_kx(0);
 constexpr int ws_wait_epew(int L) { return ws_clamp(ws_w(false, L, 3) + ws_sum(false, L, 4, WS_EPEW_AT) + WS_NP); }
 static_assert(ws_top(false, 7, 8) == 40 && ws_top(false, 7, 3) == 63 && ws_top(true, 7, 0) == 49 && ws_wait_eg(7) == 20, "issue-order bookkeeping");
 
@@ -154,8 +168,8 @@ struct GateWs {
     }
     // one 128-byte table line (4 gates x the lane's 4 units) + the old cell state of block nb -> slot
     __device__ __forceinline__ void load_ops(int nb, int slot) {
-        const float *xrp = a.xg + (size_t)ew[nb] * (size_t)(4 * H) + n0 + 32 * wave + 4 * hf;
-        const float *cpp = a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+        const float *xrp = a.xg + (size_t)((WS_ABL & 16) ? 0 : ew[nb]) * (size_t)(4 * H) + n0 + 32 * wave + 4 * hf;      // (WS_ABL & 16: every operand
+        const float *cpp = a.c_in + (size_t)((WS_ABL & 16) ? 0 : ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;                     //  from one line: L2 hits)
         asm volatile("global_load_dwordx4 %0, %5, off\n\t"
                      "global_load_dwordx4 %1, %5, off offset:32\n\t"
                      "global_load_dwordx4 %2, %5, off offset:64\n\t"
@@ -163,6 +177,30 @@ struct GateWs {
                      "global_load_dwordx4 %4, %6, off"
                      : "=&v"(xg[slot][0]), "=&v"(xg[slot][1]), "=&v"(xg[slot][2]), "=&v"(xg[slot][3]), "=&v"(cp[slot])
                      : "v"(xrp), "v"(cpp) : "memory");
+    }
+    // the same into the fragment registers: set 2 = B[0][0], B[0][1], B[1][0], B[1][1], B[2][0]; set 3 = B[2][1], B[3][0], B[3][1], B[4][0], B[4][1]
+    template <int SET>
+    __device__ __forceinline__ void load_ops_b(int nb) {
+        const float *xrp = a.xg + (size_t)((WS_ABL & 16) ? 0 : ew[nb]) * (size_t)(4 * H) + n0 + 32 * wave + 4 * hf;
+        const float *cpp = a.c_in + (size_t)((WS_ABL & 16) ? 0 : ep[nb] >= 0 ? ep[nb] : 0) * ld + u0;
+        constexpr int o = SET == 2 ? 0 : 5;
+        asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                     "global_load_dwordx4 %1, %5, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %5, off offset:64\n\t"
+                     "global_load_dwordx4 %3, %5, off offset:96\n\t"
+                     "global_load_dwordx4 %4, %6, off"
+                     : "=&v"(B[(o + 0) >> 1][(o + 0) & 1]), "=&v"(B[(o + 1) >> 1][(o + 1) & 1]), "=&v"(B[(o + 2) >> 1][(o + 2) & 1]),
+                       "=&v"(B[(o + 3) >> 1][(o + 3) & 1]), "=&v"(B[(o + 4) >> 1][(o + 4) & 1])
+                     : "v"(xrp), "v"(cpp) : "memory");
+    }
+    template <int SET, int N>
+    __device__ __forceinline__ void wait_ops_b(f32x4 (&xq)[4], f32x4 &cq) {
+        constexpr int o = SET == 2 ? 0 : 5;
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(B[(o + 0) >> 1][(o + 0) & 1]), "+v"(B[(o + 1) >> 1][(o + 1) & 1]), "+v"(B[(o + 2) >> 1][(o + 2) & 1]),
+                                             "+v"(B[(o + 3) >> 1][(o + 3) & 1]), "+v"(B[(o + 4) >> 1][(o + 4) & 1]) : "n"(N) : "memory");
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) xq[g4] = __builtin_bit_cast(f32x4, B[(o + g4) >> 1][(o + g4) & 1]);
+        cq = __builtin_bit_cast(f32x4, B[(o + 4) >> 1][(o + 4) & 1]);
     }
     template <int N>
     __device__ __forceinline__ void wait_ops(int slot) {
@@ -191,7 +229,8 @@ struct GateWs {
     // its MFMA;  group 3  W_hi . B_lo[nb], B_lo[nb] refilled.  The refill is the NEXT half step's fragment (stage KT + 1 from half 1)
     template <int KT, int ST, int DMA, bool ZERO>         // DMA: stage to request behind the first MFMA (-1: none); ZERO: the tile's first half step
     __device__ __forceinline__ void half() {
-        constexpr int NKT = ST == 0 ? KT : KT + 1, NST = 1 - ST;       // the half step the refills belong to (KT + 1 = 16: next tile's stage 0)
+        constexpr int NKT = ST == 0 ? KT : KT + 1, NST = 1 - ST;       // the half step the refills belong to
+        constexpr bool REFILL = !(WS_OPS4 && KT == WS_NK - 1 && ST == 1);   // (the tile's last: the registers take epilogue operands instead)
         const f32x16 zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < WS_NB; ++nb) {
@@ -201,18 +240,18 @@ struct GateWs {
 #pragma unroll
         for (int nb = 0; nb < WS_NB; ++nb) {
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * KT + ST][0], B[nb][0], acc[nb], 0, 0, 0);
-            rdB(NKT, NST, nb, 0);
+            if constexpr (REFILL) rdB(NKT, NST, nb, 0);
         }
 #pragma unroll
         for (int nb = 0; nb < WS_NB; ++nb) {
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * KT + ST][0], B[nb][1], acc[nb], 0, 0, 0);
-            rdB(NKT, NST, nb, 1);
+            if constexpr (REFILL) rdB(NKT, NST, nb, 1);
         }
 #pragma unroll
         for (int i = 0; i < 3 * WS_NB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (i < WS_NP && DMA >= 0 && !(WS_ABL & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // (one LDS-DMA instruction behind each of the first five MFMAs)
-            if (i >= WS_NB && !(WS_ABL & 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i >= WS_NB && !(WS_ABL & 2) && REFILL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -221,8 +260,8 @@ struct GateWs {
     __device__ __forceinline__ void kstep(int m0, int m0n, bool has_next) {
         top<FIRST, KT>();
         if constexpr (KT == 0 && FIRST) JLM_WS_T(2);
-        if constexpr (KT == 0 && FIRST) {
-            // the very first fragments (stage 0 landed: it is older than stage 1)
+        if constexpr (KT == 0 && (FIRST || WS_OPS4)) {
+            // the tile's first fragments (stage 0 landed: it is older than stage 1; later tiles: both landed under the tile before)
 #pragma unroll
             for (int nb = 0; nb < WS_NB; ++nb) { rdB(0, 0, nb, 0); rdB(0, 0, nb, 1); }
         }
@@ -278,8 +317,9 @@ struct GateWs {
                 touch_line(a.c_in + (size_t)(ep[nb] >= 0 ? ep[nb] : 0) * ld + u0);
             }
         }
-        if constexpr (KT == 14) load_ops(0, 0);
-        if constexpr (KT == 15) load_ops(1, 1);
+        if constexpr (KT == ws_kx(0)) load_ops(0, 0);
+        if constexpr (KT == ws_kx(1)) load_ops(1, 1);
+        if constexpr (KT == ws_kx(2)) load_ops_b<2>(2);
         if constexpr (FIRST && KT + L + 1 < WS_NK) load_w<(KT + L + 1) & (WS_NK - 1)>();
         __builtin_amdgcn_sched_barrier(0);
         half<KT, 1, -1, false>();
@@ -289,18 +329,45 @@ struct GateWs {
     // gate `gate`, unit u0 + e, hypothesis li of block nb
     template <int NBK>
     __device__ __forceinline__ void cell() {
-        constexpr int sl = NBK & 1;
-        // younger than this block's operands: the next block's (5), and what was issued between them (stores, the block after)
-        constexpr int younger = NBK == 0 ? 10 : NBK == 1 ? 5 + WS_ST : NBK == 4 ? 2 * WS_ST : 2 * WS_ST + 5;
-        wait_ops<younger>(sl);
-        if constexpr (NBK == 0 && WS_PF >= 0) asm volatile("" : "+v"(warm));        // (in-order returns: the warming loads are older)
         f32x4 xq[4], cq;
+        if constexpr (WS_OPS4) {
+            // issue order behind k-step 14's D:  ops0 | D15 ops1 | ops2 ops3 | [cell 0: ops4, stores] [cell 1: stores] ...  (stores counted as
+            // WS_ST per block: with the f32 copy there is one more -- a smaller count only waits longer)
+            if constexpr (NBK == 0) {
+                wait_ops<WS_NP * (15 - ws_kx(0)) + 3 * 5>(0);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[sl][g4];
-        cq = cp[sl];
-        if constexpr (NBK + 2 < WS_NB) {
-            asm volatile("" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(cq));       // (copied out before the slot is requested again)
-            load_ops(NBK + 2, sl);
+                for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[0][g4];
+                cq = cp[0];
+                asm volatile("" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(cq));       // (copied out before the set is requested again)
+                load_ops(4, 0);
+            } else if constexpr (NBK == 1) {
+                wait_ops<WS_NP * (15 - ws_kx(1)) + 3 * 5 + WS_ST>(1);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[1][g4];
+                cq = cp[1];
+            } else if constexpr (NBK == 2) {
+                wait_ops_b<2, 2 * 5 + 2 * WS_ST>(xq, cq);
+            } else if constexpr (NBK == 3) {
+                wait_ops_b<3, 5 + 3 * WS_ST>(xq, cq);
+            } else {
+                wait_ops<4 * WS_ST>(0);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[0][g4];
+                cq = cp[0];
+            }
+        } else {
+            constexpr int sl = NBK & 1;
+            // younger than this block's operands: the next block's (5), and what was issued between them (stores, the block after)
+            constexpr int younger = NBK == 0 ? 10 : NBK == 1 ? 5 + WS_ST : NBK == 4 ? 2 * WS_ST : 2 * WS_ST + 5;
+            wait_ops<younger>(sl);
+            if constexpr (NBK == 0 && WS_PF >= 0) asm volatile("" : "+v"(warm));        // (in-order returns: the warming loads are older)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) xq[g4] = xg[sl][g4];
+            cq = cp[sl];
+            if constexpr (NBK + 2 < WS_NB) {
+                asm volatile("" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]), "+v"(cq));       // (copied out before the slot is requested again)
+                load_ops(NBK + 2, sl);
+            }
         }
         const float ds = a.descale;
         const int g = eok[NBK] ? eg[NBK] : -1;
@@ -333,6 +400,8 @@ struct GateWs {
         gate_for_each_ic([&](auto ktc) { this->template kstep<FIRST, decltype(ktc)::value>(m0, m0n, has_next); },
                          std::make_integer_sequence<int, WS_NK>{});
         JLM_WS_T(3 + 2 * t_no);
+        if constexpr (ws_kx(2) == 16) load_ops_b<2>(2);
+        if constexpr (ws_kx(3) == 16) load_ops_b<3>(3);
         gate_for_each_ic([&](auto nbc) { this->template cell<decltype(nbc)::value>(); }, std::make_integer_sequence<int, WS_NB>{});
         JLM_WS_T(4 + 2 * t_no);
     }
