@@ -317,7 +317,8 @@ typedef struct {
  * too but never reads the result (decoder.py:233-237).
  * max_cands >= beam * (largest number of nodes ending at one (frame, sentence)).
  * 1 <= beam <= JLM_MAX_BEAM (the reference has no limit, decoder.py:227-229); a cell's candidates live in one wave's
- * LDS: -1 when max_cands exceeds jlm_beam_step_max_cands(beam, n_frames, mode). */
+ * LDS -- in one piece up to ~13 k, above that chunk by chunk with the chunks' winners merged (round 6: same order, same result);
+ * -1 when max_cands exceeds jlm_beam_step_max_cands(beam, n_frames, mode). */
 int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host,
                   int frame, int mode, int max_cands, void *stream);
 
@@ -392,6 +393,8 @@ int jlm_vocab_lse_hybrid(const jlm_segment *segs_host, const float *t_scale, con
 /* ABI 6: the largest max_cands (a multiple of 256, as the plans round it) jlm_beam_step accepts for this beam,
  * frame count and mode -- the launcher's own LDS formula, so that callers can route sentences with a larger lattice
  * cell to a host-side search (Decoder._decode_unpruned / DynamicDecoder._decode_host) instead of failing the batch.
+ * Round 6: cells that do not fit one wave's LDS in one piece are selected chunk by chunk, so the figure is what the chunk
+ * winners leave room for (3.4 M candidates at beam 10, 0.5 M at beam 64): no real lexicon gets near it.
  * 0: no cell fits (beam or frame count too large).  Pure host function, no GPU needed. */
 int jlm_beam_step_max_cands(int beam, int n_frames, int mode);
 

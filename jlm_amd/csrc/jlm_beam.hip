@@ -480,6 +480,201 @@ __global__ __launch_bounds__(64) void beam_step_kernel(jlm_lattice lat, jlm_beam
         for (int r = lane; r < K; r += 64) st.live[(size_t)frame * rmax + base + r] = gout + r;
 }
 
+// ---- the same step for cells whose candidates do not fit one wave's LDS (round 6): the candidates are taken `cap` at a time -- keys and
+// predecessor rows of ONE chunk in LDS, the K selection rounds of the kernel above on it -- and every chunk leaves its K winners (key, global
+// candidate index, predecessor row) behind; a last selection over the chunk winners gives the frame's K.  The order is the lexicographic
+// (key, candidate index) minimum throughout, so the result is the one-chunk kernel's (and Python's stable sort) whatever the cut.  Nothing
+// here is on the decode's usual path: a cell needs more than ~13 k candidates (1 300 nodes at beam 10) to get here -- before this kernel such
+// sentences left the batch for a host-side search (Decoder._decode_unpruned with the beam, DynamicDecoder._decode_host).
+template <int MODE>
+__global__ __launch_bounds__(64) void beam_step_chunked_kernel(jlm_lattice lat, jlm_beam_state st, int frame, int cap, int nch_max) {
+    extern __shared__ __attribute__((aligned(16))) double keys[];   // [cap] | MODE 2: [n_frames*beam] | int [cap] | [beam] | int [n_frames] | winners | chunk winners
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
+    const int len = lat.sent_len[s];
+    const int fs = frame * B + s;
+    if (frame > len) { if (lane == 0) st.cnt[fs] = 0; return; }
+    const int nb = lat.end_off[fs], ne = lat.end_off[fs + 1];
+    const int gout = frame * rmax + s * beam;
+    const double INF = __longlong_as_double(0x7ff0000000000000LL);
+    double *Sarr = keys + cap;                                             // MODE 2 only
+    int *gp_of = reinterpret_cast<int *>(Sarr + (MODE == 2 ? lat.n_frames * beam : 0));
+    double *lse_new = reinterpret_cast<double *>(gp_of + ((cap + 1) & ~1));         // [beam]
+    int *cnt_s = reinterpret_cast<int *>(lse_new + beam);                           // [n_frames]
+    double *win_v = reinterpret_cast<double *>(cnt_s + ((lat.n_frames + 1) & ~1));  // [beam]
+    int *win_i = reinterpret_cast<int *>(win_v + beam);                             // [beam]
+    int *win_g = win_i + beam;                                                      // [beam]
+    double *cw_v = reinterpret_cast<double *>(win_g + beam + (beam & 1));           // [nch_max * beam] chunk winners: key,
+    int *cw_i = reinterpret_cast<int *>(cw_v + (size_t)nch_max * beam);             //   global candidate index,
+    int *cw_g = cw_i + (size_t)nch_max * beam;                                      //   predecessor row
+    int K;
+    if (frame == 0) {
+        K = 1;
+    } else {
+        const bool fused = MODE == 0 && st.lse_part != nullptr;
+        const int fprev = (frame - 1) * B + s;
+        for (int f = lane; f < frame; f += 64) cnt_s[f] = st.cnt[f * B + s];
+        const int kprev = st.cnt[fprev];
+        if (fused && kprev > 0) {
+            const int base = st.live_base[fprev];
+            const float2 *part = reinterpret_cast<const float2 *>(st.lse_part);
+            const int sub = lane & 7;
+            for (int r0 = 0; r0 < kprev; r0 += 8) {
+                const int r = r0 + (lane >> 3);
+                float m = JLM_NEG_BIG;
+                double sm = 0.0;
+                if (r < kprev)
+                    for (int p = sub; p < st.n_parts; p += 8) {
+                        const float2 v = part[(size_t)p * st.ld_part + base + r];
+                        const float mm = fmaxf(m, v.x);
+                        sm = sm * (double)expf(m - mm) + (double)v.y * (double)expf(v.x - mm);
+                        m = mm;
+                    }
+#pragma unroll
+                for (int off = 4; off >= 1; off >>= 1) {
+                    const float m2 = __shfl_xor(m, off);
+                    const double s2 = __shfl_xor(sm, off);
+                    const float mm = fmaxf(m, m2);
+                    sm = sm * (double)expf(m - mm) + s2 * (double)expf(m2 - mm);
+                    m = mm;
+                }
+                if (sub == 0 && r < kprev) {
+                    double l = (double)m + log(sm);
+                    if (!(fabs(l) < 1.0e300)) { if (st.flags) atomicOr(st.flags, 1); l = 1.0e30; }
+                    lse_new[r] = l;
+                    st.lse[(size_t)(frame - 1) * rmax + s * beam + r] = l;
+                }
+            }
+        }
+        const int C = (ne - nb) * beam;
+        if (MODE == 2) {
+            for (int f = 0; f < frame; ++f) {
+                const int c = st.cnt[f * B + s];
+                for (int l = lane; l < c; l += 64) {
+                    const int g = f * rmax + s * beam + l;
+                    const int p = st.bp[g];
+                    double S = 0.0;
+                    if (p >= 0) {
+                        const int pf = p / rmax, pk = p - pf * rmax - s * beam;
+                        S = Sarr[pf * beam + pk] + st.lse[p];
+                    }
+                    Sarr[f * beam + l] = S;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        const int nch = (C + cap - 1) / cap;               // <= nch_max: the launcher sized the chunk winners for the batch's largest cell
+        int nvalid_all = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int c_lo = ch * cap, Cc = min(C - c_lo, cap);
+            int nvalid = 0;
+            double bv = INF;
+            int bi = 0x7fffffff;                           // LOCAL candidate index inside the chunk
+            for (int lc = lane; lc < Cc; lc += 64) {
+                const int c = c_lo + lc;
+                const int n = nb + c / beam, k = c % beam;
+                const int sf = lat.node_start[n];
+                const bool ok = k < cnt_s[sf];
+                const int gp = sf * rmax + s * beam + (ok ? k : 0);
+                double sc = INF;
+                if (ok) {
+                    const double e = (double)st.edge[(size_t)n * beam + k];
+                    if (MODE == 0) sc = st.score[gp] + (((fused && sf == frame - 1) ? lse_new[k] : st.lse[gp]) - e);
+                    else if (MODE == 1) sc = st.score[gp] - e;
+                    else sc = (Sarr[sf * beam + k] + st.lse[gp]) - (st.ysum[gp] + e);
+                    ++nvalid;
+                }
+                keys[lc] = sc;
+                gp_of[lc] = ok ? gp : -1;
+                if (sc < bv) { bv = sc; bi = lc; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) nvalid += __shfl_xor(nvalid, off);
+            nvalid_all += nvalid;
+            const int Kc = min(beam, nvalid);
+            __syncthreads();                               // gp_of of other lanes' candidates
+            for (int r = 0; r < beam; ++r) {
+                if (r < Kc) {
+                    double v = bv;
+                    int i = bi;
+                    wave_argmin(v, i);                     // (local indices rise with the global ones: the same order)
+                    if (lane == 0) { cw_v[ch * beam + r] = v; cw_i[ch * beam + r] = c_lo + i; cw_g[ch * beam + r] = gp_of[i]; }
+                    if ((i & 63) == lane) {
+                        keys[i] = INF;
+                        bv = INF;
+                        bi = 0x7fffffff;
+                        for (int lc = lane; lc < Cc; lc += 64) {
+                            const double kv = keys[lc];
+                            if (kv < bv) { bv = kv; bi = lc; }
+                        }
+                    }
+                } else if (lane == 0) {
+                    cw_v[ch * beam + r] = INF; cw_i[ch * beam + r] = 0x7fffffff; cw_g[ch * beam + r] = -1;
+                }
+            }
+            __syncthreads();                               // the chunk's keys are dead: the next chunk overwrites them
+        }
+        K = min(beam, nvalid_all);
+        // ---- the frame's K out of the chunk winners: lane l owns entries l, l + 64, ...; a candidate index is unique, so the owner of
+        //      a winner is the lane whose best entry carries it
+        const int E = nch * beam;
+        double bv = INF;
+        int bi = 0x7fffffff, be = -1;
+        for (int e = lane; e < E; e += 64) {
+            const double v = cw_v[e];
+            const int i = cw_i[e];
+            if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; be = e; }
+        }
+        for (int r = 0; r < K; ++r) {
+            double v = bv;
+            int i = bi;
+            wave_argmin(v, i);
+            if (bi == i && be >= 0) {                      // this lane owns the winner
+                win_v[r] = v; win_i[r] = i; win_g[r] = cw_g[be];
+                cw_v[be] = INF; cw_i[be] = 0x7fffffff;
+                bv = INF; bi = 0x7fffffff; be = -1;
+                for (int e = lane; e < E; e += 64) {
+                    const double v2 = cw_v[e];
+                    const int i2 = cw_i[e];
+                    if (v2 < bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; be = e; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = lane; r < K; r += 64) {
+        const int g = gout + r;
+        if (frame == 0) {
+            st.score[g] = 0.0;
+            if (st.ysum) st.ysum[g] = 0.0;
+            st.bp[g] = -1;
+            st.node[g] = nb;
+            st.word[g] = lat.node_word[nb];
+        } else {
+            const int wi = win_i[r];
+            const int n = nb + wi / beam, k = wi % beam;
+            const int gp = win_g[r];
+            st.score[g] = win_v[r];
+            if (MODE == 2) st.ysum[g] = st.ysum[gp] + (double)st.edge[(size_t)n * beam + k];
+            st.bp[g] = gp;
+            st.node[g] = n;
+            st.word[g] = lat.node_word[n];
+        }
+    }
+    int base = 0;
+    if (lane == 0) {
+        st.cnt[fs] = K;
+        if (frame < len) {
+            base = atomicAdd(&st.n_live[frame], K);
+            if (st.live_base) st.live_base[fs] = base;
+        }
+    }
+    base = __shfl(base, 0);
+    if (frame < len)
+        for (int r = lane; r < K; r += 64) st.live[(size_t)frame * rmax + base + r] = gout + r;
+}
+
 // LDS of one sentence's wave: keys [max_cands] f64 | mode 2: S [n_frames x beam] f64 | predecessor rows [max_cands] i32 |
 // folded log-normalisers [beam] f64 | the sentence's counts [n_frames] i32 | winners [beam] f64 + [beam] i32
 static size_t beam_step_lds_bytes(int beam, int n_frames, int mode, int max_cands) {
@@ -488,17 +683,45 @@ static size_t beam_step_lds_bytes(int beam, int n_frames, int mode, int max_cand
            (size_t)beam * (sizeof(double) + sizeof(int)) + 8;
 }
 
-// Largest max_cands (candidates of one (frame, sentence) cell = nodes ending there x beam, as the plans round it: a
-// multiple of 256) that jlm_beam_step accepts for this beam / frame count / mode; 0: none.  Callers route sentences with a
-// larger cell to their host-side search instead of failing the batch (jlm_amd/decoder.py, decoder_dynamic.py).
-extern "C" int jlm_beam_step_max_cands(int beam, int n_frames, int mode) {
-    if (beam < 1 || beam > JLM_MAX_BEAM || n_frames < 1 || mode < 0 || mode > 2) return 0;
+// the chunked kernel's: keys / predecessor rows of one chunk [cap], the chunk winners [nch x beam] (f64 + 2 x i32), one more i32 per rank
+static size_t beam_step_chunked_lds_bytes(int beam, int n_frames, int mode, int cap, int nch) {
+    return beam_step_lds_bytes(beam, n_frames, mode, cap) + (size_t)(beam + (beam & 1)) * sizeof(int) +
+           (size_t)nch * beam * (sizeof(double) + 2 * sizeof(int));
+}
+// chunk size of the chunked kernel: half of what one wave's LDS would hold in one piece, the other half is for the chunk winners
+static int beam_step_chunk_cap(int beam, int n_frames, int mode) {
+    const size_t fixed = beam_step_lds_bytes(beam, n_frames, mode, 0);
+    if (fixed + 256 * 12 > 160 * 1024) return 0;
+    size_t c = (160 * 1024 - fixed) / 12 / 2;
+    return (int)(c / 256 * 256);
+}
+static int beam_step_one_chunk_max(int beam, int n_frames, int mode) {
     const size_t fixed = beam_step_lds_bytes(beam, n_frames, mode, 0);
     if (fixed + 256 * 12 > 160 * 1024) return 0;
     size_t c = (160 * 1024 - fixed) / 12;
     c = c / 256 * 256;
     while (c > 0 && beam_step_lds_bytes(beam, n_frames, mode, (int)c) > 160 * 1024) c -= 256;
     return (int)c;
+}
+
+// Largest max_cands (candidates of one (frame, sentence) cell = nodes ending there x beam, as the plans round it: a
+// multiple of 256) that jlm_beam_step accepts for this beam / frame count / mode; 0: none.  Round 6: cells above what one wave's
+// LDS holds in one piece (~13 k candidates at beam 10) are selected chunk by chunk (beam_step_chunked_kernel), so the figure is what
+// the chunk winners leave room for -- hundreds of thousands at beam 10, capped at 2^22.  Callers still route sentences with a larger cell
+// to their host-side search instead of failing the batch (jlm_amd/decoder.py, decoder_dynamic.py).
+extern "C" int jlm_beam_step_max_cands(int beam, int n_frames, int mode) {
+    if (beam < 1 || beam > JLM_MAX_BEAM || n_frames < 1 || mode < 0 || mode > 2) return 0;
+    const int one = beam_step_one_chunk_max(beam, n_frames, mode);
+    const int cap = beam_step_chunk_cap(beam, n_frames, mode);
+    if (one <= 0) return 0;
+    if (cap <= 0) return one;
+    const size_t base = beam_step_chunked_lds_bytes(beam, n_frames, mode, cap, 0);
+    if (base >= 160 * 1024) return one;
+    const size_t nch = (160 * 1024 - base) / ((size_t)beam * 16);
+    size_t total = nch * (size_t)cap;
+    if (total > (1u << 22)) total = 1u << 22;
+    total = total / 256 * 256;
+    return total > (size_t)one ? (int)total : one;
 }
 
 extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int frame, int mode,
@@ -512,7 +735,25 @@ extern "C" int jlm_beam_step(const jlm_lattice *lat_host, const jlm_beam_state *
     if (st.lse_part && (!st.live_base || st.n_parts < 1 || mode != 0)) return -1;
     if (max_cands < 1) max_cands = 1;
     const size_t lds = beam_step_lds_bytes(lat.beam, lat.n_frames, mode, max_cands);
-    if (lds > 160 * 1024) return -1;
+    // JLM_BEAM_CHUNK=<candidates>: every launch through the chunked kernel with that chunk size (tests: ordinary cells in several chunks)
+    static const int chunk_env = getenv("JLM_BEAM_CHUNK") ? atoi(getenv("JLM_BEAM_CHUNK")) : 0;
+    if (lds > 160 * 1024 || chunk_env > 0) {
+        const int cap = chunk_env > 0 ? chunk_env : beam_step_chunk_cap(lat.beam, lat.n_frames, mode);
+        if (cap <= 0) return -1;
+        const int nch = (max_cands + cap - 1) / cap;
+        const size_t lds_c = beam_step_chunked_lds_bytes(lat.beam, lat.n_frames, mode, cap, nch);
+        if (lds_c > 160 * 1024) return -1;
+        const void *fc = mode == 0 ? (const void *)beam_step_chunked_kernel<0>
+                       : mode == 1 ? (const void *)beam_step_chunked_kernel<1> : (const void *)beam_step_chunked_kernel<2>;
+        static JlmLdsGrant grant_c[3];
+        if (lds_c > 64 * 1024)
+            if (int rc = jlm_grant_lds(grant_c[mode], fc, (int)lds_c)) return rc;
+        if (mode == 0) hipLaunchKernelGGL(beam_step_chunked_kernel<0>, dim3(lat.n_sent), dim3(64), lds_c, (hipStream_t)stream, lat, st, frame, cap, nch);
+        else if (mode == 1) hipLaunchKernelGGL(beam_step_chunked_kernel<1>, dim3(lat.n_sent), dim3(64), lds_c, (hipStream_t)stream, lat, st, frame, cap, nch);
+        else hipLaunchKernelGGL(beam_step_chunked_kernel<2>, dim3(lat.n_sent), dim3(64), lds_c, (hipStream_t)stream, lat, st, frame, cap, nch);
+        JLM_LAUNCH_CHECK();
+        return 0;
+    }
     const void *fn = mode == 0 ? (const void *)beam_step_kernel<0>
                    : mode == 1 ? (const void *)beam_step_kernel<1> : (const void *)beam_step_kernel<2>;
     static JlmLdsGrant grant[3];

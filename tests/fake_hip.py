@@ -95,15 +95,26 @@ class FakeLib:
                                          None, stream)
 
     def jlm_beam_step_max_cands(self, beam, n_frames, mode):
-        """the launcher's LDS formula (csrc/jlm_beam.hip, beam_step_lds_bytes)"""
+        """the launcher's LDS formulas (csrc/jlm_beam.hip: beam_step_lds_bytes, and from round 6 the chunked kernel's -- cells above what one
+        wave's LDS holds in one piece are selected chunk by chunk, the figure is what the chunk winners leave room for)"""
         if beam < 1 or beam > 1024 or n_frames < 1 or mode not in (0, 1, 2):
             return 0
         lds = lambda c: (c * 8 + (n_frames * beam * 8 if mode == 2 else 0) + ((c + 1) & ~1) * 4 + beam * 8 +
                          ((n_frames + 1) & ~1) * 4 + beam * 12 + 8)
+        if lds(0) + 256 * 12 > 160 * 1024:
+            return 0
         c = (160 * 1024 - lds(0)) // 12 // 256 * 256
         while c > 0 and lds(c) > 160 * 1024:
             c -= 256
-        return max(c, 0)
+        one = max(c, 0)
+        cap = (160 * 1024 - lds(0)) // 12 // 2 // 256 * 256
+        if one <= 0 or cap <= 0:
+            return one
+        base = lds(cap) + (beam + (beam & 1)) * 4
+        if base >= 160 * 1024:
+            return one
+        total = min((160 * 1024 - base) // (beam * 16) * cap, 1 << 22) // 256 * 256
+        return max(total, one)
 
     # ------------------------------------------------------- the frame loop (ABI 3)
     def jlm_decode_frames(self, m, p, lat, st, stream, side_stream, events=None):

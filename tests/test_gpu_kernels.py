@@ -126,6 +126,23 @@ def _pack(L, src_g, k, scale, ld_dst=None, dst=None, col0=0, src_col0=0):
     return dst
 
 
+@pytest.mark.parametrize("chunk", ["48", "256"])
+def test_beam_step_chunked_on_ordinary_cells(chunk):
+    """JLM_BEAM_CHUNK: every beam step through the chunked kernel (csrc/jlm_beam.hip beam_step_chunked_kernel) with chunks of 48 / 256
+    candidates, so that ordinary cells are cut into several -- the kernel tests of all three modes incl. the fused fold of the vocabulary
+    partials, and the decodes whose per-frame beams the reference's traces pin (static, vocabulary selection, incremental).  The
+    variable is read once per process, hence the child."""
+    import os, subprocess, sys
+    env = dict(os.environ, JLM_BEAM_CHUNK=chunk)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_gpu_decode.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "(test_beam_step_and_backtrace or test_beam_step_fused_combine or test_per_frame_beams_match_reference_traces)"
+                              " and not 64-6-300"],        # (19 k candidates in chunks of 48: more chunk winners than LDS)
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
+
+
 @pytest.mark.parametrize("variant", ["2", "3", "4"])
 def test_lstm_step_xg_forced_forms(variant):
     """Every H = 512 form of the LSTM step on every row count of test_lstm_step_xg, whatever the launcher would pick by the row bound:
@@ -639,9 +656,14 @@ def _run_beam(lib, P, mode, cuda, rng_seed):
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("B,beam,F,max_nodes", [(7, 10, 9, 12), (64, 3, 6, 40), (3, 20, 22, 70)])
+@pytest.mark.parametrize("B,beam,F,max_nodes", [(7, 10, 9, 12), (64, 3, 6, 40), (3, 20, 22, 70),
+                                                # cells above what one wave's LDS holds in one piece (13 312 candidates at beam 64): the
+                                                # chunked kernel (round 6) -- before it such sentences left the batch for a host-side search
+                                                (3, 64, 6, 300)])
 def test_beam_step_and_backtrace(L, mode, B, beam, F, max_nodes):
     P = _beam_problem(np.random.default_rng(B * 100 + beam + F), B, beam, F, max_nodes)
+    if max_nodes >= 300:
+        assert P["max_cands"] > 13312 and L.jlm_beam_step_max_cands(beam, F, mode) > P["max_cands"]
     want = _run_beam(FK, P, mode, False, 5)
     got = _run_beam(L, P, mode, True, 5)
     np.testing.assert_array_equal(got["cnt"], want["cnt"])
