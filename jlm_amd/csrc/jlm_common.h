@@ -49,6 +49,12 @@ __device__ __forceinline__ float jlm_tanh(float x) {
     return fmaf(2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -2.8853900817779268f) + 1.0f), -1.0f);
 }
 
+// The same with the pre-activation's scale folded into the exponent's: sigma(x * ds) = 1 / (1 + 2^(x * ks)), ks = ds * -log2(e), and
+// tanh(x * ds) with kt = 2 ks.  The LSTM-step kernels' ds is a power of two (2^-S: jlm_amd/model.py gate_descale), so ds * c is c with another
+// exponent and x * (ds * c) rounds exactly as (x * ds) * c did: bit-identical results, one multiply less per gate (hipcc cannot know).
+__device__ __forceinline__ float jlm_sigmoid_k(float x, float ks) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * ks) + 1.0f); }
+__device__ __forceinline__ float jlm_tanh_k(float x, float kt) { return fmaf(2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * kt) + 1.0f), -1.0f); }
+
 // online log-sum-exp pair merge: (m, s) <- (m, s) (+) (m2, s2); empty = (NEG_BIG, 0)
 __device__ __forceinline__ void lse_merge(float &m, float &s, float m2, float s2) {
     float mm = fmaxf(m, m2);

@@ -333,7 +333,7 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
 
     // ---- cell update in registers: acc[4 gate + e] + table = pre-activation (x 1 / descale) of gate `gate`, unit u0 + e,
     //      hypothesis li
-    const float ds = a.descale;
+    const float ks = a.descale * -1.4426950408889634f, kt = a.descale * -2.8853900817779268f;      // (jlm_common.h: exact for ds = 2^-S)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int g = eok[nb] ? eg[nb] : -1;
@@ -341,8 +341,8 @@ __device__ __forceinline__ void gate_xg_body(const GateXgArgs &a, const int m0, 
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
-            const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
+            const float gi = jlm_sigmoid_k(acc[nb][e] + xg[nb][0][e], ks), gf = jlm_sigmoid_k(acc[nb][4 + e] + xg[nb][1][e], ks);
+            const float go = jlm_sigmoid_k(acc[nb][8 + e] + xg[nb][2][e], ks), gg = jlm_tanh_k(acc[nb][12 + e] + xg[nb][3][e], kt);
             cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
             hn[e] = jlm_tanh(cn[e]) * go;
         }
@@ -606,7 +606,7 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
     JLM_GT_T(3);
     wait_epilogue_operands();
 
-    const float ds = a.descale;
+    const float ks = a.descale * -1.4426950408889634f, kt = a.descale * -2.8853900817779268f;      // (jlm_common.h: exact for ds = 2^-S)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int g = eok[nb] ? eg[nb] : -1;
@@ -614,8 +614,8 @@ __device__ __forceinline__ void gate_xg_body_u(const GateXgArgs &a, const int m0
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
-            const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
+            const float gi = jlm_sigmoid_k(acc[nb][e] + xg[nb][0][e], ks), gf = jlm_sigmoid_k(acc[nb][4 + e] + xg[nb][1][e], ks);
+            const float go = jlm_sigmoid_k(acc[nb][8 + e] + xg[nb][2][e], ks), gg = jlm_tanh_k(acc[nb][12 + e] + xg[nb][3][e], kt);
             cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
             hn[e] = jlm_tanh(cn[e]) * go;
         }
@@ -895,15 +895,15 @@ struct GatePu {
         // the epilogue operands: requested at k-step xg_at <= 12 -- at least the three stages of k-steps 13 .. 15 are younger
         wait_ops<3 * NP>();
         JLM_PU_T(2);
-        const float ds = a.descale;
+        const float ks = a.descale * -1.4426950408889634f, kt = a.descale * -2.8853900817779268f;      // (jlm_common.h: exact for ds = 2^-S)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int g = eok[nb] ? eg[nb] : -1;
             f32x4 cn, hn;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float gi = jlm_sigmoid((acc[nb][e] + xg[nb][0][e]) * ds), gf = jlm_sigmoid((acc[nb][4 + e] + xg[nb][1][e]) * ds);
-                const float go = jlm_sigmoid((acc[nb][8 + e] + xg[nb][2][e]) * ds), gg = jlm_tanh((acc[nb][12 + e] + xg[nb][3][e]) * ds);
+                const float gi = jlm_sigmoid_k(acc[nb][e] + xg[nb][0][e], ks), gf = jlm_sigmoid_k(acc[nb][4 + e] + xg[nb][1][e], ks);
+                const float go = jlm_sigmoid_k(acc[nb][8 + e] + xg[nb][2][e], ks), gg = jlm_tanh_k(acc[nb][12 + e] + xg[nb][3][e], kt);
                 cn[e] = (ep[nb] >= 0 ? cp[nb][e] : 0.0f) * gf + gg * gi;
                 hn[e] = jlm_tanh(cn[e]) * go;
             }

@@ -283,14 +283,14 @@ struct GateP2 {
         constexpr int j = BK >> 1, i = BK & 1;
         wait_ops<p2_clamp(p2_cell(LATE, BK, ST))>(BK);
         if constexpr (BK == 0) JLM_P2_T(2);
-        const float ds = a.descale;
+        const float ks = a.descale * -1.4426950408889634f, kt = a.descale * -2.8853900817779268f;      // (jlm_common.h: exact for ds = 2^-S)
         const int g = eok[i] ? eg[i] : -1;
         const int u0 = (n0 >> 2) + 8 * (2 * gp + j) + 4 * hf;
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid((acc[j][i][e] + xg[BK][0][e]) * ds), gf = jlm_sigmoid((acc[j][i][4 + e] + xg[BK][1][e]) * ds);
-            const float go = jlm_sigmoid((acc[j][i][8 + e] + xg[BK][2][e]) * ds), gg = jlm_tanh((acc[j][i][12 + e] + xg[BK][3][e]) * ds);
+            const float gi = jlm_sigmoid_k(acc[j][i][e] + xg[BK][0][e], ks), gf = jlm_sigmoid_k(acc[j][i][4 + e] + xg[BK][1][e], ks);
+            const float go = jlm_sigmoid_k(acc[j][i][8 + e] + xg[BK][2][e], ks), gg = jlm_tanh_k(acc[j][i][12 + e] + xg[BK][3][e], kt);
             cn[e] = (ep[i] >= 0 ? cp[BK][e] : 0.0f) * gf + gg * gi;
             hn[e] = jlm_tanh(cn[e]) * go;
         }

@@ -369,13 +369,13 @@ struct GateWs {
                 load_ops(NBK + 2, sl);
             }
         }
-        const float ds = a.descale;
+        const float ks = a.descale * -1.4426950408889634f, kt = a.descale * -2.8853900817779268f;      // (jlm_common.h: exact for ds = 2^-S)
         const int g = eok[NBK] ? eg[NBK] : -1;
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gi = jlm_sigmoid((acc[NBK][e] + xq[0][e]) * ds), gf = jlm_sigmoid((acc[NBK][4 + e] + xq[1][e]) * ds);
-            const float go = jlm_sigmoid((acc[NBK][8 + e] + xq[2][e]) * ds), gg = jlm_tanh((acc[NBK][12 + e] + xq[3][e]) * ds);
+            const float gi = jlm_sigmoid_k(acc[NBK][e] + xq[0][e], ks), gf = jlm_sigmoid_k(acc[NBK][4 + e] + xq[1][e], ks);
+            const float go = jlm_sigmoid_k(acc[NBK][8 + e] + xq[2][e], ks), gg = jlm_tanh_k(acc[NBK][12 + e] + xq[3][e], kt);
             cn[e] = (ep[NBK] >= 0 ? cq[e] : 0.0f) * gf + gg * gi;
             hn[e] = jlm_tanh(cn[e]) * go;
         }
