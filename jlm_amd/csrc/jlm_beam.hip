@@ -787,12 +787,74 @@ __global__ void backtrace_kernel(jlm_lattice lat, jlm_beam_state st, int *out_no
     out_len[idx] = d;
 }
 
+// Round 6: one WAVE per sentence.  The thread-per-path walk above is a chain of (sentence length + 1) dependent global loads per path
+// (12 us per batch at the headline shape).  A sentence's whole back-pointer table is small -- (length + 1) x beam rows, 210 at the headline
+// shape -- so the wave loads it ONCE (row e = frame x beam + rank in lane e % 64, register e / 64: node id and predecessor as a local row
+// number), one round trip, and lane r then walks path r through the other lanes' registers with wavefront shuffles (ds_bpermute), no memory
+// in the loop; the node ids are stored as they are met.  Shapes it hosts: beam <= 64 (a lane per path), n_frames x beam <= 64 NREG.
+template <int NREG>
+__global__ __launch_bounds__(64) void backtrace_wave_kernel(jlm_lattice lat, jlm_beam_state st, int *out_nodes, int *out_len, double *out_score,
+                                                            int stride) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int B = lat.n_sent, beam = lat.beam, rmax = B * beam;
+    const int len = lat.sent_len[s];
+    const int E = (len + 1) * beam;
+    int nd[NREG], pl[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const int e = lane + 64 * j;
+        const int f = e / beam, k = e - f * beam;
+        const bool in = e < E;
+        const size_t g = (size_t)(in ? f : 0) * rmax + s * beam + (in ? k : 0);
+        // (rows past a frame's count hold whatever an earlier batch left there: no surviving path points at them)
+        const int n = st.node[g], p = st.bp[g];
+        nd[j] = in ? n : -1;
+        int q = -1;
+        if (in && p >= 0) { const int pf = p / rmax; q = pf * beam + (p - pf * rmax - s * beam); }
+        pl[j] = q;
+    }
+    const int c = st.cnt[len * B + s];
+    const bool valid = lane < beam && lane < c;
+    const int idx = s * beam + lane;
+    int e = valid ? len * beam + lane : -1, d = 0;
+    const int steps = min(stride, len + 1);              // (a path visits every frame at most once)
+    for (int t = 0; t < steps; ++t) {
+        const int src = e & 63, jr = e >> 6;             // every lane takes part in the shuffles, whatever its own state
+        int nv = -1, pv = -1;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            const int a = __shfl(nd[j], src), b2 = __shfl(pl[j], src);
+            if (jr == j) { nv = a; pv = b2; }
+        }
+        if (e >= 0) {
+            out_nodes[(size_t)idx * stride + d] = nv;
+            ++d;
+            e = pv;
+        }
+    }
+    if (lane < beam) {
+        out_len[idx] = valid ? d : 0;
+        out_score[idx] = valid ? st.score[(size_t)len * rmax + s * beam + lane] : 0.0;
+    }
+}
+
 extern "C" int jlm_backtrace(const jlm_lattice *lat_host, const jlm_beam_state *st_host, int *out_nodes, int *out_len,
                              double *out_score, int stride, void *stream) {
     const jlm_lattice lat = *lat_host;
     const jlm_beam_state st = *st_host;
     const int total = lat.n_sent * lat.beam;
     if (total <= 0) return 0;
+    // JLM_BACKTRACE_WAVE=0: the thread-per-path kernel for every shape (A/B, tests)
+    static const int wave_env = getenv("JLM_BACKTRACE_WAVE") ? atoi(getenv("JLM_BACKTRACE_WAVE")) : 1;
+    const long rows = (long)lat.n_frames * lat.beam;
+    if (wave_env && lat.beam <= 64 && rows <= 64 * 16) {
+        const dim3 grid(lat.n_sent), block(64);
+        if (rows <= 64 * 4) hipLaunchKernelGGL(backtrace_wave_kernel<4>, grid, block, 0, (hipStream_t)stream, lat, st, out_nodes, out_len, out_score, stride);
+        else if (rows <= 64 * 8) hipLaunchKernelGGL(backtrace_wave_kernel<8>, grid, block, 0, (hipStream_t)stream, lat, st, out_nodes, out_len, out_score, stride);
+        else hipLaunchKernelGGL(backtrace_wave_kernel<16>, grid, block, 0, (hipStream_t)stream, lat, st, out_nodes, out_len, out_score, stride);
+        JLM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(backtrace_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, lat, st,
                        out_nodes, out_len, out_score, stride);
     JLM_LAUNCH_CHECK();
